@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark: structures/s of GNN polarizability evaluation on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path -- ``PotGNN.calc_polarizabilities`` on one batch of
+synthetic MD frames already resident in HBM -- plus, for N > 1, the single all-gather of
+per-frame polarizabilities.  Workload = BASELINE.json configs[1]: 128-atom rocksalt cell
+(cutoff 3.2 A: E = 2304 directed edges, T = 39168 triplets), 1000 frames per GPU, perf
+widths Fn = Fe = 64, P = 4.  Weak scaling: every rank evaluates its
+own 1000 frames.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HPARAMS = {
+    # name: (Fn, Fe, P)
+    "perf": (64, 64, 4),
+    "parity": (5, 14, 4),  # the only documented set (machine-learning.ipynb:187-192)
+}
+EDGE_AGG_KERNEL_ID = 7  # index of "edge_agg" in rn_potgnn_kernel_times / csrc/api.hip
+LIGHT_CM_PER_FS = 2.99792458e-5
+
+
+# ----------------------------------------------------------------------------- workload
+def rocksalt(nx, ny, nz, a=4.2):
+    """Rocksalt supercell: Z=12 on even-parity sites, Z=8 on odd."""
+    pos, zs = [], []
+    for ix in range(2 * nx):
+        for iy in range(2 * ny):
+            for iz in range(2 * nz):
+                pos.append([ix / (2.0 * nx), iy / (2.0 * ny), iz / (2.0 * nz)])
+                zs.append(12 if (ix + iy + iz) % 2 == 0 else 8)
+    lattice = np.diag([nx * a, ny * a, nz * a]).astype(np.float64)
+    return lattice, np.array(pos), zs
+
+
+def md_frames(rng, lattice, ref, frames, amplitude=0.05, dt_fs=1.0, t0=0):
+    """Bounded per-atom sinusoids (A = 0.05 A, 100-800 cm^-1): no neighbour crosses the
+    cutoff shell, and the MD spectrum is structured."""
+    n = ref.shape[0]
+    nu = rng.uniform(100.0, 800.0, (1, n, 3))
+    phi = rng.uniform(0.0, 2 * np.pi, (1, n, 3))
+    t = (t0 + np.arange(frames))[:, None, None] * dt_fs
+    cart = amplitude * np.cos(2 * np.pi * LIGHT_CM_PER_FS * nu * t + phi)
+    x = ref[None] + cart / np.diag(lattice)[None, None, :]
+    return x - np.floor(x)
+
+
+def synthetic_state(model, seed):
+    """Notebook-style init (weights ~ N(0,1), Linear bias ~ U(-0.5,0.5)) + non-trivial
+    LayerNorm / BatchNorm statistics."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if not v.is_floating_point() or k == "_edge_embedding.offset":
+            continue
+        norm = "norm" in k or "_to_polarizability_embedding.1." in k
+        if k.endswith("running_mean"):
+            v.copy_(torch.randn(v.shape, generator=gen) * 0.3)
+        elif k.endswith("running_var"):
+            v.copy_(torch.rand(v.shape, generator=gen) + 0.5)
+        elif norm and k.endswith("weight"):
+            v.copy_(torch.rand(v.shape, generator=gen) + 0.5)
+        elif norm and k.endswith("bias"):
+            v.copy_(torch.rand(v.shape, generator=gen) * 0.6 - 0.3)
+        elif k.endswith("bias"):
+            v.copy_(torch.rand(v.shape, generator=gen) - 0.5)
+        else:
+            v.copy_(torch.randn(v.shape, generator=gen))
+    return sd
+
+
+def make_workload(num_cells=(4, 2, 2), frames=1000, hparams="perf", seed=22, t0=0):
+    from ramannoodle_amd.pmodel import PotGNN
+    from ramannoodle_amd.structure import ReferenceStructure
+
+    fn, fe, passes = HPARAMS[hparams]
+    lattice, ref, zs = rocksalt(*num_cells)
+    rng = np.random.default_rng(seed)
+    positions = md_frames(rng, lattice, ref, frames, t0=t0)
+    sym = rng.normal(size=(3, 3))
+    mean = (sym + sym.T) + np.diag([30.0, 31.0, 29.0])
+    std = np.abs(rng.normal(size=(3, 3)))
+    std = (std + std.T) * 0.5 + 0.2
+    structure = ReferenceStructure(zs, lattice, ref)
+    cutoff = 3.2
+    state = {}
+
+    def build(**kw):
+        torch.manual_seed(7)
+        model = PotGNN(structure, cutoff, fn, fe, passes, 0.0, 5.0, mean, std, **kw)
+        if not state:
+            state.update(synthetic_state(model, 7))
+        model.load_state_dict(state)
+        return model
+
+    def build_oracle():
+        from oracle import potgnn_oracle as O  # checker / CPU baseline only
+        if not state:
+            build()
+        edges, trip, tmap = O.build_topology(lattice, ref, zs, cutoff)
+        proto = build()
+        return O.OracleModel(lattice, np.array(zs), edges, trip, tmap,
+                             {k: v.clone() for k, v in state.items()}, proto.gauss_coefficient,
+                             fn, fe, passes, mean, std)
+
+    return dict(model=build, oracle=build_oracle, positions=positions, lattice=lattice,
+                num_atoms=len(zs), hparams=(fn, fe, passes))
+
+
+# ----------------------------------------------------------------------------- roofline
+def algorithmic_bytes_edge_block(n, e, fn, fe):
+    """B_EB per structure and pass: 4 (N Fn + 2 E Fe)."""
+    return 4 * (n * fn + 2 * e * fe)
+
+
+def cpu_baseline(workload, sample):
+    """The oracle's faithful restatement of the reference CPU path, on `sample` frames."""
+    from oracle import potgnn_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    model = workload["oracle"]()
+    pos = workload["positions"][:sample]
+    O.calc_polarizabilities(model, pos[:2])  # warm-up
+    t0 = time.perf_counter()
+    O.calc_polarizabilities(model, pos, faithful=True)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "structures/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} frames of the same workload, oracle faithful variant "
+                      f"(100-frame sub-batches, N^2 geometry, O(S^2 E) readout), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
+    ap.add_argument("--cells", type=str, default="4,2,2")
+    ap.add_argument("--hparams", choices=list(HPARAMS), default="perf")
+    ap.add_argument("--cpu-sample", type=int, default=100)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--profile-all", action="store_true",
+                    help="HIP-event timing of every kernel (perturbs the timed region)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    cells = tuple(int(c) for c in args.cells.split(","))
+    wl = make_workload(cells, args.frames, args.hparams, seed=22 + rank, t0=rank * args.frames)
+    model = wl["model"](device=local, max_chunk_structures=args.chunk)
+    n, e = model.num_atoms, model.num_edges
+    fn, fe, passes = wl["hparams"]
+    pos = torch.tensor(wl["positions"], device="cuda")
+    out = torch.empty((args.frames, 3, 3), dtype=torch.float64, device="cuda")
+    gathered = torch.empty((world * args.frames, 3, 3), dtype=torch.float64, device="cuda")
+
+    def step():
+        model.calc_polarizabilities_device(pos, out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    model.set_profiling(1 if args.profile_all else 100 + EDGE_AGG_KERNEL_ID)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    times = model.kernel_times()
+    model.set_profiling(0)
+
+    if rank == 0:
+        agg_ms, agg_launches = times.get("edge_agg", (0.0, 0))
+        total_bytes = algorithmic_bytes_edge_block(n, e, fn, fe) * args.frames * passes * args.steps
+        achieved = total_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
+        peak = 8000.0
+        result = {
+            "metric": "structures/sec (GNN polarizability eval)",
+            "value": world * args.frames * args.steps / elapsed,
+            "unit": "structures/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"PotGNN eval, rocksalt {cells[0]}x{cells[1]}x{cells[2]} "
+                            f"({n} atoms, E={e}, cutoff 3.2 A), {args.frames} MD frames per GPU, "
+                            f"Fn={fn} Fe={fe} P={passes}",
+                "frames_per_gpu": args.frames,
+                "hparams": args.hparams,
+                "parallelism": f"frames sharded x{world}, one all-gather of alpha" if world > 1
+                               else "single GPU",
+            },
+            "roofline": {
+                "kernel": "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "GB/s",
+                "frac": achieved / peak if achieved else None,
+                "traffic": None,
+                "launches": agg_launches,
+                "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
+                "algorithmic_bytes_per_structure_pass": algorithmic_bytes_edge_block(n, e, fn, fe),
+            },
+        }
+        if args.profile_all:
+            result["kernel_ms"] = {k: round(v[0], 3) for k, v in times.items()}
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, args.frames))
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/*
+ * rn_potgnn.h -- C ABI of the MI355X (gfx950) PotGNN polarizability evaluator.
+ *
+ * This is the drop-in boundary for ONE path of wolearyc/ramannoodle: batched evaluation
+ * of the PotGNN polarizability model.  The reference has no FFI of its own (it is pure
+ * Python); each entry point below names the reference interface it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, no torch types; all pointers are caller-owned unless stated otherwise.
+ *   - every function returns RN_OK (0) or a negative rn_status; rn_potgnn_last_error()
+ *     gives a human-readable message for the most recent failure on that handle
+ *     (or the most recent rn_potgnn_create failure when the handle is NULL).
+ *   - a handle is immutable after create; evaluation calls on one handle must be
+ *     serialised by the caller (they share the handle's device workspace).
+ *   - "host" entry points take host buffers and include PCIe transfers;
+ *     "device" entry points take device (HBM) pointers and a hipStream_t (as void*).
+ */
+#ifndef RN_POTGNN_H
+#define RN_POTGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rn_status {
+  RN_OK = 0,
+  RN_ERR_INVALID_ARGUMENT = -1, /* mapped to ValueError by the Python wrapper          */
+  RN_ERR_UNSUPPORTED = -2,      /* e.g. embedding size > 128                            */
+  RN_ERR_NO_DEVICE = -3,        /* no gfx950 device / HIP runtime failure at init       */
+  RN_ERR_HIP = -4,              /* a HIP call failed; see rn_potgnn_last_error          */
+  RN_ERR_OUT_OF_MEMORY = -5
+} rn_status;
+
+typedef struct rn_potgnn rn_potgnn; /* opaque */
+
+/*
+ * Model description handed to rn_potgnn_create.  Replaces the state that
+ * PotGNN.__init__ builds (ramannoodle/pmodel/torch/_gnn.py:484-539).
+ */
+typedef struct rn_potgnn_config {
+  int32_t num_atoms;            /* N                                                    */
+  int32_t num_edges;            /* E  directed edges of the frozen reference graph      */
+  int32_t num_atom_types;       /* K  rows of the Embedding (_gnn.py:503,509)           */
+  int32_t size_node_embedding;  /* Fn (1..128)                                          */
+  int32_t size_edge_embedding;  /* Fe (1..128)                                          */
+  int32_t num_message_passes;   /* P                                                    */
+  double gauss_coefficient;     /* -0.5/(mu1-mu0)^2 as the reference computed it
+                                   (_gnn.py:64); the mu grid itself is the
+                                   "_edge_embedding.offset" buffer inside `weights`     */
+  int32_t max_chunk_structures; /* 0 = choose automatically; else structures per device
+                                   work chunk (workspace is sized from it)              */
+  int32_t device;               /* HIP device ordinal                                   */
+} rn_potgnn_config;
+
+/* Number of floats rn_potgnn_create expects in `weights` for this configuration. */
+size_t rn_potgnn_weight_count(const rn_potgnn_config *cfg);
+
+/*
+ * Create an evaluator.
+ *   edge_a, edge_b  int32[E]  reference-graph edges (a -> b), sorted by (a, b), exactly
+ *                             rows 1 and 2 of PotGNN._ref_edge_indexes
+ *                             (_gnn.py:492-496, _utils.py:137).  The edge triplets
+ *                             (_utils.py:153-168) are a pure function of this list and
+ *                             are enumerated on the device; see
+ *                             rn_potgnn_debug_triplets.
+ *   atom_types      int32[N]  _atom_type_map[atomic_numbers] (_gnn.py:502-506,557)
+ *   lattice         f64[3*3]  row-major, rows are lattice vectors (Angstrom)
+ *   weights         f32[rn_potgnn_weight_count]  the floating-point entries of
+ *                             PotGNN.state_dict() concatenated in state_dict order,
+ *                             each tensor row-major in its native torch layout
+ *                             (SURVEY.md section 8b lists the keys; the integer
+ *                             "num_batches_tracked" entry is skipped)
+ *   mean, stddev    f64[3*3]  _mean_polarizability / _stddev_polarizability
+ */
+int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a,
+                     const int32_t *edge_b, const int32_t *atom_types,
+                     const double *lattice, const float *weights, size_t num_weights,
+                     const double *mean, const double *stddev, rn_potgnn **out);
+
+/* Releases device memory and streams owned by the handle.  NULL is allowed. */
+void rn_potgnn_destroy(rn_potgnn *h);
+
+/*
+ * Replaces PotGNN.calc_polarizabilities (_gnn.py:667-721).
+ *   positions  host f64[S*N*3]  fractional coordinates, C-contiguous, not modified
+ *   alpha      host f64[S*3*3]  de-standardised symmetric tensors (alpha*sigma + mu)
+ * S may be 0.  Includes H2D/D2H copies.
+ */
+int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64_t S,
+                                    double *alpha);
+
+/*
+ * Same computation on device-resident buffers (what bench.py times):
+ *   d_positions device f64[S*N*3];  d_alpha device f64[S*9] or NULL;
+ *   d_vec6 device f32[S*6] or NULL -- standardised (xx,yy,zz,xy,xz,yz), i.e. the value
+ *   of PotGNN.forward in eval mode (_gnn.py:617-665).
+ * Work is enqueued on `stream` (a hipStream_t; NULL = the null stream) and, when
+ * `synchronize` is non-zero, waited for before returning.
+ */
+int rn_potgnn_forward_device(rn_potgnn *h, const double *d_positions, int64_t S,
+                             double *d_alpha, float *d_vec6, void *stream,
+                             int synchronize);
+
+/*
+ * Replaces PotGNN.forward for host callers (_gnn.py:617-665, eval mode):
+ * host f64 positions -> host f32[S*6] standardised 6-vectors.
+ */
+int rn_potgnn_forward(rn_potgnn *h, const double *positions, int64_t S, float *vec6);
+
+/*
+ * Replaces the finite-difference loop of Phonons.get_raman_spectrum
+ * (ramannoodle/dynamics/_phonon.py:93-106) with ONE batched evaluation of the 2M
+ * displaced cells in double precision on the device:
+ *   raman[m] = (alpha(ref + delta*d_m) - alpha(ref - delta*d_m)) / delta
+ * (divides by delta, not 2*delta -- as the reference does).
+ *   ref_positions host f64[N*3], displacements host f64[M*N*3], raman host f64[M*9].
+ */
+int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions,
+                            const double *displacements, int64_t M, double delta,
+                            double *raman);
+
+/* ------------------------------------------------------------------ introspection */
+
+/* Number of edge triplets T of the frozen graph. */
+int64_t rn_potgnn_num_triplets(const rn_potgnn *h);
+
+/*
+ * Writes the triplet index arrays exactly as the device kernels enumerate them, in
+ * the order and meaning of the 7-tuple BatchTriplets holds (_utils.py:161-168):
+ * idx_i, idx_j, idx_k, slot5 (= PyG idx_kj), slot6 (= PyG idx_ji); each host int32[T].
+ * Produced by a device kernel that shares the enumeration code with the aggregation
+ * kernel, so tests can check bit-exact index parity.
+ */
+int rn_potgnn_debug_triplets(rn_potgnn *h, int32_t *idx_i, int32_t *idx_j,
+                             int32_t *idx_k, int32_t *slot5, int32_t *slot6);
+
+/*
+ * Copies one intermediate of the most recent evaluation's LAST chunk to the host,
+ * un-padded: stage 0 = unit vectors+distance [rows,4], 1 = node embedding after pass
+ * `index` (0 = initial) [S_c*N,Fn], 2 = edge embedding after pass `index` [S_c*E,Fe]
+ * (only the most recent pass and pass 0... see DESIGN.md: intermediates are kept only
+ * when the handle was created with RN_POTGNN_KEEP_STAGES=1 in the environment),
+ * 3 = readout embedding [S_c*E,12].  Returns rows written via *rows.
+ */
+int rn_potgnn_debug_stage(rn_potgnn *h, int stage, int index, float *out,
+                          size_t out_capacity, int64_t *rows, int64_t *cols);
+
+/* Per-kernel device time of the most recent evaluation (HIP events on the handle's
+ * stream), accumulated over chunks; names[i] are static strings.  Enabled with
+ * rn_potgnn_set_profiling(h, 1).  Returns the number of entries written (<= cap). */
+int rn_potgnn_set_profiling(rn_potgnn *h, int enabled);
+int rn_potgnn_kernel_times(rn_potgnn *h, const char **names, double *millis,
+                           int64_t *launches, int cap);
+
+const char *rn_potgnn_last_error(const rn_potgnn *h);
+const char *rn_potgnn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RN_POTGNN_H */

@@ -1,0 +1,948 @@
+// Host orchestration + C ABI (include/rn_potgnn.h) for the gfx950 PotGNN evaluator.
+//
+// A handle owns: the frozen graph (CSR both ways, node tiles, triplet offsets), the
+// weights re-laid-out for the kernels (transposed, [filter|core] halves padded to a
+// power-of-two width, concatenated Linear layers split into per-operand blocks), and
+// per-"lane" device workspaces.  An evaluation walks the frames in chunks small enough
+// for the per-chunk intermediates to stay in the 256 MiB Infinity Cache, alternating
+// chunks between two HIP streams so that the MFMA-bound projections of one chunk overlap
+// the VALU-bound aggregation of the other.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rn_potgnn.h"
+#include "kernels.hpp"
+
+using namespace rn;
+
+namespace {
+
+std::string g_create_error;
+
+int pad_pow2(int f) {
+  int p = 16;
+  while (p < f) p *= 2;
+  return p;
+}
+
+struct HipError {
+  hipError_t code;
+  const char *what;
+};
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) throw HipError{_e, #expr};   \
+  } while (0)
+
+struct DeviceBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DeviceBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void ensure(size_t n) {
+    if (n <= bytes) return;
+    release();
+    HIP_TRY(hipMalloc(&p, n));
+    bytes = n;
+  }
+  template <typename T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum KernelId {
+  K_GEOM = 0, K_NODE_INIT, K_PROJ_NODE, K_PROJ_EDGE_C1, K_NODE_AGG, K_PROJ_EDGE_C3, K_PROJ_C2,
+  K_EDGE_AGG, K_READOUT_MLP, K_READOUT_REDUCE, K_COUNT
+};
+const char *kKernelNames[K_COUNT] = {
+    "geom_rbf", "node_init", "proj_node", "proj_edge_c1", "node_agg", "proj_edge_c3",
+    "proj_c2", "edge_agg", "readout_mlp", "readout_reduce"};
+
+// Host-side packed weights, one flat array + offsets; uploaded per precision.
+struct PackedLayout {
+  // setup inputs (unpadded)
+  size_t emb, W2, b2, W4, b4, b0, bn_w, bn_b, bn_rm, bn_rv;
+  size_t offsets;  // [FeP]
+  struct Pass {
+    size_t c1_WnT, c1_WeT, c1_bias, c1n_g, c1n_b, fin_g, fin_b;
+    size_t c2_WT, c2_bias, c2n1_g, c2n1_b, c2n2_g, c2n2_b;
+    size_t c3_WnT, c3_nshift, c3_WeT, c3n1_g, c3n1_b, c3n2_g, c3n2_b;
+  };
+  std::vector<Pass> pass;
+  size_t W0T, W3T, b3, W5T, b5, ones;
+  // device-computed
+  size_t node_table, scale0, shift0;
+  size_t total = 0;
+  size_t take(size_t n) {
+    size_t o = total;
+    total += (n + 3) & ~size_t(3);  // keep 16-byte alignment for float4 loads
+    return o;
+  }
+};
+
+template <typename T>
+struct Lane {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  DeviceBuf unit4, node[2], edge[2], npc1, np3, bufA, bufB;
+};
+
+template <typename T>
+struct Precision {
+  bool ready = false;
+  DeviceBuf weights;     // packed, type T
+  DeviceBuf lattice;     // [9] T
+  std::vector<PassW<T>> pass;
+  ReadoutW<T> ro{};
+  const T *offsets = nullptr, *node_table = nullptr, *ones = nullptr;
+  Lane<T> lanes[2];
+  // stage snapshots (debug)
+  std::vector<DeviceBuf> snap_node, snap_edge;
+};
+
+struct TimedLaunch {
+  int kid;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rn_potgnn {
+  rn_potgnn_config cfg{};
+  Dims d{};
+  int chunk = 1;
+  int num_lanes = 2;
+  bool keep_stages = false;
+  // graph
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off;
+  Graph g{};
+  DeviceBuf g_ints;
+  double lattice[9], mean[9], stdv[9];
+  DeviceBuf d_mean_std;  // [18] double
+  std::vector<float> packed;  // host packed weights (float master copy)
+  PackedLayout lay;
+  Precision<float> f32;
+  Precision<double> f64;
+  // cached I/O staging for the host entry points
+  DeviceBuf io_pos, io_alpha, io_vec6;
+  int last_chunk_structs = 0;
+  bool last_was_f64 = false;
+  // profiling
+  int profiling = 0;
+  std::vector<TimedLaunch> timed;
+  double k_ms[K_COUNT] = {0};
+  int64_t k_launches[K_COUNT] = {0};
+  std::string error;
+  hipEvent_t ev_start = nullptr;
+};
+
+namespace {
+
+void set_error(rn_potgnn *h, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->error = buf;
+  else g_create_error = buf;
+}
+
+// ----------------------------------------------------------------------------- packing
+// Column of the padded [filter | core] layout for original output row r of a Linear /
+// LayerNorm of logical width 2F (first F rows = filter, last F = core; _gnn.py:143).
+inline int gated_col(int r, int F, int FP) { return r < F ? r : FP + (r - F); }
+
+void pack_weights(rn_potgnn *h, const float *w) {
+  const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP,
+            FeP = h->d.FeP, P = h->cfg.num_message_passes;
+  PackedLayout &L = h->lay;
+  L = PackedLayout();
+  L.emb = L.take((size_t)K * Fn);
+  L.W2 = L.take((size_t)Fn * Fn);
+  L.b2 = L.take(Fn);
+  L.W4 = L.take((size_t)Fn * Fn);
+  L.b4 = L.take(Fn);
+  L.offsets = L.take(FeP);
+  L.pass.resize(P);
+  for (auto &p : L.pass) {
+    p.c1_WnT = L.take((size_t)FnP * 2 * FnP);
+    p.c1_WeT = L.take((size_t)FeP * 2 * FnP);
+    p.c1_bias = L.take(2 * FnP);
+    p.c1n_g = L.take(2 * FnP);
+    p.c1n_b = L.take(2 * FnP);
+    p.fin_g = L.take(FnP);
+    p.fin_b = L.take(FnP);
+    p.c2_WT = L.take((size_t)FnP * 2 * FeP);
+    p.c2_bias = L.take(2 * FeP);
+    p.c2n1_g = L.take(2 * FeP);
+    p.c2n1_b = L.take(2 * FeP);
+    p.c2n2_g = L.take(FeP);
+    p.c2n2_b = L.take(FeP);
+    p.c3_WnT = L.take((size_t)FnP * 6 * FeP);
+    p.c3_nshift = L.take(6 * FeP);
+    p.c3_WeT = L.take((size_t)FeP * 4 * FeP);
+    p.c3n1_g = L.take(2 * FeP);
+    p.c3n1_b = L.take(2 * FeP);
+    p.c3n2_g = L.take(FeP);
+    p.c3n2_b = L.take(FeP);
+  }
+  L.W0T = L.take((size_t)FeP * FeP);
+  L.b0 = L.take(Fe);
+  L.bn_w = L.take(Fe);
+  L.bn_b = L.take(Fe);
+  L.bn_rm = L.take(Fe);
+  L.bn_rv = L.take(Fe);
+  L.W3T = L.take((size_t)FeP * FeP);
+  L.b3 = L.take(FeP);
+  L.W5T = L.take((size_t)FeP * 32);
+  L.b5 = L.take(32);
+  L.ones = L.take(std::max(FeP, 32));
+  L.node_table = L.take((size_t)K * FnP);
+  L.scale0 = L.take(FeP);
+  L.shift0 = L.take(FeP);
+
+  std::vector<float> &o = h->packed;
+  o.assign(L.total, 0.0f);
+  const float *c = w;  // cursor over the state_dict-ordered blob
+  auto copy = [&](size_t dst, size_t n) {
+    std::memcpy(&o[dst], c, n * sizeof(float));
+    c += n;
+  };
+  copy(L.emb, (size_t)K * Fn);
+  copy(L.W2, (size_t)Fn * Fn);
+  copy(L.b2, Fn);
+  copy(L.W4, (size_t)Fn * Fn);
+  copy(L.b4, Fn);
+  copy(L.offsets, Fe);  // "_edge_embedding.offset"
+  // node blocks (all passes) come first in the state dict, then edge blocks
+  for (int p = 0; p < P; ++p) {
+    auto &q = L.pass[p];
+    const float *W = c;  // c1_linear.weight [2Fn, Fn+Fe]
+    for (int r = 0; r < 2 * Fn; ++r) {
+      const int col = gated_col(r, Fn, FnP);
+      for (int k = 0; k < Fn; ++k) o[q.c1_WnT + (size_t)k * 2 * FnP + col] = W[r * (Fn + Fe) + k];
+      for (int k = 0; k < Fe; ++k)
+        o[q.c1_WeT + (size_t)k * 2 * FnP + col] = W[r * (Fn + Fe) + Fn + k];
+    }
+    c += (size_t)2 * Fn * (Fn + Fe);
+    for (int r = 0; r < 2 * Fn; ++r) o[q.c1_bias + gated_col(r, Fn, FnP)] = c[r];
+    c += 2 * Fn;
+    for (int r = 0; r < 2 * Fn; ++r) o[q.c1n_g + gated_col(r, Fn, FnP)] = c[r];
+    c += 2 * Fn;
+    for (int r = 0; r < 2 * Fn; ++r) o[q.c1n_b + gated_col(r, Fn, FnP)] = c[r];
+    c += 2 * Fn;
+    copy(q.fin_g, Fn);
+    copy(q.fin_b, Fn);
+  }
+  for (int p = 0; p < P; ++p) {
+    auto &q = L.pass[p];
+    const float *W2 = c;  // c2_linear.weight [2Fe, Fn]
+    for (int r = 0; r < 2 * Fe; ++r) {
+      const int col = gated_col(r, Fe, FeP);
+      for (int k = 0; k < Fn; ++k) o[q.c2_WT + (size_t)k * 2 * FeP + col] = W2[r * Fn + k];
+    }
+    c += (size_t)2 * Fe * Fn;
+    for (int r = 0; r < 2 * Fe; ++r) o[q.c2_bias + gated_col(r, Fe, FeP)] = c[r];
+    c += 2 * Fe;
+    const float *W3 = c;  // c3_linear.weight [2Fe, 3Fn+2Fe]: [n_i | n_j | n_k | e_slot5 | e_slot6]
+    const int ld = 3 * Fn + 2 * Fe;
+    for (int r = 0; r < 2 * Fe; ++r) {
+      const int col = gated_col(r, Fe, FeP);
+      for (int blk = 0; blk < 3; ++blk)
+        for (int k = 0; k < Fn; ++k)
+          o[q.c3_WnT + (size_t)k * 6 * FeP + blk * 2 * FeP + col] = W3[r * ld + blk * Fn + k];
+      for (int blk = 0; blk < 2; ++blk)
+        for (int k = 0; k < Fe; ++k)
+          o[q.c3_WeT + (size_t)k * 4 * FeP + blk * 2 * FeP + col] =
+              W3[r * ld + 3 * Fn + blk * Fe + k];
+    }
+    c += (size_t)2 * Fe * ld;
+    for (int r = 0; r < 2 * Fe; ++r) o[q.c3_nshift + 2 * FeP + gated_col(r, Fe, FeP)] = c[r];
+    c += 2 * Fe;
+    for (int r = 0; r < 2 * Fe; ++r) o[q.c2n1_g + gated_col(r, Fe, FeP)] = c[r];
+    c += 2 * Fe;
+    for (int r = 0; r < 2 * Fe; ++r) o[q.c2n1_b + gated_col(r, Fe, FeP)] = c[r];
+    c += 2 * Fe;
+    for (int r = 0; r < 2 * Fe; ++r) o[q.c3n1_g + gated_col(r, Fe, FeP)] = c[r];
+    c += 2 * Fe;
+    for (int r = 0; r < 2 * Fe; ++r) o[q.c3n1_b + gated_col(r, Fe, FeP)] = c[r];
+    c += 2 * Fe;
+    copy(q.c2n2_g, Fe);
+    copy(q.c2n2_b, Fe);
+    copy(q.c3n2_g, Fe);
+    copy(q.c3n2_b, Fe);
+  }
+  {  // readout
+    const float *W0 = c;
+    for (int r = 0; r < Fe; ++r)
+      for (int k = 0; k < Fe; ++k) o[L.W0T + (size_t)k * FeP + r] = W0[r * Fe + k];
+    c += (size_t)Fe * Fe;
+    copy(L.b0, Fe);
+    copy(L.bn_w, Fe);
+    copy(L.bn_b, Fe);
+    copy(L.bn_rm, Fe);
+    copy(L.bn_rv, Fe);
+    const float *W3 = c;
+    for (int r = 0; r < Fe; ++r)
+      for (int k = 0; k < Fe; ++k) o[L.W3T + (size_t)k * FeP + r] = W3[r * Fe + k];
+    c += (size_t)Fe * Fe;
+    copy(L.b3, Fe);
+    const float *W5 = c;
+    for (int r = 0; r < 12; ++r)
+      for (int k = 0; k < Fe; ++k) o[L.W5T + (size_t)k * 32 + r] = W5[r * Fe + k];
+    c += (size_t)12 * Fe;
+    copy(L.b5, 12);
+  }
+  for (int i = 0; i < std::max(FeP, 32); ++i) o[L.ones + i] = 1.0f;
+}
+
+template <typename T>
+Precision<T> &prec(rn_potgnn *h);
+template <>
+Precision<float> &prec<float>(rn_potgnn *h) { return h->f32; }
+template <>
+Precision<double> &prec<double>(rn_potgnn *h) { return h->f64; }
+
+size_t per_structure_elems(const rn_potgnn *h) {
+  const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges;
+  const size_t FnP = h->d.FnP, FeP = h->d.FeP;
+  const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
+  return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA + E * 4 * FeP;
+}
+
+template <typename T>
+void ensure_precision(rn_potgnn *h) {
+  Precision<T> &P = prec<T>(h);
+  if (P.ready) return;
+  const PackedLayout &L = h->lay;
+  std::vector<T> host(h->packed.size());
+  for (size_t i = 0; i < host.size(); ++i) host[i] = (T)h->packed[i];
+  P.weights.ensure(host.size() * sizeof(T));
+  HIP_TRY(hipMemcpy(P.weights.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  T lat[9];
+  for (int i = 0; i < 9; ++i) lat[i] = (T)h->lattice[i];
+  P.lattice.ensure(sizeof(lat));
+  HIP_TRY(hipMemcpy(P.lattice.p, lat, sizeof(lat), hipMemcpyHostToDevice));
+  T *w = P.weights.template as<T>();
+  P.pass.resize(L.pass.size());
+  for (size_t p = 0; p < L.pass.size(); ++p) {
+    const auto &q = L.pass[p];
+    PassW<T> &o = P.pass[p];
+    o.c1_WnT = w + q.c1_WnT;
+    o.c1_WeT = w + q.c1_WeT;
+    o.c1_bias = w + q.c1_bias;
+    o.c1_norm = {w + q.c1n_g, w + q.c1n_b};
+    o.final_norm = {w + q.fin_g, w + q.fin_b};
+    o.c2_WT = w + q.c2_WT;
+    o.c2_bias = w + q.c2_bias;
+    o.c2_norm_1 = {w + q.c2n1_g, w + q.c2n1_b};
+    o.c2_norm_2 = {w + q.c2n2_g, w + q.c2n2_b};
+    o.c3_WnT = w + q.c3_WnT;
+    o.c3_nshift = w + q.c3_nshift;
+    o.c3_WeT = w + q.c3_WeT;
+    o.c3_norm_1 = {w + q.c3n1_g, w + q.c3n1_b};
+    o.c3_norm_2 = {w + q.c3n2_g, w + q.c3n2_b};
+  }
+  P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5};
+  P.offsets = w + L.offsets;
+  P.node_table = w + L.node_table;
+  P.ones = w + L.ones;
+
+  const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges, S = h->chunk;
+  const size_t FnP = h->d.FnP, FeP = h->d.FeP;
+  const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
+  for (int l = 0; l < h->num_lanes; ++l) {
+    Lane<T> &ln = P.lanes[l];
+    HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    ln.unit4.ensure(S * E * 4 * sizeof(T));
+    for (int i = 0; i < 2; ++i) {
+      ln.node[i].ensure(S * N * FnP * sizeof(T));
+      ln.edge[i].ensure(S * E * FeP * sizeof(T));
+    }
+    ln.npc1.ensure(S * N * 2 * FnP * sizeof(T));
+    ln.np3.ensure(S * N * 6 * FeP * sizeof(T));
+    ln.bufA.ensure(S * E * bufA * sizeof(T));
+    ln.bufB.ensure(S * E * 4 * FeP * sizeof(T));
+  }
+  if (h->keep_stages) {
+    const int np = h->cfg.num_message_passes + 1;
+    P.snap_node.resize(np);
+    P.snap_edge.resize(np);
+    for (int i = 0; i < np; ++i) {
+      P.snap_node[i].ensure(S * N * FnP * sizeof(T));
+      P.snap_edge[i].ensure(S * E * FeP * sizeof(T));
+    }
+  }
+  // frame-independent device precompute
+  launch_setup<T>(w + L.emb, w + L.W2, w + L.b2, w + L.W4, w + L.b4, h->cfg.num_atom_types, h->d,
+                  w + L.node_table, w + L.b0, w + L.bn_w, w + L.bn_b, w + L.bn_rm, w + L.bn_rv,
+                  w + L.scale0, w + L.shift0, P.lanes[0].stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(P.lanes[0].stream));
+  P.ready = true;
+}
+
+struct Timer {
+  rn_potgnn *h;
+  hipStream_t st;
+  int kid;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  Timer(rn_potgnn *h_, hipStream_t st_, int kid_) : h(h_), st(st_), kid(kid_) {
+    on = h->profiling == 1 || (h->profiling >= 100 && h->profiling - 100 == kid);
+    if (on) {
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      HIP_TRY(hipEventRecord(a, st));
+    }
+  }
+  ~Timer() {
+    if (on) {
+      (void)hipEventRecord(b, st);
+      h->timed.push_back({kid, a, b});
+    }
+  }
+};
+
+void resolve_timers(rn_potgnn *h) {
+  for (auto &t : h->timed) {
+    float ms = 0;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      h->k_ms[t.kid] += ms;
+      h->k_launches[t.kid] += 1;
+    }
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  h->timed.clear();
+}
+
+// One chunk of `S` frames on one lane.  Mirrors PotGNN.forward (_gnn.py:641-665).
+template <typename T>
+void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_alpha,
+               float *d_vec6, double *d_alpha_raw) {
+  Precision<T> &P = prec<T>(h);
+  const Graph &g = h->g;
+  const Dims d = h->d;
+  hipStream_t st = ln.stream;
+  const int64_t MN = (int64_t)S * g.N, ME = (int64_t)S * g.E;
+  T *node[2] = {ln.node[0].template as<T>(), ln.node[1].template as<T>()};
+  T *edge[2] = {ln.edge[0].template as<T>(), ln.edge[1].template as<T>()};
+  T *unit4 = ln.unit4.template as<T>();
+  T *npc1 = ln.npc1.template as<T>(), *np3 = ln.np3.template as<T>();
+  T *bufA = ln.bufA.template as<T>(), *bufB = ln.bufB.template as<T>();
+  const size_t nbytes = (size_t)MN * d.FnP * sizeof(T), ebytes = (size_t)ME * d.FeP * sizeof(T);
+
+  {
+    Timer t(h, st, K_GEOM);
+    launch_geom_rbf<T>(d_pos, S, g, P.lattice.template as<T>(), P.offsets,
+                       (T)h->cfg.gauss_coefficient, d, unit4, edge[0], st);
+  }
+  {
+    Timer t(h, st, K_NODE_INIT);
+    launch_node_init<T>(P.node_table, S, g, d, node[0], st);
+  }
+  if (h->keep_stages) {
+    HIP_TRY(hipMemcpyAsync(P.snap_node[0].p, node[0], nbytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(P.snap_edge[0].p, edge[0], ebytes, hipMemcpyDeviceToDevice, st));
+  }
+  int cur = 0;
+  for (int p = 0; p < h->cfg.num_message_passes; ++p) {
+    const PassW<T> &w = P.pass[p];
+    const int nxt = cur ^ 1;
+    {  // NodeBlock
+      Timer t(h, st, K_PROJ_NODE);
+      launch_rowgemm<T>(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, nullptr, w.c1_bias, false,
+                        0, nullptr, g, st);
+    }
+    {
+      Timer t(h, st, K_PROJ_EDGE_C1);
+      launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0,
+                        nullptr, g, st);
+    }
+    {
+      Timer t(h, st, K_NODE_AGG);
+      launch_node_agg<T>(npc1, bufA, node[cur], node[nxt], S, g, d, w, st);
+    }
+    {  // EdgeBlock (uses the UPDATED node embedding, _gnn.py:649-650)
+      Timer t(h, st, K_PROJ_NODE);
+      launch_rowgemm<T>(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, nullptr, w.c3_nshift, false,
+                        0, nullptr, g, st);
+    }
+    {
+      Timer t(h, st, K_PROJ_EDGE_C3);
+      launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0,
+                        nullptr, g, st);
+    }
+    {
+      Timer t(h, st, K_PROJ_C2);
+      launch_rowgemm<T>(nullptr, ME, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1,
+                        node[nxt], g, st);
+    }
+    {
+      Timer t(h, st, K_EDGE_AGG);
+      launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, g, d, w, st);
+    }
+    cur = nxt;
+    if (h->keep_stages) {
+      HIP_TRY(hipMemcpyAsync(P.snap_node[p + 1].p, node[cur], nbytes, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(P.snap_edge[p + 1].p, edge[cur], ebytes, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  {  // readout MLP (_gnn.py:532-539): bufA <- ssp(BN(L0 edge)), bufB <- ssp(L3 .), bufA <- L5 .
+    Timer t(h, st, K_READOUT_MLP);
+    launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, d.FeP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
+                      nullptr, g, st);
+    launch_rowgemm<T>(bufA, ME, d.FeP, P.ro.W3T, d.FeP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g,
+                      st);
+    launch_rowgemm<T>(bufB, ME, d.FeP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g,
+                      st);
+  }
+  {
+    Timer t(h, st, K_READOUT_REDUCE);
+    const double *ms = h->d_mean_std.as<double>();
+    launch_readout_reduce<T>(bufA, unit4, S, g, ms, ms + 9, d_vec6, d_alpha, d_alpha_raw, st);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename T>
+void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alpha, float *d_vec6,
+                    double *d_alpha_raw, hipStream_t user, bool sync) {
+  ensure_precision<T>(h);
+  Precision<T> &P = prec<T>(h);
+  const int N = h->cfg.num_atoms;
+  HIP_TRY(hipEventRecord(h->ev_start, user));
+  const int lanes = h->num_lanes;
+  for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(P.lanes[l].stream, h->ev_start, 0));
+  int64_t done = 0;
+  int ci = 0;
+  while (done < S) {
+    const int s = (int)std::min<int64_t>(h->chunk, S - done);
+    Lane<T> &ln = P.lanes[ci % lanes];
+    run_chunk<T>(h, ln, d_pos + done * N * 3, s, d_alpha ? d_alpha + done * 9 : nullptr,
+                 d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr);
+    h->last_chunk_structs = s;
+    done += s;
+    ++ci;
+  }
+  h->last_was_f64 = sizeof(T) == 8;
+  for (int l = 0; l < lanes; ++l) {
+    HIP_TRY(hipEventRecord(P.lanes[l].done, P.lanes[l].stream));
+    HIP_TRY(hipStreamWaitEvent(user, P.lanes[l].done, 0));
+  }
+  if (sync) {
+    HIP_TRY(hipStreamSynchronize(user));
+    resolve_timers(h);
+  }
+}
+
+int guarded(rn_potgnn *h, const std::function<void()> &fn) {
+  try {
+    if (h) HIP_TRY(hipSetDevice(h->cfg.device));
+    fn();
+    return RN_OK;
+  } catch (const HipError &e) {
+    set_error(h, "HIP error %d (%s) in %s", (int)e.code, hipGetErrorString(e.code), e.what);
+    return e.code == hipErrorOutOfMemory ? RN_ERR_OUT_OF_MEMORY : RN_ERR_HIP;
+  } catch (const std::bad_alloc &) {
+    set_error(h, "host allocation failed");
+    return RN_ERR_OUT_OF_MEMORY;
+  }
+}
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+const char *rn_potgnn_version(void) { return "ramannoodle_amd-potgnn 0.1 (gfx950)"; }
+
+size_t rn_potgnn_weight_count(const rn_potgnn_config *c) {
+  if (!c) return 0;
+  const size_t K = c->num_atom_types, Fn = c->size_node_embedding, Fe = c->size_edge_embedding,
+               P = c->num_message_passes;
+  size_t n = K * Fn + 2 * (Fn * Fn + Fn) + Fe;
+  n += P * (2 * Fn * (Fn + Fe) + 2 * Fn + 2 * (2 * Fn) + 2 * Fn);
+  n += P * (2 * Fe * Fn + 2 * Fe + 2 * Fe * (3 * Fn + 2 * Fe) + 2 * Fe + 4 * (2 * Fe) + 4 * Fe);
+  n += (Fe * Fe + Fe) + 4 * Fe + (Fe * Fe + Fe) + (12 * Fe + 12);
+  return n;
+}
+
+const char *rn_potgnn_last_error(const rn_potgnn *h) {
+  return h ? h->error.c_str() : g_create_error.c_str();
+}
+
+int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const int32_t *edge_b,
+                     const int32_t *atom_types, const double *lattice, const float *weights,
+                     size_t num_weights, const double *mean, const double *stddev,
+                     rn_potgnn **out) {
+  if (!out) return RN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!cfg || !atom_types || !lattice || !weights || !mean || !stddev ||
+      (cfg->num_edges > 0 && (!edge_a || !edge_b))) {
+    set_error(nullptr, "null argument");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  const int N = cfg->num_atoms, E = cfg->num_edges;
+  if (N <= 0 || E < 0 || cfg->num_atom_types <= 0 || cfg->size_node_embedding <= 0 ||
+      cfg->size_edge_embedding <= 0 || cfg->num_message_passes <= 0) {
+    set_error(nullptr, "invalid configuration (non-positive size)");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (E == 0) {
+    set_error(nullptr, "reference graph has no edges: the per-structure mean over edges "
+                       "(_gnn.py:662-664) is undefined");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (cfg->size_node_embedding > 128 || cfg->size_edge_embedding > 128) {
+    set_error(nullptr, "embedding sizes above 128 are not supported (Fn=%d, Fe=%d)",
+              cfg->size_node_embedding, cfg->size_edge_embedding);
+    return RN_ERR_UNSUPPORTED;
+  }
+  if (num_weights != rn_potgnn_weight_count(cfg)) {
+    set_error(nullptr, "weights has %zu floats, expected %zu", num_weights,
+              rn_potgnn_weight_count(cfg));
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  for (int e = 0; e < E; ++e) {
+    if (edge_a[e] < 0 || edge_a[e] >= N || edge_b[e] < 0 || edge_b[e] >= N ||
+        edge_a[e] == edge_b[e]) {
+      set_error(nullptr, "edge %d = (%d,%d) is out of range or a self loop", e, edge_a[e],
+                edge_b[e]);
+      return RN_ERR_INVALID_ARGUMENT;
+    }
+    if (e > 0 && (edge_a[e] < edge_a[e - 1] ||
+                  (edge_a[e] == edge_a[e - 1] && edge_b[e] <= edge_b[e - 1]))) {
+      set_error(nullptr, "edges must be strictly sorted by (a, b); violated at edge %d", e);
+      return RN_ERR_INVALID_ARGUMENT;
+    }
+  }
+  for (int n = 0; n < N; ++n)
+    if (atom_types[n] < 0 || atom_types[n] >= cfg->num_atom_types) {
+      set_error(nullptr, "atom %d has type %d outside [0,%d)", n, atom_types[n],
+                cfg->num_atom_types);
+      return RN_ERR_INVALID_ARGUMENT;
+    }
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 ||
+      cfg->device >= ndev) {
+    set_error(nullptr, "no usable HIP device (count=%d, requested=%d)", ndev, cfg->device);
+    return RN_ERR_NO_DEVICE;
+  }
+
+  std::unique_ptr<rn_potgnn> h(new rn_potgnn());
+  h->cfg = *cfg;
+  h->d = {cfg->size_node_embedding, cfg->size_edge_embedding, pad_pow2(cfg->size_node_embedding),
+          pad_pow2(cfg->size_edge_embedding)};
+  std::memcpy(h->lattice, lattice, sizeof(h->lattice));
+  std::memcpy(h->mean, mean, sizeof(h->mean));
+  std::memcpy(h->stdv, stddev, sizeof(h->stdv));
+  h->keep_stages = getenv("RN_POTGNN_KEEP_STAGES") && atoi(getenv("RN_POTGNN_KEEP_STAGES")) != 0;
+  if (const char *e = getenv("RN_POTGNN_LANES")) h->num_lanes = std::max(1, std::min(2, atoi(e)));
+
+  // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets
+  h->edge_a.assign(edge_a, edge_a + E);
+  h->edge_b.assign(edge_b, edge_b + E);
+  h->atom_type.assign(atom_types, atom_types + N);
+  h->out_ptr.assign(N + 1, 0);
+  h->in_ptr.assign(N + 1, 0);
+  for (int e = 0; e < E; ++e) {
+    h->out_ptr[edge_a[e] + 1]++;
+    h->in_ptr[edge_b[e] + 1]++;
+  }
+  for (int n = 0; n < N; ++n) {
+    h->out_ptr[n + 1] += h->out_ptr[n];
+    h->in_ptr[n + 1] += h->in_ptr[n];
+  }
+  h->in_edge.assign(E, 0);
+  {
+    std::vector<int> fill(h->in_ptr.begin(), h->in_ptr.end() - 1);
+    for (int e = 0; e < E; ++e) h->in_edge[fill[edge_b[e]]++] = e;  // ascending edge id per b
+  }
+  const Dims d = h->d;
+  // node tiles: consecutive atoms whose outgoing-edge rows fit the LDS budget
+  // (budget counted in float32 rows; the float64 path uses twice the bytes for the same tiles)
+  const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB")) : 36;
+  const size_t budget_rows = std::max<size_t>(1, tile_kb * 1024 / ((size_t)2 * d.FeP * sizeof(float)));
+  const size_t cap_rows = (size_t)150 * 1024 / ((size_t)2 * d.FeP * sizeof(double) + 4);
+  int max_rows = 0;
+  h->tile_begin.push_back(0);
+  {
+    int rows = 0;
+    for (int n = 0; n < N; ++n) {
+      const int deg = h->out_ptr[n + 1] - h->out_ptr[n];
+      if ((size_t)deg > cap_rows) {
+        set_error(nullptr, "atom %d has %d outgoing edges; more than %zu per atom is unsupported",
+                  n, deg, cap_rows);
+        return RN_ERR_UNSUPPORTED;
+      }
+      if (rows > 0 && (size_t)(rows + deg) > budget_rows) {
+        h->tile_begin.push_back(n);
+        rows = 0;
+      }
+      rows += deg;
+      max_rows = std::max(max_rows, rows);
+    }
+    h->tile_begin.push_back(N);
+  }
+  h->trip_off.assign(E + 1, 0);
+  for (int e = 0; e < E; ++e) {
+    const int bd = edge_b[e], ad = edge_a[e];
+    int cnt = 0;
+    for (int o = h->out_ptr[bd]; o < h->out_ptr[bd + 1]; ++o) cnt += edge_b[o] != ad;
+    h->trip_off[e + 1] = h->trip_off[e] + cnt;
+  }
+
+  rn_potgnn *hp = h.get();
+  int rc = guarded(nullptr, [&]() {
+    HIP_TRY(hipSetDevice(cfg->device));
+    HIP_TRY(hipEventCreateWithFlags(&hp->ev_start, hipEventDisableTiming));
+    // upload all int arrays in one allocation
+    std::vector<int> ints;
+    auto push = [&](const std::vector<int> &v) {
+      size_t o = ints.size();
+      ints.insert(ints.end(), v.begin(), v.end());
+      while (ints.size() % 4) ints.push_back(0);
+      return o;
+    };
+    const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
+                 o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
+                 o_tb = push(hp->tile_begin), o_to = push(hp->trip_off);
+    hp->g_ints.ensure(ints.size() * sizeof(int));
+    HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int *base = hp->g_ints.as<int>();
+    Graph &g = hp->g;
+    g.N = N;
+    g.E = E;
+    g.edge_a = base + o_a;
+    g.edge_b = base + o_b;
+    g.out_ptr = base + o_op;
+    g.in_ptr = base + o_ip;
+    g.in_edge = base + o_ie;
+    g.atom_type = base + o_at;
+    g.num_tiles = (int)hp->tile_begin.size() - 1;
+    g.tile_begin = base + o_tb;
+    g.max_tile_out_rows = max_rows;
+    g.trip_off = base + o_to;
+    g.T = hp->trip_off[E];
+    double ms[18];
+    std::memcpy(ms, hp->mean, sizeof(hp->mean));
+    std::memcpy(ms + 9, hp->stdv, sizeof(hp->stdv));
+    hp->d_mean_std.ensure(sizeof(ms));
+    HIP_TRY(hipMemcpy(hp->d_mean_std.p, ms, sizeof(ms), hipMemcpyHostToDevice));
+
+    pack_weights(hp, weights);
+    // chunk size: keep one chunk's intermediates around ~160 MiB so they stay cache resident
+    int chunk = cfg->max_chunk_structures;
+    if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
+    if (chunk <= 0) {
+      const size_t per = per_structure_elems(hp) * sizeof(float);
+      chunk = (int)std::max<size_t>(1, ((size_t)160 << 20) / std::max<size_t>(per, 1));
+      chunk = std::min(chunk, 4096);
+    }
+    hp->chunk = chunk;
+    ensure_precision<float>(hp);
+  });
+  if (rc != RN_OK) return rc;
+  *out = h.release();
+  return RN_OK;
+}
+
+void rn_potgnn_destroy(rn_potgnn *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  resolve_timers(h);
+  for (int l = 0; l < 2; ++l) {
+    if (h->f32.lanes[l].stream) (void)hipStreamDestroy(h->f32.lanes[l].stream);
+    if (h->f32.lanes[l].done) (void)hipEventDestroy(h->f32.lanes[l].done);
+    if (h->f64.lanes[l].stream) (void)hipStreamDestroy(h->f64.lanes[l].stream);
+    if (h->f64.lanes[l].done) (void)hipEventDestroy(h->f64.lanes[l].done);
+  }
+  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  delete h;
+}
+
+int rn_potgnn_forward_device(rn_potgnn *h, const double *d_positions, int64_t S, double *d_alpha,
+                             float *d_vec6, void *stream, int synchronize) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && !d_positions)) {
+    set_error(h, "invalid positions / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    forward_device<float>(h, d_positions, S, d_alpha, d_vec6, nullptr, (hipStream_t)stream,
+                          synchronize != 0);
+  });
+}
+
+int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64_t S,
+                                    double *alpha) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !alpha))) {
+    set_error(h, "invalid positions / alpha / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    const size_t pb = (size_t)S * h->cfg.num_atoms * 3 * sizeof(double);
+    h->io_pos.ensure(pb);
+    h->io_alpha.ensure((size_t)S * 9 * sizeof(double));
+    HIP_TRY(hipMemcpy(h->io_pos.p, positions, pb, hipMemcpyHostToDevice));
+    forward_device<float>(h, h->io_pos.as<double>(), S, h->io_alpha.as<double>(), nullptr, nullptr,
+                          nullptr, true);
+    HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
+  });
+}
+
+int rn_potgnn_forward(rn_potgnn *h, const double *positions, int64_t S, float *vec6) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !vec6))) {
+    set_error(h, "invalid positions / vec6 / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    const size_t pb = (size_t)S * h->cfg.num_atoms * 3 * sizeof(double);
+    h->io_pos.ensure(pb);
+    h->io_vec6.ensure((size_t)S * 6 * sizeof(float));
+    HIP_TRY(hipMemcpy(h->io_pos.p, positions, pb, hipMemcpyHostToDevice));
+    forward_device<float>(h, h->io_pos.as<double>(), S, nullptr, h->io_vec6.as<float>(), nullptr,
+                          nullptr, true);
+    HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions, const double *displacements,
+                            int64_t M, double delta, double *raman) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (M < 0 || delta == 0.0 || !ref_positions || (M > 0 && (!displacements || !raman))) {
+    set_error(h, "invalid arguments to raman_tensors");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0) return RN_OK;
+  return guarded(h, [&]() {
+    const size_t n3 = (size_t)h->cfg.num_atoms * 3;
+    // frames 2m / 2m+1 = ref +/- delta * d_m   (_phonon.py:95-101)
+    std::vector<double> pos((size_t)2 * M * n3);
+    for (int64_t m = 0; m < M; ++m)
+      for (size_t i = 0; i < n3; ++i) {
+        const double eps = displacements[m * n3 + i] * delta;
+        pos[(2 * m) * n3 + i] = ref_positions[i] + eps;
+        pos[(2 * m + 1) * n3 + i] = ref_positions[i] - eps;
+      }
+    h->io_pos.ensure(pos.size() * sizeof(double));
+    h->io_alpha.ensure((size_t)2 * M * 9 * sizeof(double));
+    HIP_TRY(hipMemcpy(h->io_pos.p, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
+    forward_device<double>(h, h->io_pos.as<double>(), 2 * M, h->io_alpha.as<double>(), nullptr,
+                           nullptr, nullptr, true);
+    std::vector<double> a((size_t)2 * M * 9);
+    HIP_TRY(hipMemcpy(a.data(), h->io_alpha.p, a.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t m = 0; m < M; ++m)
+      for (int i = 0; i < 9; ++i)
+        raman[m * 9 + i] = (a[(2 * m) * 9 + i] - a[(2 * m + 1) * 9 + i]) / delta;  // _phonon.py:106
+  });
+}
+
+int64_t rn_potgnn_num_triplets(const rn_potgnn *h) { return h ? h->g.T : -1; }
+
+int rn_potgnn_debug_triplets(rn_potgnn *h, int32_t *idx_i, int32_t *idx_j, int32_t *idx_k,
+                             int32_t *slot5, int32_t *slot6) {
+  if (!h || !idx_i || !idx_j || !idx_k || !slot5 || !slot6) return RN_ERR_INVALID_ARGUMENT;
+  return guarded(h, [&]() {
+    const size_t T = (size_t)h->g.T;
+    if (T == 0) return;
+    DeviceBuf buf;
+    buf.ensure(5 * T * sizeof(int));
+    int *p = buf.as<int>();
+    launch_enum_triplets(h->g, p, p + T, p + 2 * T, p + 3 * T, p + 4 * T, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t *outs[5] = {idx_i, idx_j, idx_k, slot5, slot6};
+    for (int k = 0; k < 5; ++k)
+      HIP_TRY(hipMemcpy(outs[k], p + k * T, T * sizeof(int), hipMemcpyDeviceToHost));
+  });
+}
+
+int rn_potgnn_debug_stage(rn_potgnn *h, int stage, int index, float *out, size_t out_capacity,
+                          int64_t *rows, int64_t *cols) {
+  if (!h || !out || !rows || !cols) return RN_ERR_INVALID_ARGUMENT;
+  if (h->last_was_f64) {
+    set_error(h, "debug_stage only reads the float32 path");
+    return RN_ERR_UNSUPPORTED;
+  }
+  const int S = h->last_chunk_structs;
+  const int lane_of_last = 0;  // debug use: evaluate <= one chunk so lane 0 holds it
+  (void)lane_of_last;
+  Precision<float> &P = h->f32;
+  return guarded(h, [&]() {
+    HIP_TRY(hipDeviceSynchronize());
+    const float *src = nullptr;
+    int64_t r = 0, c = 0, ld = 0;
+    const int64_t ME = (int64_t)S * h->g.E, MN = (int64_t)S * h->g.N;
+    if (stage == 0) {
+      src = P.lanes[0].unit4.as<float>(); r = ME; c = 4; ld = 4;
+    } else if (stage == 1 || stage == 2) {
+      if (!h->keep_stages || index < 0 || index > h->cfg.num_message_passes)
+        throw HipError{hipErrorInvalidValue, "stage snapshots need RN_POTGNN_KEEP_STAGES=1"};
+      if (stage == 1) { src = P.snap_node[index].as<float>(); r = MN; c = h->d.Fn; ld = h->d.FnP; }
+      else { src = P.snap_edge[index].as<float>(); r = ME; c = h->d.Fe; ld = h->d.FeP; }
+    } else if (stage == 3) {
+      src = P.lanes[0].bufA.as<float>(); r = ME; c = 12; ld = 32;
+    } else {
+      throw HipError{hipErrorInvalidValue, "unknown stage"};
+    }
+    if ((size_t)(r * c) > out_capacity) throw HipError{hipErrorInvalidValue, "out_capacity too small"};
+    HIP_TRY(hipMemcpy2D(out, c * sizeof(float), src, ld * sizeof(float), c * sizeof(float), r,
+                        hipMemcpyDeviceToHost));
+    *rows = r;
+    *cols = c;
+  });
+}
+
+int rn_potgnn_set_profiling(rn_potgnn *h, int enabled) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  resolve_timers(h);
+  h->profiling = enabled;
+  for (int k = 0; k < K_COUNT; ++k) {
+    h->k_ms[k] = 0;
+    h->k_launches[k] = 0;
+  }
+  return RN_OK;
+}
+
+int rn_potgnn_kernel_times(rn_potgnn *h, const char **names, double *millis, int64_t *launches,
+                           int cap) {
+  if (!h || !names || !millis || !launches) return RN_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(h->cfg.device);
+  resolve_timers(h);
+  int n = 0;
+  for (int k = 0; k < K_COUNT && n < cap; ++k, ++n) {
+    names[n] = kKernelNames[k];
+    millis[n] = h->k_ms[k];
+    launches[n] = h->k_launches[k];
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// Kernel launch interface between api.hip (host orchestration) and the kernel TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rn {
+
+// Frozen reference graph on the device (all int32).
+struct Graph {
+  int N, E;
+  const int *edge_a;   // [E]  source atom a of edge (a -> b); edges sorted by (a, b)
+  const int *edge_b;   // [E]  destination atom b
+  const int *out_ptr;  // [N+1] CSR over a: edges out_ptr[a]..out_ptr[a+1] leave a
+  const int *in_ptr;   // [N+1] CSR over b
+  const int *in_edge;  // [E]  edge ids entering b, ascending
+  const int *atom_type;  // [N]
+  // node tiles for the edge-block kernel
+  int num_tiles;
+  const int *tile_begin;  // [num_tiles+1] node ranges
+  int max_tile_out_rows;  // LDS rows needed by the largest tile
+  // triplet enumeration
+  const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
+  int64_t T;
+};
+
+// One LayerNorm's affine parameters (device pointers, padded with zeros).
+template <typename T>
+struct Ln {
+  const T *g, *b;
+};
+
+template <typename T>
+struct PassW {
+  const T *c1_WnT;   // [FnP][2FnP]   node part of c1_linear, transposed, [filter|core]
+  const T *c1_WeT;   // [FeP][2FnP]   edge part
+  const T *c1_bias;  // [2FnP]
+  Ln<T> c1_norm;     // [2FnP]
+  Ln<T> final_norm;  // [FnP]
+  const T *c2_WT;    // [FnP][2FeP]
+  const T *c2_bias;  // [2FeP]
+  Ln<T> c2_norm_1;   // [2FeP]
+  Ln<T> c2_norm_2;   // [FeP]
+  const T *c3_WnT;   // [FnP][6FeP]   (W_i | W_j | W_k) node parts of c3_linear
+  const T *c3_nshift;  // [6FeP]      (0 | c3 bias | 0)
+  const T *c3_WeT;   // [FeP][4FeP]   (W_4 | W_5) edge parts: dest-edge | source-edge
+  Ln<T> c3_norm_1;   // [2FeP]
+  Ln<T> c3_norm_2;   // [FeP]
+};
+
+template <typename T>
+struct ReadoutW {
+  const T *W0T;  // [FeP][FeP]
+  const T *scale0, *shift0;  // BatchNorm(eval) folded with bias 0: ssp(acc*scale+shift)
+  const T *W3T;  // [FeP][FeP]
+  const T *b3;   // [FeP]
+  const T *W5T;  // [FeP][32]  (12 real columns)
+  const T *b5;   // [32]
+};
+
+struct Dims {
+  int Fn, Fe, FnP, FeP;  // logical and padded (pow2 >= 16) embedding widths
+};
+
+// ---- launchers (all asynchronous on `st`) ----
+template <typename T>
+void launch_setup(const T *emb, const T *W2, const T *b2, const T *W4, const T *b4, int K,
+                  Dims d, T *node_table, const T *b0, const T *bn_w, const T *bn_b,
+                  const T *bn_rm, const T *bn_rv, T *scale0, T *shift0, hipStream_t st);
+
+template <typename T>
+void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
+                     const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st);
+
+template <typename T>
+void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node, hipStream_t st);
+
+// Y[M, NOUT] = act(X[M, KP] * WT[KP, NOUT] * scale + shift)
+//   amode 0: X rows are read from `X` (row stride KP)
+//   amode 1: X row r = node[s*N + b_e] * node[s*N + a_e]  (r = s*E + e)   -- c2 input
+template <typename T>
+void launch_rowgemm(const T *X, int64_t M, int KP, const T *WT, int NOUT, T *Y,
+                    const T *scale, const T *shift, bool act, int amode, const T *node,
+                    const Graph &g, hipStream_t st);
+
+template <typename T>
+void launch_node_agg(const T *npc1, const T *bc1, const T *node_in, T *node_out, int S,
+                     const Graph &g, Dims d, const PassW<T> &w, hipStream_t st);
+
+template <typename T>
+void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in,
+                     T *edge_out, int S, const Graph &g, Dims d, const PassW<T> &w,
+                     hipStream_t st);
+
+template <typename T>
+void launch_readout_reduce(const T *pol, const T *unit4, int S, const Graph &g,
+                           const double *mean9, const double *std9, float *vec6,
+                           double *alpha, double *alpha_raw, hipStream_t st);
+
+void launch_enum_triplets(const Graph &g, int *idx_i, int *idx_j, int *idx_k, int *slot5,
+                          int *slot6, hipStream_t st);
+
+size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem);
+
+}  // namespace rn

@@ -1,0 +1,240 @@
+// Dense per-row projections  Y[M, NOUT] = epi(X[M, KP] * WT[KP, NOUT])  for gfx950.
+//
+// These are the factorised pieces of the reference's concatenated Linear layers
+// (_gnn.py:142 c1_linear, :224 c2_linear, :280 c3_linear) and the readout MLP
+// (_gnn.py:532-539).  M is huge (frames x edges), K and NOUT are small (<= 128 / <= 768):
+// the weights live in registers as MFMA B-fragments for the whole kernel, X tiles are
+// staged through LDS, and the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 does
+// the arithmetic (result == an fp32 fma chain, so parity with the fp32 reference holds).
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace rn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float *X;
+  int64_t M;
+  const float *WT;
+  int NOUT;
+  float *Y;
+  const float *scale, *shift;
+  const float *node;  // amode 1
+  const int *edge_a, *edge_b;
+  int N, E;
+};
+
+// KP: padded K (16..128).  A workgroup (4 waves) owns WN*TN*32 output columns and walks
+// 128-row tiles; wave (wm, wn) computes 32-row sub-tiles wm, wm+WM, .. for its TN column
+// tiles.  k is split between the two lane halves of the 32x32x2 instruction as
+// k = h*KP/2 + step so that every lane reads one contiguous run of its X row from LDS.
+template <int KP, int WN, int TN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
+  constexpr int WM = 4 / WN;
+  constexpr int BM = 128;
+  constexpr int LDA = KP + 4;  // +4 floats: conflict-free ds_read_b128 across rows
+  constexpr int KH = KP / 2;
+  constexpr int C4 = KP / 4;
+  __shared__ __attribute__((aligned(16))) float xs[BM * LDA];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ncol0 = blockIdx.y * (WN * TN * 32) + wn * (TN * 32);
+
+  float bfrag[TN][KH];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+      bfrag[t][s] = a.WT[(int64_t)(h * KH + s) * a.NOUT + ncol0 + t * 32 + l31];
+
+  float sc[TN], sh[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    sc[t] = (EPI == 2) ? a.scale[ncol0 + t * 32 + l31] : 1.0f;
+    sh[t] = (EPI >= 1) ? a.shift[ncol0 + t * 32 + l31] : 0.0f;
+  }
+
+  const int64_t num_tiles = (a.M + BM - 1) / BM;
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * BM;
+    for (int i = tid; i < BM * C4; i += 256) {
+      const int r = i / C4, c = (i % C4) * 4;
+      const int64_t row = row0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < a.M) {
+        if (AMODE == 0) {
+          v = *reinterpret_cast<const float4 *>(a.X + row * KP + c);
+        } else {
+          const int64_t s = row / a.E;
+          const int e = (int)(row % a.E);
+          const float4 nb =
+              *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_b[e]) * KP + c);
+          const float4 na =
+              *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_a[e]) * KP + c);
+          v = make_float4(nb.x * na.x, nb.y * na.y, nb.z * na.z, nb.w * na.w);
+        }
+      }
+      *reinterpret_cast<float4 *>(xs + r * LDA + c) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = wm; mt < BM / 32; mt += WM) {
+      float afrag[KH];
+      const float *ap = xs + (mt * 32 + l31) * LDA + h * KH;
+#pragma unroll
+      for (int s = 0; s < KH; s += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(ap + s);
+        afrag[s] = v.x;
+        afrag[s + 1] = v.y;
+        afrag[s + 2] = v.z;
+        afrag[s + 3] = v.w;
+      }
+      f32x16 acc[TN];
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KH; ++s)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], bfrag[t][s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int col = ncol0 + t * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < a.M) {
+            float v = acc[t][r];
+            if (EPI == 1) v += sh[t];
+            if (EPI == 2) v = ssp(v * sc[t] + sh[t]);
+            a.Y[row * a.NOUT + col] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int KP, int WN, int TN>
+static void launch_mfma_cfg(const GemmArgs &a, int amode, int epi, dim3 grid, hipStream_t st) {
+#define RN_GEMM(AM, EP) rowgemm_mfma_kernel<KP, WN, TN, AM, EP><<<grid, 256, 0, st>>>(a)
+  if (amode == 0) {
+    if (epi == 0) RN_GEMM(0, 0);
+    else if (epi == 1) RN_GEMM(0, 1);
+    else RN_GEMM(0, 2);
+  } else {
+    RN_GEMM(1, 0);
+  }
+#undef RN_GEMM
+}
+
+template <int KP>
+static void launch_mfma_kp(const GemmArgs &a, int amode, int epi, hipStream_t st) {
+  // column slice per workgroup: the largest of 256/128/64/32 that divides NOUT and keeps
+  // the B fragments within 64 VGPRs (TN * KP/2 <= 64).
+  int slice = 32;
+  if (a.NOUT % 64 == 0) slice = 64;
+  if (a.NOUT % 128 == 0) slice = 128;
+  if (a.NOUT % 256 == 0 && KP <= 64) slice = 256;
+  const int64_t tiles = (a.M + 127) / 128;
+  dim3 grid((unsigned)(tiles < 2048 ? tiles : 2048), (unsigned)(a.NOUT / slice));
+  switch (slice) {
+    case 32: launch_mfma_cfg<KP, 1, 1>(a, amode, epi, grid, st); break;
+    case 64: launch_mfma_cfg<KP, 2, 1>(a, amode, epi, grid, st); break;
+    case 128: launch_mfma_cfg<KP, 4, 1>(a, amode, epi, grid, st); break;
+    case 256:
+      if constexpr (KP <= 64) launch_mfma_cfg<KP, 4, 2>(a, amode, epi, grid, st);
+      break;
+  }
+}
+
+template <>
+void launch_rowgemm<float>(const float *X, int64_t M, int KP, const float *WT, int NOUT, float *Y,
+                           const float *scale, const float *shift, bool act, int amode,
+                           const float *node, const Graph &g, hipStream_t st) {
+  if (M == 0) return;
+  GemmArgs a{X, M, WT, NOUT, Y, scale, shift, node, g.edge_a, g.edge_b, g.N, g.E};
+  const int epi = act ? 2 : (shift ? 1 : 0);
+  switch (KP) {
+    case 16: launch_mfma_kp<16>(a, amode, epi, st); break;
+    case 32: launch_mfma_kp<32>(a, amode, epi, st); break;
+    case 64: launch_mfma_kp<64>(a, amode, epi, st); break;
+    case 128: launch_mfma_kp<128>(a, amode, epi, st); break;
+  }
+}
+
+// ---------------------------------------------------------------------------- float64
+// Double-precision variant used by the finite-difference Raman-tensor path
+// (dynamics/_phonon.py:93-106), where fp32 cancellation would dominate.  Plain FMA
+// kernel: 32-row X tile in LDS, one output column per thread.
+__global__ __launch_bounds__(256) void rowgemm_f64_kernel(const double *X, int64_t M, int KP,
+                                                          const double *WT, int NOUT, double *Y,
+                                                          const double *scale, const double *shift,
+                                                          int epi, int amode, const double *node,
+                                                          Graph g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double *xs = reinterpret_cast<double *>(smem_raw);  // [32][KP]
+  const int64_t num_tiles = (M + 31) / 32;
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 32;
+    for (int i = threadIdx.x; i < 32 * KP; i += 256) {
+      const int r = i / KP, c = i % KP;
+      const int64_t row = row0 + r;
+      double v = 0;
+      if (row < M) {
+        if (amode == 0) {
+          v = X[row * KP + c];
+        } else {
+          const int64_t s = row / g.E;
+          const int e = (int)(row % g.E);
+          v = node[(s * g.N + g.edge_b[e]) * KP + c] * node[(s * g.N + g.edge_a[e]) * KP + c];
+        }
+      }
+      xs[i] = v;
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < NOUT; col += 256) {
+      double acc[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) acc[r] = 0;
+      for (int k = 0; k < KP; ++k) {
+        const double wv = WT[(int64_t)k * NOUT + col];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc[r] += xs[r * KP + k] * wv;
+      }
+      const double sc = (epi == 2) ? scale[col] : 1.0;
+      const double sh = (epi >= 1) ? shift[col] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int64_t row = row0 + r;
+        if (row < M) {
+          double v = acc[r];
+          if (epi == 1) v += sh;
+          if (epi == 2) v = ssp(v * sc + sh);
+          Y[row * NOUT + col] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <>
+void launch_rowgemm<double>(const double *X, int64_t M, int KP, const double *WT, int NOUT,
+                            double *Y, const double *scale, const double *shift, bool act,
+                            int amode, const double *node, const Graph &g, hipStream_t st) {
+  if (M == 0) return;
+  const int epi = act ? 2 : (shift ? 1 : 0);
+  const int64_t tiles = (M + 31) / 32;
+  const unsigned grid = (unsigned)(tiles < 8192 ? tiles : 8192);
+  rowgemm_f64_kernel<<<grid, 256, (size_t)32 * KP * sizeof(double), st>>>(
+      X, M, KP, WT, NOUT, Y, scale, shift, epi, amode, node, g);
+}
+
+}  // namespace rn

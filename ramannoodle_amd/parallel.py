@@ -1,0 +1,51 @@
+"""Frame sharding across the GPUs of a node (one process per GPU).
+
+In evaluation mode every frame is independent, so the frames (MD) or
+displaced cells (phonons) are split into contiguous blocks, one per rank, with no
+collective on the data path; the only exchange is ONE all-gather of the per-frame
+``float64[S_local,3,3]`` results (72 B/frame -- latency-bound, a single step on the
+fully connected xGMI mesh).  ``torch.distributed`` with backend ``nccl`` is RCCL on ROCm;
+``gloo`` is used for CPU tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_items: int, world_size: int, rank: int) -> tuple[int, int, int]:
+    """Contiguous block ``[lo, hi)`` of rank ``rank`` and the padded per-rank length."""
+    per = -(-num_items // world_size) if num_items else 0
+    lo = min(rank * per, num_items)
+    hi = min(lo + per, num_items)
+    return lo, hi, per
+
+
+def all_gather_frames(local: torch.Tensor, num_items: int, group=None) -> torch.Tensor:
+    """All-gather per-rank blocks ``[S_local, ...]`` (padded to equal length) and trim."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    _, _, per = shard_bounds(num_items, world, rank)
+    tail = tuple(local.shape[1:])
+    padded = torch.zeros((per,) + tail, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    gathered = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    return gathered[:num_items]
+
+
+def calc_polarizabilities_sharded(model, positions_batch: np.ndarray, group=None) -> np.ndarray:
+    """Every rank passes the same ``positions_batch``; each evaluates its block with
+    ``model.calc_polarizabilities`` and all ranks return the full ``(S,3,3)`` array."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return model.calc_polarizabilities(positions_batch)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    total = positions_batch.shape[0]
+    lo, hi, _ = shard_bounds(total, world, rank)
+    local = model.calc_polarizabilities(positions_batch[lo:hi])
+    on_gpu = dist.get_backend(group) == "nccl"
+    tensor = torch.from_numpy(np.ascontiguousarray(local))
+    if on_gpu:
+        tensor = tensor.cuda()
+    return all_gather_frames(tensor, total, group).cpu().numpy()

@@ -1,0 +1,358 @@
+"""PotGNN polarizability model evaluated by hand-written gfx950 kernels.
+
+Host-side mirror of ``ramannoodle.pmodel.torch.PotGNN`` (``ramannoodle/pmodel/torch/
+_gnn.py:418-721``) for the evaluation path: same constructor signature and error
+messages, same ``state_dict`` keys, ``forward`` / ``calc_polarizabilities`` with the same
+argument meaning.  All arithmetic on positions happens on the device through the C ABI
+in ``include/rn_potgnn.h``; PyTorch is used only to hold parameter tensors and device
+buffers.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from numpy.typing import NDArray
+
+from ramannoodle_amd import _lib
+from ramannoodle_amd.abstract import PolarizabilityModel
+from ramannoodle_amd.constants import RAMAN_TENSOR_CENTRAL_DIFFERENCE
+from ramannoodle_amd.exceptions import verify_ndarray_shape
+from ramannoodle_amd.pmodel import graph as graph_utils
+
+_VEC_TO_TENSOR = np.array([[0, 3, 4], [3, 1, 5], [4, 5, 2]])  # dataset/torch/utils.py:30-37
+
+
+def polarizability_vectors_to_tensors(vectors):
+    """``[S,6] (xx,yy,zz,xy,xz,yz) -> [S,3,3]`` (``dataset/torch/utils.py:20-41``)."""
+    if vectors.ndim != 2 or vectors.shape[1] != 6:
+        raise ValueError(f"polarizability_vectors has wrong size: {list(vectors.shape)} != [_,6]")
+    return vectors[:, _VEC_TO_TENSOR]
+
+
+def polarizability_tensors_to_vectors(tensors):
+    """``[S,3,3] -> [S,6]`` (``dataset/torch/utils.py:44-60``)."""
+    if tensors.ndim != 3 or tuple(tensors.shape[1:]) != (3, 3):
+        raise ValueError(f"polarizability_tensors has wrong size: {list(tensors.shape)} != [_,3,3]")
+    return tensors[:, [0, 1, 2, 0, 0, 1], [0, 1, 2, 1, 2, 2]]
+
+
+def _ptr(array) -> C.c_void_p:
+    return C.c_void_p(array.ctypes.data)
+
+
+class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attributes
+    """POlarizability Tensor Graph Neural Network, device evaluation.
+
+    Parameters are positional-compatible with the reference
+    (``_gnn.py:453-464``); ``device`` (HIP ordinal) and ``max_chunk_structures`` are
+    additions.  ``ref_structure`` only needs ``lattice``, ``positions``,
+    ``atomic_numbers`` and ``num_atoms``.
+    """
+
+    # pylint: disable=too-many-arguments,too-many-positional-arguments,too-many-locals
+    def __init__(self, ref_structure, cutoff: float, size_node_embedding: int,
+                 size_edge_embedding: int, num_message_passes: int,
+                 gaussian_filter_start: float, gaussian_filter_end: float,
+                 mean_polarizability: NDArray[np.float64],
+                 stddev_polarizability: NDArray[np.float64], device: int | None = None,
+                 max_chunk_structures: int = 0):
+        if cutoff <= 0:
+            raise ValueError(f"invalid cutoff: {cutoff} <= 0")
+        if size_node_embedding <= 0:
+            raise ValueError(f"invalid size_node_embedding: {size_node_embedding} <= 0")
+        if size_edge_embedding <= 0:
+            raise ValueError(f"invalid size_edge_embedding: {size_edge_embedding} <= 0")
+        if num_message_passes <= 0:
+            raise ValueError(f"invalid num_message_passes: {num_message_passes} <= 0")
+        if gaussian_filter_start < 0:
+            raise ValueError(f"invalid gaussian_filter_start: {gaussian_filter_start} < 0")
+        if gaussian_filter_end <= gaussian_filter_start:
+            raise ValueError(
+                f"invalid gaussian_filter_end: {gaussian_filter_end} <= gaussian_filter_start")
+        verify_ndarray_shape("mean_polarizability", mean_polarizability, (3, 3))
+        verify_ndarray_shape("stddev_polarizability", stddev_polarizability, (3, 3))
+        _lib.load()  # fail loudly before any work if the HIP library is absent
+
+        self._ref_structure = ref_structure
+        self._cutoff = cutoff
+        self._fn = int(size_node_embedding)
+        self._fe = int(size_edge_embedding)
+        self._passes = int(num_message_passes)
+        self._mean_polarizability = np.array(mean_polarizability, dtype=np.float64)
+        self._stddev_polarizability = np.array(stddev_polarizability, dtype=np.float64)
+        self._device = device
+        self._max_chunk = int(max_chunk_structures)
+
+        # frozen graph of the reference structure (_gnn.py:489-499)
+        edges = graph_utils.radius_graph_pbc(ref_structure.lattice, ref_structure.positions, cutoff)
+        self._ref_edge_indexes = np.vstack([np.zeros((1, edges.shape[1]), dtype=np.int64), edges])
+        self._atom_type_map = graph_utils.atom_type_map(ref_structure.atomic_numbers)
+        self._num_atom_types = int((self._atom_type_map >= 0).sum())
+
+        # parameters, created in the reference's module order so that the same
+        # torch.manual_seed gives the same initial weights (_gnn.py:508-539)
+        fn, fe, k = self._fn, self._fe, self._num_atom_types
+        state: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+        def add(prefix, module):
+            for name, tensor in module.state_dict().items():
+                state[f"{prefix}.{name}"] = tensor.detach().clone()
+
+        add("_node_embedding.0", torch.nn.Embedding(k, fn))
+        add("_node_embedding.2", torch.nn.Linear(fn, fn))
+        add("_node_embedding.4", torch.nn.Linear(fn, fn))
+        offset = torch.linspace(gaussian_filter_start, gaussian_filter_end, fe, dtype=torch.float32)
+        state["_edge_embedding.offset"] = offset
+        if fe < 2:
+            raise ValueError("invalid size_edge_embedding: the Gaussian filter needs >= 2 steps")
+        self._gauss_coefficient = -0.5 / (float(offset[1]) - float(offset[0])) ** 2  # _gnn.py:64
+        for p in range(self._passes):
+            add(f"_node_blocks.{p}.c1_linear", torch.nn.Linear(fn + fe, 2 * fn))
+            add(f"_node_blocks.{p}.c1_norm", torch.nn.LayerNorm(2 * fn))
+            add(f"_node_blocks.{p}.final_norm", torch.nn.LayerNorm(fn))
+        for p in range(self._passes):
+            add(f"_edge_blocks.{p}.c2_linear", torch.nn.Linear(fn, 2 * fe))
+            add(f"_edge_blocks.{p}.c3_linear", torch.nn.Linear(3 * fn + 2 * fe, 2 * fe))
+            add(f"_edge_blocks.{p}.c2_norm_1", torch.nn.LayerNorm(2 * fe))
+            add(f"_edge_blocks.{p}.c3_norm_1", torch.nn.LayerNorm(2 * fe))
+            add(f"_edge_blocks.{p}.c2_norm_2", torch.nn.LayerNorm(fe))
+            add(f"_edge_blocks.{p}.c3_norm_2", torch.nn.LayerNorm(fe))
+        add("_to_polarizability_embedding.0", torch.nn.Linear(fe, fe))
+        add("_to_polarizability_embedding.1", torch.nn.BatchNorm1d(fe))
+        add("_to_polarizability_embedding.3", torch.nn.Linear(fe, fe))
+        add("_to_polarizability_embedding.5", torch.nn.Linear(fe, 12))
+        self._state = state
+        self._handle = None
+        self._profiling = 0
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def ref_edge_indexes(self) -> np.ndarray:
+        """``int64[3,E]`` (graph, a, b) as ``PotGNN._ref_edge_indexes`` (_gnn.py:492)."""
+        return self._ref_edge_indexes.copy()
+
+    @property
+    def num_edges(self) -> int:
+        return int(self._ref_edge_indexes.shape[1])
+
+    @property
+    def num_atoms(self) -> int:
+        return int(self._ref_structure.num_atoms)
+
+    @property
+    def atom_type_map(self) -> np.ndarray:
+        return self._atom_type_map.copy()
+
+    @property
+    def gauss_coefficient(self) -> float:
+        return self._gauss_coefficient
+
+    # ------------------------------------------------------------------ parameters
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """Same keys, shapes and order as the reference's ``state_dict()``."""
+        return OrderedDict((k, v.clone()) for k, v in self._state.items())
+
+    def load_state_dict(self, state) -> None:
+        """Load parameters (torch tensors or numpy arrays); keys and shapes must match."""
+        missing = [k for k in self._state if k not in state]
+        unexpected = [k for k in state if k not in self._state]
+        if missing or unexpected:
+            raise RuntimeError(f"state_dict mismatch: missing {missing}, unexpected {unexpected}")
+        new = OrderedDict()
+        for key, old in self._state.items():
+            value = torch.as_tensor(np.asarray(state[key]) if not torch.is_tensor(state[key])
+                                    else state[key].detach().cpu())
+            if tuple(value.shape) != tuple(old.shape):
+                raise RuntimeError(f"size mismatch for {key}: {tuple(value.shape)} != "
+                                   f"{tuple(old.shape)}")
+            new[key] = value.to(old.dtype).clone()
+        self._state = new
+        self._release()
+
+    def eval(self) -> "PotGNN":
+        """Evaluation mode is the only mode of this implementation."""
+        return self
+
+    def train(self, mode: bool = True) -> "PotGNN":
+        if mode:
+            raise NotImplementedError("training (batch-statistics BatchNorm, backward) is not "
+                                      "part of the device evaluation path yet")
+        return self
+
+    # ------------------------------------------------------------------ device handle
+    def _weights_blob(self) -> np.ndarray:
+        parts = [v.numpy().astype(np.float32).ravel() for v in self._state.values()
+                 if v.is_floating_point()]
+        return np.ascontiguousarray(np.concatenate(parts))
+
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return self._handle
+        lib = _lib.load()
+        device = self._device
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        cfg = _lib.Config(self.num_atoms, self.num_edges, self._num_atom_types, self._fn, self._fe,
+                          self._passes, self._gauss_coefficient, self._max_chunk, int(device))
+        blob = self._weights_blob()
+        expected = lib.rn_potgnn_weight_count(C.byref(cfg))
+        if blob.size != expected:
+            raise RuntimeError(f"weight blob has {blob.size} floats, library expects {expected}")
+        edge_a = np.ascontiguousarray(self._ref_edge_indexes[1], dtype=np.int32)
+        edge_b = np.ascontiguousarray(self._ref_edge_indexes[2], dtype=np.int32)
+        types = np.ascontiguousarray(
+            self._atom_type_map[np.asarray(self._ref_structure.atomic_numbers)], dtype=np.int32)
+        lattice = np.ascontiguousarray(self._ref_structure.lattice, dtype=np.float64)
+        mean = np.ascontiguousarray(self._mean_polarizability)
+        std = np.ascontiguousarray(self._stddev_polarizability)
+        handle = C.c_void_p()
+        rc = lib.rn_potgnn_create(C.byref(cfg), _ptr(edge_a), _ptr(edge_b), _ptr(types),
+                                  _ptr(lattice), _ptr(blob), blob.size, _ptr(mean), _ptr(std),
+                                  C.byref(handle))
+        _lib.check(rc, None, "rn_potgnn_create")
+        self._handle = handle
+        if self._profiling:
+            lib.rn_potgnn_set_profiling(handle, self._profiling)
+        return handle
+
+    def _release(self) -> None:
+        if getattr(self, "_handle", None) is not None:
+            _lib.load().rn_potgnn_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    # ------------------------------------------------------------------ evaluation
+    def _check_positions(self, positions_batch) -> np.ndarray:
+        verify_ndarray_shape("positions_batch", positions_batch, (None, self.num_atoms, 3))
+        return np.ascontiguousarray(positions_batch, dtype=np.float64)
+
+    def calc_polarizabilities(self, positions_batch: NDArray[np.float64]) -> NDArray[np.float64]:
+        """Polarizabilities ``(S,3,3)`` for fractional positions ``(S,N,3)``
+        (``_gnn.py:667-721``): host arrays in, host arrays out."""
+        pos = self._check_positions(positions_batch)
+        out = np.empty((pos.shape[0], 3, 3), dtype=np.float64)
+        handle = self._ensure_handle()
+        rc = _lib.load().rn_potgnn_calc_polarizabilities(handle, _ptr(pos), pos.shape[0], _ptr(out))
+        _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities")
+        return out
+
+    def calc_polarizabilities_device(self, positions: torch.Tensor, out: torch.Tensor | None = None,
+                                     synchronize: bool = False) -> torch.Tensor:
+        """Same computation on a device-resident ``float64[S,N,3]`` tensor; returns a device
+        ``float64[S,3,3]`` tensor.  Work is enqueued on torch's current stream."""
+        if not (positions.is_cuda and positions.dtype == torch.float64 and positions.is_contiguous()):
+            raise ValueError("positions must be a contiguous float64 device tensor")
+        if positions.dim() != 3 or tuple(positions.shape[1:]) != (self.num_atoms, 3):
+            raise ValueError(f"positions_batch has wrong shape: {tuple(positions.shape)} != "
+                             f"(_,{self.num_atoms},3)")
+        s = positions.shape[0]
+        if out is None:
+            out = torch.empty((s, 3, 3), dtype=torch.float64, device=positions.device)
+        handle = self._ensure_handle()
+        stream = torch.cuda.current_stream(positions.device).cuda_stream
+        rc = _lib.load().rn_potgnn_forward_device(
+            handle, C.c_void_p(positions.data_ptr()), s, C.c_void_p(out.data_ptr()), None,
+            C.c_void_p(stream), int(synchronize))
+        _lib.check(rc, handle, "rn_potgnn_forward_device")
+        return out
+
+    def forward(self, lattice, atomic_numbers, positions) -> torch.Tensor:
+        """Standardised 6-vectors ``[S,6]`` (``_gnn.py:617-665``, eval mode).  ``lattice``
+        ``[S,3,3]`` and ``atomic_numbers`` ``[S,N]`` must repeat the reference structure's
+        (the graph, and hence the device model, is frozen to it)."""
+        pos = np.ascontiguousarray(torch.as_tensor(positions).detach().cpu().numpy(), dtype=np.float64)
+        verify_ndarray_shape("positions", pos, (None, self.num_atoms, 3))
+        lat = torch.as_tensor(lattice).detach().cpu().numpy().astype(np.float64)
+        zs = torch.as_tensor(atomic_numbers).detach().cpu().numpy()
+        if lat.shape != (pos.shape[0], 3, 3) or zs.shape != (pos.shape[0], self.num_atoms):
+            raise ValueError("lattice / atomic_numbers do not match positions")
+        if pos.shape[0] and (
+                not np.allclose(lat, self._ref_structure.lattice[None], rtol=1e-6, atol=1e-9)
+                or not np.array_equal(zs, np.broadcast_to(
+                    np.asarray(self._ref_structure.atomic_numbers), zs.shape))):
+            raise NotImplementedError("per-sample lattices / species that differ from the "
+                                      "reference structure are not supported")
+        out = np.empty((pos.shape[0], 6), dtype=np.float32)
+        handle = self._ensure_handle()
+        rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), pos.shape[0], _ptr(out))
+        _lib.check(rc, handle, "rn_potgnn_forward")
+        return torch.from_numpy(out)
+
+    __call__ = forward
+
+    def calc_raman_tensors(self, ref_positions, displacements,
+                           delta: float = RAMAN_TENSOR_CENTRAL_DIFFERENCE) -> NDArray[np.float64]:
+        """``(alpha(r + delta d_m) - alpha(r - delta d_m)) / delta`` for all modes in one
+        float64 device batch (``dynamics/_phonon.py:93-106``)."""
+        verify_ndarray_shape("ref_positions", ref_positions, (self.num_atoms, 3))
+        verify_ndarray_shape("displacements", displacements, (None, self.num_atoms, 3))
+        ref = np.ascontiguousarray(ref_positions, dtype=np.float64)
+        disp = np.ascontiguousarray(displacements, dtype=np.float64)
+        out = np.empty((disp.shape[0], 3, 3), dtype=np.float64)
+        handle = self._ensure_handle()
+        rc = _lib.load().rn_potgnn_raman_tensors(handle, _ptr(ref), _ptr(disp), disp.shape[0],
+                                                 float(delta), _ptr(out))
+        _lib.check(rc, handle, "rn_potgnn_raman_tensors")
+        return out
+
+    # ------------------------------------------------------------------ introspection
+    def triplets(self):
+        """Edge triplets as the device enumerates them, re-sorted into the reference's
+        order: ``(i, j, idx_i, idx_j, idx_k, slot5, slot6)`` int64 arrays with the meaning of
+        ``BatchTriplets._ref_triplets`` (``_utils.py:161-168``)."""
+        handle = self._ensure_handle()
+        lib = _lib.load()
+        t = int(lib.rn_potgnn_num_triplets(handle))
+        arrs = [np.empty(t, dtype=np.int32) for _ in range(5)]
+        rc = lib.rn_potgnn_debug_triplets(handle, *[_ptr(a) for a in arrs])
+        _lib.check(rc, handle, "rn_potgnn_debug_triplets")
+        idx_i, idx_j, idx_k, slot5, slot6 = [a.astype(np.int64) for a in arrs]
+        order = np.lexsort((idx_k, slot6))  # by source edge (j->i), then k
+        return (self._ref_edge_indexes[2].copy(), self._ref_edge_indexes[1].copy(),
+                idx_i[order], idx_j[order], idx_k[order], slot5[order], slot6[order])
+
+    def device_triplets_raw(self):
+        """Triplets in device aggregation order (grouped by destination edge)."""
+        handle = self._ensure_handle()
+        lib = _lib.load()
+        t = int(lib.rn_potgnn_num_triplets(handle))
+        arrs = [np.empty(t, dtype=np.int32) for _ in range(5)]
+        _lib.check(lib.rn_potgnn_debug_triplets(handle, *[_ptr(a) for a in arrs]), handle,
+                   "rn_potgnn_debug_triplets")
+        return arrs
+
+    def debug_stage(self, stage: int, index: int = 0) -> np.ndarray:
+        """Intermediate of the last evaluation's last chunk (see ``rn_potgnn.h``)."""
+        handle = self._ensure_handle()
+        lib = _lib.load()
+        cap = 64 * 1024 * 1024
+        buf = np.empty(cap, dtype=np.float32)
+        rows, cols = C.c_int64(), C.c_int64()
+        rc = lib.rn_potgnn_debug_stage(handle, stage, index, _ptr(buf), cap, C.byref(rows),
+                                       C.byref(cols))
+        _lib.check(rc, handle, "rn_potgnn_debug_stage")
+        return buf[: rows.value * cols.value].reshape(rows.value, cols.value).copy()
+
+    def set_profiling(self, mode: int) -> None:
+        """0 = off, 1 = HIP-event timing of every kernel launch, 100+k = kernel k only."""
+        self._profiling = int(mode)
+        if self._handle is not None:
+            _lib.load().rn_potgnn_set_profiling(self._handle, self._profiling)
+
+    def kernel_times(self) -> dict:
+        """``{kernel: (milliseconds, launches)}`` accumulated since ``set_profiling``."""
+        handle = self._ensure_handle()
+        lib = _lib.load()
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        launches = (C.c_int64 * 16)()
+        n = lib.rn_potgnn_kernel_times(handle, names, ms, launches, 16)
+        return {names[i].decode(): (ms[i], launches[i]) for i in range(max(n, 0))}

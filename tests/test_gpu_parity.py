@@ -1,0 +1,164 @@
+"""Parity of the HIP path (through the C ABI) against the golden fixtures produced by the
+reference and against the CPU oracle.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (float32 path): per-stage intermediates atol 2e-5 on O(1) values; final
+polarizabilities within 1e-5 relative (the north-star bar); indices bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden
+from tests.helpers import product_model_from_golden
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+
+
+def _rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture
+def staged(monkeypatch):
+    monkeypatch.setenv("RN_POTGNN_KEEP_STAGES", "1")
+
+
+def test_device_loaded():
+    assert torch.cuda.is_available()
+    from ramannoodle_amd import _lib
+    assert b"gfx950" in _lib.load().rn_potgnn_version()
+
+
+def test_triplet_indices_bit_exact(golden):
+    name, g = golden
+    model = product_model_from_golden(g)
+    trip = model.triplets()
+    for mine, key in zip(trip, ["i", "j", "idx_i", "idx_j", "idx_k", "slot5", "slot6"]):
+        np.testing.assert_array_equal(mine, g["trip/" + key], err_msg=key)
+    # device order: grouped by destination edge, ascending source edge == scatter order
+    raw = model.device_triplets_raw()
+    key = raw[3].astype(np.int64) * (model.num_edges + 1) + raw[4]
+    assert np.all(np.diff(key) > 0)
+
+
+def test_stages_match_reference(golden, staged):
+    name, g = golden
+    model = product_model_from_golden(g)
+    pos = g["pos_batch"][:5]
+    s = pos.shape[0]
+    lat = torch.tensor(g["lattice"]).expand(s, 3, 3)
+    zs = torch.tensor(g["atomic_numbers"]).expand(s, -1)
+    out = model.forward(lat, zs, torch.tensor(pos)).numpy()
+    np.testing.assert_allclose(out, g["f32/forward"][:s], rtol=0,
+                               atol=REL * np.abs(g["f32/forward"]).max())
+    n, e = model.num_atoms, model.num_edges
+    if "f32/unit" in g.files:
+        geo = model.debug_stage(0)
+        np.testing.assert_allclose(geo[:, :3], g["f32/unit"][: s * e], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(geo[:, 3:], g["f32/dist"][: s * e], rtol=2e-6, atol=0)
+    for p in range(int(g["hp"][3]) + 1):
+        if f"f32/node{p}" in g.files:
+            np.testing.assert_allclose(model.debug_stage(1, p), g[f"f32/node{p}"][: s * n], rtol=0,
+                                       atol=2e-5, err_msg=f"node{p}")
+        if f"f32/edge{p}" in g.files:
+            np.testing.assert_allclose(model.debug_stage(2, p), g[f"f32/edge{p}"][: s * e], rtol=0,
+                                       atol=2e-5, err_msg=f"edge{p}")
+    if "f32/pol_emb" in g.files:
+        ref = g["f32/pol_emb"][: s * e]
+        np.testing.assert_allclose(model.debug_stage(3), ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_calc_polarizabilities_matches_reference_and_oracle(golden):
+    from oracle import potgnn_oracle as O
+    name, g = golden
+    model = product_model_from_golden(g)
+    pos = g["pos_batch"]
+    alpha = model.calc_polarizabilities(pos)
+    assert alpha.dtype == np.float64 and alpha.shape == (pos.shape[0], 3, 3)
+    np.testing.assert_array_equal(alpha, np.swapaxes(alpha, 1, 2))
+    # standardised part within 1e-5 relative; de-standardised alpha likewise
+    std_part = (alpha - g["mean"]) / g["std"]
+    ref_part = (g["f32/alpha"] - g["mean"]) / g["std"]
+    assert _rel_err(std_part, ref_part) < REL
+    assert _rel_err(alpha, g["f32/alpha"]) < REL
+    orc = O.calc_polarizabilities(O.model_from_arrays(g), pos[:8], faithful=False)
+    assert _rel_err(alpha[:8], orc) < REL
+    if "f64/alpha" in g.files:
+        assert _rel_err(alpha, g["f64/alpha"]) < REL
+
+
+def test_batch_size_independence_and_edge_cases():
+    """Results do not depend on chunking (reference: test_gnn.py:76-113,163-193);
+    S = 0 and S = 1 work."""
+    g = load_golden("rocksalt64_s205")
+    whole = product_model_from_golden(g)
+    chunked = product_model_from_golden(g, max_chunk_structures=7)
+    pos = g["pos_batch"]
+    a = whole.calc_polarizabilities(pos)
+    b = chunked.calc_polarizabilities(pos)
+    np.testing.assert_array_equal(a, b)
+    assert _rel_err(a, g["f32/alpha"]) < REL
+    assert whole.calc_polarizabilities(pos[:0]).shape == (0, 3, 3)
+    np.testing.assert_array_equal(whole.calc_polarizabilities(pos[17:18])[0], a[17])
+    # permuting frames permutes results
+    perm = np.random.default_rng(0).permutation(pos.shape[0])
+    np.testing.assert_array_equal(whole.calc_polarizabilities(pos[perm]), a[perm])
+    # determinism (segmented reductions, no atomics)
+    np.testing.assert_array_equal(whole.calc_polarizabilities(pos), a)
+
+
+def test_device_resident_entry_point():
+    g = load_golden("rocksalt64_parity")
+    model = product_model_from_golden(g)
+    pos = torch.tensor(g["pos_batch"], device="cuda")
+    out = model.calc_polarizabilities_device(pos, synchronize=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), model.calc_polarizabilities(g["pos_batch"]))
+
+
+def test_phonon_raman_tensors_float64_and_spectrum():
+    from ramannoodle_amd.dynamics import Phonons
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g)
+    ph = Phonons(g["positions"], g["ph/wavenumbers"], g["ph/displacements"])
+    spec = ph.get_raman_spectrum(model)
+    ref = g["ph/raman_tensors"]
+    assert _rel_err(spec.raman_tensors, ref) < REL
+    w, i = spec.measure()
+    np.testing.assert_allclose(i, g["ph/int_raw"], rtol=5e-5, atol=REL * g["ph/int_raw"].max())
+    w, i = spec.measure(laser_correction=True, laser_wavelength=532,
+                        bose_einstein_correction=True, temperature=300)
+    np.testing.assert_allclose(i, g["ph/int_corr"], rtol=5e-5, atol=REL * g["ph/int_corr"].max())
+
+
+def test_md_trajectory_spectrum():
+    from ramannoodle_amd.dynamics import Trajectory
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g)
+    spec = Trajectory(g["md/positions"], float(g["md/timestep"])).get_raman_spectrum(model)
+    assert _rel_err(spec.polarizability_ts, g["md/alpha_ts"]) < REL
+    w, i = spec.measure()
+    np.testing.assert_allclose(w, g["md/wavenumbers"], rtol=1e-12)
+    # intensities are built from differences of alpha(t): compare on the spectrum's scale
+    assert np.abs(i - g["md/int_raw"]).max() < 2e-3 * np.abs(g["md/int_raw"]).max()
+
+
+def test_full_size_properties():
+    """Config 2 size (128 atoms, 18 neighbours, perf widths): properties that need no
+    oracle -- chunk independence, lattice-translation invariance, symmetric output."""
+    from bench import make_workload
+    wl = make_workload(num_cells=(4, 2, 2), frames=24, hparams="perf", seed=22)
+    model = wl["model"](max_chunk_structures=0)
+    small = wl["model"](max_chunk_structures=5)
+    pos = wl["positions"]
+    a = model.calc_polarizabilities(pos)
+    np.testing.assert_array_equal(a, small.calc_polarizabilities(pos))
+    np.testing.assert_array_equal(a, np.swapaxes(a, 1, 2))
+    shift = np.random.default_rng(1).integers(-2, 3, size=(1,) + pos.shape[1:]).astype(np.float64)
+    b = model.calc_polarizabilities(pos + shift)
+    assert _rel_err(b, a) < REL
+    from oracle import potgnn_oracle as O
+    orc = O.calc_polarizabilities(wl["oracle"](), pos[:2], faithful=False)
+    assert _rel_err(a[:2], orc) < REL

@@ -1,0 +1,278 @@
+"""Host-side logic of the product (no GPU): graph construction, API contract, spectra,
+C-ABI symbol table."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from ramannoodle_amd import _lib
+from ramannoodle_amd.dynamics import Phonons, Trajectory
+from ramannoodle_amd.exceptions import DeviceError
+from ramannoodle_amd.pmodel import PotGNN, graph as G
+from ramannoodle_amd.pmodel import polarizability_tensors_to_vectors, polarizability_vectors_to_tensors
+from ramannoodle_amd.spectrum import (MDRamanSpectrum, PhononRamanSpectrum, calc_signal_spectrum,
+                                      convolve_spectrum, get_bose_einstein_correction,
+                                      get_laser_correction)
+from ramannoodle_amd.structure import ReferenceStructure, apply_pbc
+from tests.conftest import ROOT, load_golden
+from tests.helpers import product_model_from_golden
+
+
+# ----------------------------------------------------------------------------- graph
+def test_radius_graph_bit_exact(golden):
+    name, g = golden
+    edges = G.radius_graph_pbc(g["lattice"], g["positions"], float(g["hp"][0]))
+    np.testing.assert_array_equal(edges, g["ref_edge_indexes"][1:])
+    # sorted by (a, b), no self loops
+    key = edges[0] * len(g["atomic_numbers"]) + edges[1]
+    assert np.all(np.diff(key) > 0) and np.all(edges[0] != edges[1])
+
+
+def test_reference_order_triplets_bit_exact(golden):
+    name, g = golden
+    trip = G.reference_order_triplets(g["ref_edge_indexes"][1:], len(g["atomic_numbers"]))
+    for mine, key in zip(trip, ["i", "j", "idx_i", "idx_j", "idx_k", "slot5", "slot6"]):
+        np.testing.assert_array_equal(mine, g["trip/" + key])
+
+
+def test_atom_type_map(golden):
+    name, g = golden
+    np.testing.assert_array_equal(G.atom_type_map(g["atomic_numbers"]), g["atom_type_map"])
+
+
+def test_margin_around_cutoff(golden):
+    """Fixtures keep a >= 1e-4 A gap around the cutoff, so edge lists cannot flip on
+    float32 round-off (SURVEY hard part 4)."""
+    name, g = golden
+    lat, pos = g["lattice"], g["positions"]
+    d = pos[None] - pos[:, None]
+    d = np.where(d % 1 > 0.5, d % 1 - 1, d % 1) @ lat
+    dist = np.sqrt((d**2).sum(-1))
+    np.fill_diagonal(dist, 1e9)
+    assert np.abs(dist - float(g["hp"][0])).min() > 1e-4
+
+
+# ----------------------------------------------------------------------------- model shell
+def _ref():
+    g = load_golden("triclinic20")
+    return ReferenceStructure([int(z) for z in g["atomic_numbers"]], g["lattice"], g["positions"])
+
+
+@pytest.mark.parametrize(
+    "args, message",
+    [
+        ((-2.3, 5, 5, 5, 5, 5), "invalid cutoff: -2.3 <= 0"),
+        ((2.3, -5, 5, 5, 5, 5), "invalid size_node_embedding: -5 <= 0"),
+        ((2.3, 5, 0, 5, 5, 5), "invalid size_edge_embedding: 0 <= 0"),
+        ((2.3, 5, 5, -1, 5, 5), "invalid num_message_passes: -1 <= 0"),
+        ((2.3, 5, 5, 5, -0.5, 5), "invalid gaussian_filter_start: -0.5 < 0"),
+        ((2.3, 5, 5, 5, 3, 2), "invalid gaussian_filter_end: 2 <= gaussian_filter_start"),
+    ],
+)
+def test_constructor_validation_messages(args, message):
+    """Same six messages the reference pins (test/tests/torch/test_gnn.py:196-301)."""
+    with pytest.raises(ValueError, match=re.escape(message)):
+        PotGNN(_ref(), *args, np.zeros((3, 3)), np.ones((3, 3)))
+
+
+def test_constructor_shape_errors():
+    with pytest.raises(ValueError, match=re.escape("mean_polarizability has wrong shape: (3,) != (3,3)")):
+        PotGNN(_ref(), 3.0, 4, 4, 1, 0, 5, np.zeros(3), np.ones((3, 3)))
+    with pytest.raises(TypeError, match="stddev_polarizability should have type ndarray, not list"):
+        PotGNN(_ref(), 3.0, 4, 4, 1, 0, 5, np.zeros((3, 3)), [1, 2, 3])
+
+
+def test_state_dict_layout_matches_reference(golden):
+    name, g = golden
+    model = product_model_from_golden(g)
+    want = [(k[3:], g[k].shape) for k in g.files if k.startswith("sd/")]
+    got = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert got == want
+    assert model.gauss_coefficient == pytest.approx(float(g["gauss_coefficient"]), rel=0, abs=0)
+    np.testing.assert_array_equal(model.ref_edge_indexes, g["ref_edge_indexes"])
+    blob = model._weights_blob()
+    cfg = _lib.Config(model.num_atoms, model.num_edges, model._num_atom_types, model._fn, model._fe,
+                      model._passes, model.gauss_coefficient, 0, 0)
+    assert blob.size == _lib.load().rn_potgnn_weight_count(ctypes.byref(cfg))
+
+
+def test_same_seed_same_initial_weights_as_module_order():
+    torch.manual_seed(3)
+    a = PotGNN(_ref(), 3.0, 4, 6, 2, 0, 5, np.zeros((3, 3)), np.ones((3, 3))).state_dict()
+    torch.manual_seed(3)
+    b = PotGNN(_ref(), 3.0, 4, 6, 2, 0, 5, np.zeros((3, 3)), np.ones((3, 3))).state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k])
+
+
+def test_wrong_positions_shape_is_value_error_before_any_device_work():
+    model = product_model_from_golden(load_golden("triclinic20"))
+    with pytest.raises(ValueError, match=re.escape("positions_batch has wrong shape: (2,5,3) != (_,20,3)")):
+        model.calc_polarizabilities(np.zeros((2, 5, 3)))
+    with pytest.raises(TypeError, match="positions_batch should have type ndarray, not list"):
+        model.calc_polarizabilities([[1.0]])
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_device_fails_loudly():
+    model = product_model_from_golden(load_golden("triclinic20"))
+    with pytest.raises(DeviceError):
+        model.calc_polarizabilities(load_golden("triclinic20")["pos_batch"])
+
+
+def test_vector_tensor_maps():
+    v = torch.arange(12.0).reshape(2, 6)
+    t = polarizability_vectors_to_tensors(v)
+    assert t.shape == (2, 3, 3) and torch.equal(t, t.transpose(1, 2))
+    assert torch.equal(polarizability_tensors_to_vectors(t), v)
+    with pytest.raises(ValueError):
+        polarizability_vectors_to_tensors(torch.zeros(2, 5))
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rn_potgnn.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rn_potgnn_\w+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in _lib.load().rn_potgnn_version()
+
+
+def test_create_rejects_bad_arguments_without_touching_the_gpu():
+    lib = _lib.load()
+    cfg = _lib.Config(4, 2, 1, 200, 8, 1, -1.0, 0, 0)
+    n = lib.rn_potgnn_weight_count(ctypes.byref(cfg))
+    w = np.zeros(n, dtype=np.float32)
+    ea = np.array([0, 1], dtype=np.int32)
+    eb = np.array([1, 0], dtype=np.int32)
+    ty = np.zeros(4, dtype=np.int32)
+    lat = np.eye(3)
+    h = ctypes.c_void_p()
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    rc = lib.rn_potgnn_create(ctypes.byref(cfg), p(ea), p(eb), p(ty), p(lat), p(w), n, p(lat), p(lat),
+                              ctypes.byref(h))
+    assert rc == _lib.RN_ERR_UNSUPPORTED and b"128" in lib.rn_potgnn_last_error(None)
+    cfg.size_node_embedding = 8
+    n = lib.rn_potgnn_weight_count(ctypes.byref(cfg))
+    w = np.zeros(n, dtype=np.float32)
+    eb_bad = np.array([1, 1], dtype=np.int32)  # edge (1,1) is a self loop
+    rc = lib.rn_potgnn_create(ctypes.byref(cfg), p(ea), p(eb_bad), p(ty), p(lat), p(w), n, p(lat),
+                              p(lat), ctypes.byref(h))
+    assert rc == _lib.RN_ERR_INVALID_ARGUMENT
+    ea_unsorted = np.array([1, 0], dtype=np.int32)
+    rc = lib.rn_potgnn_create(ctypes.byref(cfg), p(ea_unsorted), p(ea), p(ty), p(lat), p(w), n,
+                              p(lat), p(lat), ctypes.byref(h))
+    assert rc == _lib.RN_ERR_INVALID_ARGUMENT and b"sorted" in lib.rn_potgnn_last_error(None)
+    rc = lib.rn_potgnn_create(ctypes.byref(cfg), p(ea), p(eb), p(ty), p(lat), p(w), n - 1, p(lat),
+                              p(lat), ctypes.byref(h))
+    assert rc == _lib.RN_ERR_INVALID_ARGUMENT
+
+
+# ----------------------------------------------------------------------------- spectra
+def test_phonon_spectrum_matches_reference():
+    g = load_golden("triclinic20")
+    spec = PhononRamanSpectrum(g["ph/wavenumbers"], g["ph/raman_tensors"])
+    w, i = spec.measure()
+    np.testing.assert_array_equal(w, g["ph/wavenumbers"])
+    np.testing.assert_allclose(i, g["ph/int_raw"], rtol=1e-13)
+    w, i = spec.measure(laser_correction=True, laser_wavelength=532,
+                        bose_einstein_correction=True, temperature=300)
+    np.testing.assert_allclose(i, g["ph/int_corr"], rtol=1e-13)
+    with pytest.raises(NotImplementedError):
+        spec.measure(orientation=np.eye(3))
+
+
+def test_md_spectrum_matches_reference():
+    g = load_golden("triclinic20")
+    spec = MDRamanSpectrum(g["md/alpha_ts"], float(g["md/timestep"]))
+    w, i = spec.measure()
+    np.testing.assert_allclose(w, g["md/wavenumbers"], rtol=1e-14)
+    np.testing.assert_allclose(i, g["md/int_raw"], rtol=1e-10, atol=1e-12 * np.abs(g["md/int_raw"]).max())
+    w, i = spec.measure(laser_correction=True, laser_wavelength=532,
+                        bose_einstein_correction=True, temperature=300)
+    np.testing.assert_allclose(i, g["md/int_corr"], rtol=1e-10, atol=1e-12 * np.abs(g["md/int_corr"]).max())
+    s = g["md/alpha_ts"].shape[0]
+    assert w.shape == (int(np.ceil((s - 1) / 2)) - 1 + ((s - 1) % 2 == 0) * 0,) or w.size > 0
+
+
+def test_signal_spectrum_length():
+    """Output length ceil(S/2) (test/tests/test_trajectory_spectrum.py:18-32)."""
+    for s in (40, 51):
+        w, i = calc_signal_spectrum(np.random.default_rng(0).normal(size=s), 1.0)
+        assert w.shape == i.shape == (int(np.ceil(s / 2)),)
+
+
+def test_corrections_and_convolution_errors():
+    w = np.array([100.0, 200.0])
+    with pytest.raises(ValueError, match="invalid temperature: -1 <= 0"):
+        get_bose_einstein_correction(w, -1)
+    with pytest.raises(TypeError, match="temperature should have type float, not list"):
+        get_bose_einstein_correction(w, [])
+    with pytest.raises(ValueError, match="invalid laser_wavenumber: 0 <= 0"):
+        get_laser_correction(w, 0)
+    with pytest.raises(ValueError, match="unsupported convolution type: triangle"):
+        convolve_spectrum(w, w, "triangle")
+    ow, oi = convolve_spectrum(w, np.array([1.0, 2.0]), "gaussian", 5)
+    assert oi.sum() * (ow[1] - ow[0]) == pytest.approx(3.0, rel=1e-3)
+    ow, oi = convolve_spectrum(w, np.array([1.0, 2.0]), "lorentzian", 5, out_wavenumbers=np.linspace(0, 300, 7))
+    assert ow.shape == oi.shape == (7,)
+
+
+# ----------------------------------------------------------------------------- dynamics
+class _Raises:
+    def calc_polarizabilities(self, positions_batch):
+        raise ValueError("positions_batch has wrong shape")
+
+
+class _Linear:
+    """Deterministic stand-in model: alpha = M . mean displacement (host only)."""
+
+    def __init__(self, n):
+        rng = np.random.default_rng(5)
+        self.w = rng.normal(size=(n * 3, 6))
+
+    def calc_polarizabilities(self, positions_batch):
+        v = positions_batch.reshape(positions_batch.shape[0], -1) @ self.w
+        return v[:, [[0, 3, 4], [3, 1, 5], [4, 5, 2]]]
+
+
+def test_dynamics_constructor_and_incompatibility_errors():
+    ref = np.zeros((4, 3))
+    with pytest.raises(ValueError, match=re.escape("displacements has wrong shape: (2,3,3) != (2,4,3)")):
+        Phonons(ref, np.array([1.0, 2.0]), np.zeros((2, 3, 3)))
+    ph = Phonons(ref, np.array([1.0, 2.0]), np.zeros((2, 4, 3)))
+    with pytest.raises(ValueError, match="polarizability_model and phonons are incompatible"):
+        ph.get_raman_spectrum(_Raises())
+    with pytest.raises(ValueError, match="timestep must be positive"):
+        Trajectory(np.zeros((3, 4, 3)), 0)
+    with pytest.raises(TypeError, match="timestep should have type float, not list"):
+        Trajectory(np.zeros((3, 4, 3)), [])
+    tr = Trajectory(np.zeros((3, 4, 3)) + 1.25, 1.0)
+    assert np.allclose(tr.positions_ts, 0.25) and len(tr) == 3 and tr[1].shape == (4, 3)
+    with pytest.raises(IndexError, match="trajectory index out of bounds"):
+        tr[7]
+    with pytest.raises(ValueError, match="polarizability_model and trajectory are incompatible"):
+        tr.get_raman_spectrum(_Raises())
+
+
+def test_phonon_finite_difference_divides_by_delta_not_two_delta():
+    n = 4
+    model = _Linear(n)
+    rng = np.random.default_rng(1)
+    ref, disp = rng.uniform(size=(n, 3)), rng.normal(size=(3, n, 3))
+    spec = Phonons(ref, np.array([10.0, 20.0, 30.0]), disp).get_raman_spectrum(model)
+    expect = 2.0 * (disp.reshape(3, -1) @ model.w)[:, [[0, 3, 4], [3, 1, 5], [4, 5, 2]]]
+    np.testing.assert_allclose(spec.raman_tensors, expect, rtol=1e-9, atol=1e-9)
+
+
+def test_apply_pbc():
+    x = np.array([[-0.25, 1.5, 0.0]])
+    np.testing.assert_allclose(apply_pbc(x), [[0.75, 0.5, 0.0]])
+    with pytest.raises(TypeError):
+        apply_pbc("nope")

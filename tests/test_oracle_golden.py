@@ -1,0 +1,66 @@
+"""Pin the CPU oracle against fixtures produced by executing the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import potgnn_oracle as O
+
+
+def test_graph_and_triplet_indices_bit_exact(golden):
+    name, g = golden
+    m = O.model_from_arrays(g)
+    edges, trip, tmap = O.build_topology(g["lattice"], g["positions"], g["atomic_numbers"],
+                                         float(g["hp"][0]))
+    assert torch.equal(edges, m.edges)
+    for mine, ref in zip(trip, m.trip):
+        assert torch.equal(mine, ref)
+    assert torch.equal(tmap.int(), m.atom_type_map.int())
+
+
+def test_forward_stages_match_reference(golden):
+    name, g = golden
+    m = O.model_from_arrays(g)
+    stages = {}
+    out = O.forward(m, g["pos_batch"], faithful=True, stages=stages)
+    np.testing.assert_allclose(out.numpy(), g["f32/forward"], rtol=0, atol=2e-6)
+    for key in g.files:
+        if key.startswith("f32/") and key[4:] in stages:
+            np.testing.assert_allclose(stages[key[4:]].numpy(), g[key], rtol=0, atol=3e-6,
+                                       err_msg=f"{name}:{key}")
+
+
+def test_lean_variant_equals_faithful(golden):
+    name, g = golden
+    m = O.model_from_arrays(g)
+    pos = g["pos_batch"][:3]
+    a = O.forward(m, pos, faithful=True).numpy()
+    b = O.forward(m, pos, faithful=False).numpy()
+    np.testing.assert_allclose(a, b, rtol=0, atol=5e-6)
+
+
+def test_calc_polarizabilities_f32_and_f64(golden):
+    name, g = golden
+    m = O.model_from_arrays(g)
+    alpha = O.calc_polarizabilities(m, g["pos_batch"])
+    np.testing.assert_allclose(alpha, g["f32/alpha"], rtol=1e-6, atol=1e-6)
+    assert alpha.dtype == np.float64 and alpha.shape == (g["pos_batch"].shape[0], 3, 3)
+    np.testing.assert_array_equal(alpha, np.swapaxes(alpha, 1, 2))
+    if "f64/alpha" in g.files:
+        a64 = O.calc_polarizabilities(m.to(torch.float64), g["pos_batch"][:2])
+        np.testing.assert_allclose(a64, g["f64/alpha"][:2], rtol=1e-7, atol=1e-7)
+
+
+def test_wrong_shape_is_value_error():
+    g = np.load("tests/golden/triclinic20.npz")
+    m = O.model_from_arrays(g)
+    with pytest.raises(ValueError):
+        O.calc_polarizabilities(m, np.zeros((2, 5, 3)))
+
+
+def test_phonon_raman_tensors_f64():
+    g = np.load("tests/golden/triclinic20.npz")
+    m = O.model_from_arrays(g).to(torch.float64)
+    r = O.raman_tensors_fd(m, g["positions"], g["ph/displacements"])
+    scale = np.abs(g["ph/raman_tensors"]).max()
+    np.testing.assert_allclose(r, g["ph/raman_tensors"], rtol=0, atol=2e-5 * scale)
