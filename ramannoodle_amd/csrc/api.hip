@@ -129,6 +129,7 @@ struct rn_potgnn {
   int chunk = 1;
   int num_lanes = 2;
   bool keep_stages = false;
+  bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
   std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off;
   Graph g{};
@@ -203,20 +204,21 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3n2_g = L.take(FeP);
     p.c3n2_b = L.take(FeP);
   }
-  L.W0T = L.take((size_t)FeP * FeP);
+  const int HP = std::max(FeP, 32);  // readout hidden width: projections emit 32-column tiles
+  L.W0T = L.take((size_t)FeP * HP);
   L.b0 = L.take(Fe);
   L.bn_w = L.take(Fe);
   L.bn_b = L.take(Fe);
   L.bn_rm = L.take(Fe);
   L.bn_rv = L.take(Fe);
-  L.W3T = L.take((size_t)FeP * FeP);
-  L.b3 = L.take(FeP);
-  L.W5T = L.take((size_t)FeP * 32);
+  L.W3T = L.take((size_t)HP * HP);
+  L.b3 = L.take(HP);
+  L.W5T = L.take((size_t)HP * 32);
   L.b5 = L.take(32);
-  L.ones = L.take(std::max(FeP, 32));
+  L.ones = L.take(HP);
   L.node_table = L.take((size_t)K * FnP);
-  L.scale0 = L.take(FeP);
-  L.shift0 = L.take(FeP);
+  L.scale0 = L.take(HP);
+  L.shift0 = L.take(HP);
 
   std::vector<float> &o = h->packed;
   o.assign(L.total, 0.0f);
@@ -292,7 +294,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
   {  // readout
     const float *W0 = c;
     for (int r = 0; r < Fe; ++r)
-      for (int k = 0; k < Fe; ++k) o[L.W0T + (size_t)k * FeP + r] = W0[r * Fe + k];
+      for (int k = 0; k < Fe; ++k) o[L.W0T + (size_t)k * HP + r] = W0[r * Fe + k];
     c += (size_t)Fe * Fe;
     copy(L.b0, Fe);
     copy(L.bn_w, Fe);
@@ -301,7 +303,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
     copy(L.bn_rv, Fe);
     const float *W3 = c;
     for (int r = 0; r < Fe; ++r)
-      for (int k = 0; k < Fe; ++k) o[L.W3T + (size_t)k * FeP + r] = W3[r * Fe + k];
+      for (int k = 0; k < Fe; ++k) o[L.W3T + (size_t)k * HP + r] = W3[r * Fe + k];
     c += (size_t)Fe * Fe;
     copy(L.b3, Fe);
     const float *W5 = c;
@@ -310,7 +312,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
     c += (size_t)12 * Fe;
     copy(L.b5, 12);
   }
-  for (int i = 0; i < std::max(FeP, 32); ++i) o[L.ones + i] = 1.0f;
+  for (int i = 0; i < HP; ++i) o[L.ones + i] = 1.0f;
 }
 
 template <typename T>
@@ -414,10 +416,15 @@ struct Timer {
       HIP_TRY(hipEventRecord(a, st));
     }
   }
-  ~Timer() {
+  ~Timer() noexcept(false) {
     if (on) {
       (void)hipEventRecord(b, st);
       h->timed.push_back({kid, a, b});
+    }
+    if (h->debug_sync) {
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) throw HipError{e, kKernelNames[kid]};
     }
   }
 };
@@ -509,12 +516,11 @@ void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_
   }
   {  // readout MLP (_gnn.py:532-539): bufA <- ssp(BN(L0 edge)), bufB <- ssp(L3 .), bufA <- L5 .
     Timer t(h, st, K_READOUT_MLP);
-    launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, d.FeP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
+    const int HP = std::max(d.FeP, 32);
+    launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
                       nullptr, g, st);
-    launch_rowgemm<T>(bufA, ME, d.FeP, P.ro.W3T, d.FeP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g,
-                      st);
-    launch_rowgemm<T>(bufB, ME, d.FeP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g,
-                      st);
+    launch_rowgemm<T>(bufA, ME, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
+    launch_rowgemm<T>(bufB, ME, HP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g, st);
   }
   {
     Timer t(h, st, K_READOUT_REDUCE);
@@ -657,6 +663,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   std::memcpy(h->mean, mean, sizeof(h->mean));
   std::memcpy(h->stdv, stddev, sizeof(h->stdv));
   h->keep_stages = getenv("RN_POTGNN_KEEP_STAGES") && atoi(getenv("RN_POTGNN_KEEP_STAGES")) != 0;
+  h->debug_sync = getenv("RN_POTGNN_DEBUG_SYNC") && atoi(getenv("RN_POTGNN_DEBUG_SYNC")) != 0;
   if (const char *e = getenv("RN_POTGNN_LANES")) h->num_lanes = std::max(1, std::min(2, atoi(e)));
 
   // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets

@@ -49,11 +49,12 @@ struct PassW {
 
 template <typename T>
 struct ReadoutW {
-  const T *W0T;  // [FeP][FeP]
-  const T *scale0, *shift0;  // BatchNorm(eval) folded with bias 0: ssp(acc*scale+shift)
-  const T *W3T;  // [FeP][FeP]
-  const T *b3;   // [FeP]
-  const T *W5T;  // [FeP][32]  (12 real columns)
+  // HP = max(FeP, 32): hidden width of the readout MLP as stored
+  const T *W0T;  // [FeP][HP]
+  const T *scale0, *shift0;  // [HP] BatchNorm(eval) folded with bias 0: ssp(acc*scale+shift)
+  const T *W3T;  // [HP][HP]
+  const T *b3;   // [HP]
+  const T *W5T;  // [HP][32]  (12 real columns)
   const T *b5;   // [32]
 };
 

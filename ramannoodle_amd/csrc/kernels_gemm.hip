@@ -129,7 +129,8 @@ static void launch_mfma_cfg(const GemmArgs &a, int amode, int epi, dim3 grid, hi
     else if (epi == 1) RN_GEMM(0, 1);
     else RN_GEMM(0, 2);
   } else {
-    RN_GEMM(1, 0);
+    if (epi == 0) RN_GEMM(1, 0);
+    else RN_GEMM(1, 1);
   }
 #undef RN_GEMM
 }
