@@ -130,7 +130,9 @@ def algorithmic_bytes_edge_block(n, e, fn, fe):
 def cpu_baseline(workload, sample):
     """The oracle's faithful restatement of the reference CPU path, on `sample` frames."""
     from oracle import potgnn_oracle as O
-    threads = os.cpu_count() or 1
+    # a 1-GPU box grants ~16 host cores however many the machine has; more torch threads
+    # than that only oversubscribes (measured: 256 threads were 3x slower than 16)
+    threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     model = workload["oracle"]()
     pos = workload["positions"][:sample]
@@ -151,7 +153,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
     ap.add_argument("--cells", type=str, default="4,2,2")
     ap.add_argument("--hparams", choices=list(HPARAMS), default="perf")
-    ap.add_argument("--cpu-sample", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=25)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--profile-all", action="store_true",

@@ -3,10 +3,10 @@
 // A handle owns: the frozen graph (CSR both ways, node tiles, triplet offsets), the
 // weights re-laid-out for the kernels (transposed, [filter|core] halves padded to a
 // power-of-two width, concatenated Linear layers split into per-operand blocks), and
-// per-"lane" device workspaces.  An evaluation walks the frames in chunks small enough
-// for the per-chunk intermediates to stay in the 256 MiB Infinity Cache, alternating
-// chunks between two HIP streams so that the MFMA-bound projections of one chunk overlap
-// the VALU-bound aggregation of the other.
+// per-"lane" device workspaces.  An evaluation walks the frames in chunks (a few hundred
+// frames: large launches amortise launch gaps and tails), alternating chunks between two
+// HIP streams so that the MFMA-bound projections of one chunk overlap the VALU-bound
+// aggregation of the other.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -758,13 +758,16 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     HIP_TRY(hipMemcpy(hp->d_mean_std.p, ms, sizeof(ms), hipMemcpyHostToDevice));
 
     pack_weights(hp, weights);
-    // chunk size: keep one chunk's intermediates around ~160 MiB so they stay cache resident
+    // chunk size: measured on MI355X (profiles/r01_chunk_sweep.txt) throughput rises
+    // monotonically with the chunk (fewer, larger launches; 8 -> 500 frames: 21k -> 48k
+    // structures/s) and the Infinity Cache does not reward small chunks, so size the
+    // per-lane workspace to ~1.5 GiB of the 288 GB HBM.
     int chunk = cfg->max_chunk_structures;
     if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
     if (chunk <= 0) {
       const size_t per = per_structure_elems(hp) * sizeof(float);
-      chunk = (int)std::max<size_t>(1, ((size_t)160 << 20) / std::max<size_t>(per, 1));
-      chunk = std::min(chunk, 4096);
+      chunk = (int)std::max<size_t>(1, ((size_t)1536 << 20) / std::max<size_t>(per, 1));
+      chunk = std::min(chunk, 2048);
     }
     hp->chunk = chunk;
     ensure_precision<float>(hp);

@@ -1,0 +1,71 @@
+"""Frame sharding + the single all-gather, exercised with 2 CPU processes over gloo
+(the N > 1 path of bench.py / ramannoodle_amd.parallel; on the GPU box the same code runs
+over RCCL).  A deterministic host-side stand-in model replaces the device model here so
+the test needs no GPU -- it checks the sharding/collective logic, not the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ramannoodle_amd.parallel import all_gather_frames, calc_polarizabilities_sharded, shard_bounds
+
+
+class _Model:
+    def __init__(self, n):
+        self.w = np.random.default_rng(5).normal(size=(n * 3, 6))
+        self.calls = []
+
+    def calc_polarizabilities(self, positions_batch):
+        self.calls.append(positions_batch.shape[0])
+        v = positions_batch.reshape(positions_batch.shape[0], self.w.shape[0]) @ self.w
+        return v[:, [[0, 3, 4], [3, 1, 5], [4, 5, 2]]]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 7
+        pos = np.random.default_rng(9).uniform(size=(total, n, 3))
+        model = _Model(n)
+        full = calc_polarizabilities_sharded(model, pos)
+        lo, hi, per = shard_bounds(total, world, rank)
+        assert model.calls == [hi - lo]
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), full)
+        # the bare collective on a ragged split
+        local = torch.arange(lo, hi, dtype=torch.float64).view(-1, 1, 1).expand(-1, 3, 3).contiguous()
+        got = all_gather_frames(local, total)
+        assert torch.equal(got[:, 0, 0], torch.arange(total, dtype=torch.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [11, 8, 1])
+def test_sharded_evaluation_two_ranks(tmp_path, total):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    n = 7
+    pos = np.random.default_rng(9).uniform(size=(total, n, 3))
+    expect = _Model(n).calc_polarizabilities(pos)
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"r{r}.npy"), expect)
+
+
+def test_shard_bounds_cover_everything():
+    for total in (0, 1, 7, 8, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (lo, hi, per), (lo2, _, _) in zip(spans, spans[1:]):
+                assert hi == lo2 and hi - lo <= per
