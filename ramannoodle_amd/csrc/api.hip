@@ -131,7 +131,8 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off;
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge;
+  bool use_fused = false;
   Graph g{};
   DeviceBuf g_ints;
   double lattice[9], mean[9], stdv[9];
@@ -494,19 +495,29 @@ void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_
       launch_rowgemm<T>(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, nullptr, w.c3_nshift, false,
                         0, nullptr, g, st);
     }
-    {
-      Timer t(h, st, K_PROJ_EDGE_C3);
-      launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0,
-                        nullptr, g, st);
+    bool fused = false;
+    if constexpr (sizeof(T) == 4) {
+      if (h->use_fused) {
+        Timer t(h, st, K_EDGE_AGG);
+        launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, g, d, w, st);
+        fused = true;
+      }
     }
-    {
-      Timer t(h, st, K_PROJ_C2);
-      launch_rowgemm<T>(nullptr, ME, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1,
-                        node[nxt], g, st);
-    }
-    {
-      Timer t(h, st, K_EDGE_AGG);
-      launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, g, d, w, st);
+    if (!fused) {
+      {
+        Timer t(h, st, K_PROJ_EDGE_C3);
+        launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false,
+                          0, nullptr, g, st);
+      }
+      {
+        Timer t(h, st, K_PROJ_C2);
+        launch_rowgemm<T>(nullptr, ME, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1,
+                          node[nxt], g, st);
+      }
+      {
+        Timer t(h, st, K_EDGE_AGG);
+        launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, g, d, w, st);
+      }
     }
     cur = nxt;
     if (h->keep_stages) {
@@ -719,6 +730,14 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     h->trip_off[e + 1] = h->trip_off[e] + cnt;
   }
 
+  h->rev_edge.assign(E, -1);
+  for (int e = 0; e < E; ++e) {  // reverse edge (b -> a): binary search in b's sorted out-list
+    const int bd = edge_b[e], ad = edge_a[e];
+    const int *lo = edge_b + h->out_ptr[bd], *hi = edge_b + h->out_ptr[bd + 1];
+    const int *it = std::lower_bound(lo, hi, ad);
+    if (it != hi && *it == ad) h->rev_edge[e] = (int)(it - edge_b);
+  }
+
   rn_potgnn *hp = h.get();
   int rc = guarded(nullptr, [&]() {
     HIP_TRY(hipSetDevice(cfg->device));
@@ -733,7 +752,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     };
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
-                 o_tb = push(hp->tile_begin), o_to = push(hp->trip_off);
+                 o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -746,9 +765,14 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.in_ptr = base + o_ip;
     g.in_edge = base + o_ie;
     g.atom_type = base + o_at;
+    g.rev_edge = base + o_rv;
     g.num_tiles = (int)hp->tile_begin.size() - 1;
     g.tile_begin = base + o_tb;
     g.max_tile_out_rows = max_rows;
+    g.max_tile_in_rows = 0;
+    for (size_t t = 0; t + 1 < hp->tile_begin.size(); ++t)
+      g.max_tile_in_rows = std::max(g.max_tile_in_rows,
+                                    hp->in_ptr[hp->tile_begin[t + 1]] - hp->in_ptr[hp->tile_begin[t]]);
     g.trip_off = base + o_to;
     g.T = hp->trip_off[E];
     double ms[18];
@@ -770,6 +794,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       chunk = std::min(chunk, 2048);
     }
     hp->chunk = chunk;
+    const bool want_fused = !(getenv("RN_POTGNN_FUSED") && atoi(getenv("RN_POTGNN_FUSED")) == 0);
+    hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
     ensure_precision<float>(hp);
   });
   if (rc != RN_OK) return rc;

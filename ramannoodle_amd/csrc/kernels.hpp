@@ -14,10 +14,12 @@ struct Graph {
   const int *in_ptr;   // [N+1] CSR over b
   const int *in_edge;  // [E]  edge ids entering b, ascending
   const int *atom_type;  // [N]
+  const int *rev_edge;   // [E]  id of the reverse edge (b -> a), or -1
   // node tiles for the edge-block kernel
   int num_tiles;
   const int *tile_begin;  // [num_tiles+1] node ranges
   int max_tile_out_rows;  // LDS rows needed by the largest tile
+  int max_tile_in_rows;   // most destination edges entering one tile
   // triplet enumeration
   const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
   int64_t T;
@@ -101,5 +103,10 @@ void launch_enum_triplets(const Graph &g, int *idx_i, int *idx_j, int *idx_k, in
                           int *slot6, hipStream_t st);
 
 size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem);
+
+// Fused EdgeBlock (kernels_fused.hip): projections + triplet aggregation in one launch.
+bool edge_fused_supported(const Graph &g, Dims d);
+void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
+                       int S, const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);
 
 }  // namespace rn

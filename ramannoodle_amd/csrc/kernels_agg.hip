@@ -256,18 +256,54 @@ template void launch_node_agg<double>(const double *, const double *, const doub
 // triplet tuple positionally (_gnn.py:650), so for a triplet k->j->i the concatenation is
 //   [node_i, node_j, node_k, edge_(k->j), edge_(j->i)]   and the scatter target is (k->j).
 // With d = (k->j) the destination edge and e = (j->i) a source edge leaving j = b_d:
-//   c3_linear(...) = [Wj node[b_d] + Wk node[a_d] + W4 edge_d + bias]  (depends on d)
-//                  + [Wi node[b_e] + W5 edge_e]                        (depends on e)
-// Both brackets are precomputed per edge by the dense projections (pq, np3); the triplet
-// stage is then add -> LayerNorm(2Fe) -> sigmoid*tanh -> sum over e (e in out(b_d), b_e != a_d,
-// ascending e == the reference's scatter order), i.e. a segmented reduction with implicit
-// triplet indices: out-edges of an atom are contiguous because edges are sorted by (a, b).
+//   c3_linear(...) = [Wj node[b_d] + Wk node[a_d] + W4 edge_d + bias]  (depends on d)  = P'_d
+//                  + [Wi node[b_e] + W5 edge_e]                        (depends on e)  = Q'_e
+// Both brackets come from the dense projections (pq, np3); the triplet stage is then
+// add -> LayerNorm(2Fe) -> sigmoid*tanh -> sum over e (e in out(b_d), b_e != a_d, ascending
+// e == the reference's scatter order): a segmented reduction with implicit triplet indices,
+// because the out-edges of an atom are contiguous in the (a, b)-sorted edge list.
 //
-// One workgroup per (frame, tile of atoms).  The "source" rows of all edges leaving the
-// tile's atoms are staged once in LDS and reused by every destination edge entering the
-// same atom (~degree-fold reuse); one lane group per destination edge.
+// Work decomposition: a workgroup owns ONE atom tile for the whole launch and walks the
+// frames (the graph is identical in every frame), so the tile's topology is read once
+// into LDS and every global load inside the frame loop has a ready address (no dependent
+// index->row chains, which cost microseconds each under load).  Per frame the source rows
+// Q' of the tile are staged in LDS once -- centred, with |q|^2 -- and reused by every
+// destination edge entering the same atom (degree-fold reuse); one lane group per
+// destination edge.  LayerNorm statistics use the pre-centred identity
+//   x - mean(x) = p + q,  sum (x-mean)^2 = |p|^2 + |q|^2 + 2 p.q   (p, q centred rows)
+// so a triplet costs one DPP reduction (p.q) instead of two.
+template <typename T>
+struct GateScale;
+template <>
+struct GateScale<float> {
+  static constexpr float kF = -1.4426950408889634f;      // exp2(kF * y) = exp(-y)
+  static constexpr float kC = 2.0f * 1.4426950408889634f;  // exp2(kC * y) = exp(2y)
+  static constexpr float kClamp = 43.28f;                 // |kC * y| <= 15 * kC
+};
+template <>
+struct GateScale<double> {
+  static constexpr double kF = -1.4426950408889634;
+  static constexpr double kC = 2.0 * 1.4426950408889634;
+  static constexpr double kClamp = 115.0;  // tanh == 1 to 1e-34 there; exp2(115) finite
+};
+__device__ __forceinline__ float gate_exp2(float yf, float yc) {
+  yc = fminf(fmaxf(yc, -GateScale<float>::kClamp), GateScale<float>::kClamp);
+  const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
+  return (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
+}
+__device__ __forceinline__ double gate_exp2(double yf, double yc) {
+  yc = fmin(fmax(yc, -GateScale<double>::kClamp), GateScale<double>::kClamp);
+  const double e1 = exp2(yf), e2 = exp2(yc);
+  return (e2 - 1.0) / ((1.0 + e1) * (1.0 + e2));
+}
+
+template <typename T>
+struct DestRows {  // the three addends of P'_d (fetched one destination ahead)
+  Vec4<T> pf, pc, jf, jc, kf, kc;
+};
+
 template <int LG, bool PAD, typename T>
-__global__ __launch_bounds__(256) void edge_agg_kernel(const T *__restrict__ pq,
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 3)) void edge_agg_kernel(const T *__restrict__ pq,
                                                        const T *__restrict__ np3,
                                                        const T *__restrict__ c2pre,
                                                        const T *__restrict__ edge_in,
@@ -276,102 +312,212 @@ __global__ __launch_bounds__(256) void edge_agg_kernel(const T *__restrict__ pq,
   constexpr int FP = LG * 4;
   constexpr int G = 256 / LG;  // lane groups per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *qrows = reinterpret_cast<T *>(smem_raw);                               // [rows][2FP]
-  int *qb = reinterpret_cast<int *>(qrows + (size_t)g.max_tile_out_rows * 2 * FP);  // [rows]
+  // LDS carve-up (every region 16-byte aligned)
+  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    unsigned char *p = smem_raw + off;
+    off += (bytes + 15) & ~size_t(15);
+    return p;
+  };
+  T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));  // centred Q' rows
+  T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));               // |q|^2
+  // per-destination LayerNorm parameters (read once per destination: keep them out of VGPRs)
+  T *lnp = reinterpret_cast<T *>(carve((size_t)8 * FP * sizeof(T)));
+  T *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
+    *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP;
+  int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));                   // b_e
+  int *dl = reinterpret_cast<int *>(carve((size_t)maxD * 6 * 4));               // topology
+  int *d_edge = dl, *d_a = dl + maxD, *d_b = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
+      *d_cnt = dl + 4 * maxD, *d_skip = dl + 5 * maxD;
+  for (int c = threadIdx.x; c < 2 * FP; c += 256) {
+    s_c2n1g[c] = w.c2_norm_1.g[c];
+    s_c2n1b[c] = w.c2_norm_1.b[c];
+    if (c < FP) {
+      s_c3n2g[c] = w.c3_norm_2.g[c];
+      s_c3n2b[c] = w.c3_norm_2.b[c];
+      s_c2n2g[c] = w.c2_norm_2.g[c];
+      s_c2n2b[c] = w.c2_norm_2.b[c];
+    }
+  }
 
   const int tile = blockIdx.x % g.num_tiles;
-  const int s = blockIdx.x / g.num_tiles;
+  const int sg = blockIdx.x / g.num_tiles, nsg = gridDim.x / g.num_tiles;
   const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
-  const int eo0 = g.out_ptr[j0], eo1 = g.out_ptr[j1];
-  const int rows = eo1 - eo0;
-  const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+  const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
 
-  // ---- stage source rows: Q'_e = W5 edge_e + Wi node[b_e]
-  constexpr int C4 = FP / 2;  // float4 columns per 2FP row
-  for (int i = threadIdx.x; i < rows * C4; i += 256) {
-    const int r = i / C4, c = (i % C4) * 4;
-    const int e = eo0 + r;
-    Vec4<T> x = load4<T>(pq + (erow0 + e) * (4 * FP) + 2 * FP + c);
-    Vec4<T> y = load4<T>(np3 + (nrow0 + g.edge_b[e]) * (6 * FP) + c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x.v[k] += y.v[k];
-    store4(qrows + (size_t)r * 2 * FP + c, x);
-  }
+  // ---- tile topology -> LDS (once per launch)
   for (int r = threadIdx.x; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
+  for (int i = threadIdx.x; i < dcount; i += 256) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_b[i] = bd;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+  }
   __syncthreads();
 
   const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
   const int nvalid = min(max(d.Fe - 4 * q, 0), 4);
   const T inv2n = (T)1 / (T)(2 * d.Fe), invn = (T)1 / (T)d.Fe;
-  const LnParams<T> p3f{load4<T>(w.c3_norm_1.g + 4 * q), load4<T>(w.c3_norm_1.b + 4 * q)};
-  const LnParams<T> p3c{load4<T>(w.c3_norm_1.g + FP + 4 * q), load4<T>(w.c3_norm_1.b + FP + 4 * q)};
+  // c3_norm_1 with the exp2 scale of the gate folded in
+  T g3f[4], b3f[4], g3c[4], b3c[4];
+  {
+    const Vec4<T> gf = load4<T>(w.c3_norm_1.g + 4 * q), bf = load4<T>(w.c3_norm_1.b + 4 * q);
+    const Vec4<T> gc = load4<T>(w.c3_norm_1.g + FP + 4 * q), bc = load4<T>(w.c3_norm_1.b + FP + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g3f[i] = GateScale<T>::kF * gf.v[i];
+      b3f[i] = GateScale<T>::kF * bf.v[i];
+      g3c[i] = GateScale<T>::kC * gc.v[i];
+      b3c[i] = GateScale<T>::kC * bc.v[i];
+    }
+  }
 
-  const int di0 = g.in_ptr[j0], di1 = g.in_ptr[j1];
-  for (int idx = di0 + grp; idx < di1; idx += G) {
-    const int dst = g.in_edge[idx];
-    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
-    const int64_t drow = erow0 + dst;
-    // P'_d = W4 edge_d + Wj node[b_d] + bias + Wk node[a_d]
-    Vec4<T> pf = load4<T>(pq + drow * (4 * FP) + 4 * q);
-    Vec4<T> pc = load4<T>(pq + drow * (4 * FP) + FP + 4 * q);
-    {
-      const T *nj = np3 + (nrow0 + bd) * (6 * FP) + 2 * FP + 4 * q;
-      const T *nk = np3 + (nrow0 + ad) * (6 * FP) + 4 * FP + 4 * q;
-      Vec4<T> jf = load4<T>(nj), jc = load4<T>(nj + FP);
-      Vec4<T> kf = load4<T>(nk), kc = load4<T>(nk + FP);
+  auto load_dest = [&](int i, int64_t erow0, int64_t nrow0) {
+    DestRows<T> r;
+    const int64_t drow = erow0 + d_edge[i];
+    const T *pp = pq + drow * (4 * FP) + 4 * q;
+    const T *nj = np3 + (nrow0 + d_b[i]) * (6 * FP) + 2 * FP + 4 * q;
+    const T *nk = np3 + (nrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
+    r.pf = load4<T>(pp);
+    r.pc = load4<T>(pp + FP);
+    r.jf = load4<T>(nj);
+    r.jc = load4<T>(nj + FP);
+    r.kf = load4<T>(nk);
+    r.kc = load4<T>(nk + FP);
+    return r;
+  };
+
+  for (int s = sg; s < S; s += nsg) {
+    const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    // ---- stage source rows: Q'_e = W5 edge_e + Wi node[b_e], centred, with |q|^2
+    for (int r = grp; r < rows; r += G) {
+      const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
+      const T *np = np3 + (nrow0 + qb[r]) * (6 * FP) + 4 * q;
+      Vec4<T> f = load4<T>(qp), c = load4<T>(qp + FP);
+      const Vec4<T> nf = load4<T>(np), nc = load4<T>(np + FP);
+      T sum = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        pf.v[i] += jf.v[i] + kf.v[i];
-        pc.v[i] += jc.v[i] + kc.v[i];
+        f.v[i] += nf.v[i];
+        c.v[i] += nc.v[i];
+        sum += f.v[i] + c.v[i];
       }
-    }
-    Vec4<T> acc{{0, 0, 0, 0}};
-    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
-    for (int r = rb; r < re; ++r) {
-      const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
-      Vec4<T> xf = load4<T>(qr);
-      Vec4<T> xc = load4<T>(qr + FP);
-      const bool keep = qb[r] != ad;  // triplets with i == k are excluded (PyG mask)
+      const T mean = lg_sum<LG>(sum) * inv2n;
+      T ss = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xf.v[i] += pf.v[i];
-        xc.v[i] += pc.v[i];
+        f.v[i] = (!PAD || i < nvalid) ? f.v[i] - mean : (T)0;
+        c.v[i] = (!PAD || i < nvalid) ? c.v[i] - mean : (T)0;
+        ss += f.v[i] * f.v[i] + c.v[i] * c.v[i];
       }
-      Vec4<T> gt = ln_gate<LG, PAD>(xf, xc, p3f, p3c, inv2n, nvalid);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc.v[i] += keep ? gt.v[i] : (T)0;
+      ss = lg_sum<LG>(ss);
+      store4(qrows + (size_t)r * 2 * FP + 4 * q, f);
+      store4(qrows + (size_t)r * 2 * FP + FP + 4 * q, c);
+      if (q == 0) sq[r] = ss;
     }
-    const LnParams<T> p3n{load4<T>(w.c3_norm_2.g + 4 * q), load4<T>(w.c3_norm_2.b + 4 * q)};
-    const Vec4<T> c3 = ln_row<LG, PAD>(acc, p3n, invn, nvalid);
+    __syncthreads();
 
-    // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
-    const LnParams<T> p2f{load4<T>(w.c2_norm_1.g + 4 * q), load4<T>(w.c2_norm_1.b + 4 * q)};
-    const LnParams<T> p2c{load4<T>(w.c2_norm_1.g + FP + 4 * q),
-                          load4<T>(w.c2_norm_1.b + FP + 4 * q)};
-    const Vec4<T> c2f = load4<T>(c2pre + drow * (2 * FP) + 4 * q);
-    const Vec4<T> c2c = load4<T>(c2pre + drow * (2 * FP) + FP + 4 * q);
-    const Vec4<T> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
-    const LnParams<T> p2n{load4<T>(w.c2_norm_2.g + 4 * q), load4<T>(w.c2_norm_2.b + 4 * q)};
-    const Vec4<T> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
+    // ---- destination edges of the tile; the next destination's rows are fetched while the
+    //      current one's triplets are evaluated
+    int i = grp;
+    DestRows<T> cur;
+    if (i < dcount) cur = load_dest(i, erow0, nrow0);
+    while (i < dcount) {
+      const int inext = i + G;
+      DestRows<T> nxt;
+      if (inext < dcount) nxt = load_dest(inext, erow0, nrow0);
+      // this destination's c2 pre-activation and old embedding arrive during the triplet loop
+      const int64_t drow = erow0 + d_edge[i];
+      const Vec4<T> c2f = load4<T>(c2pre + drow * (2 * FP) + 4 * q);
+      const Vec4<T> c2c = load4<T>(c2pre + drow * (2 * FP) + FP + 4 * q);
+      const Vec4<T> old = load4<T>(edge_in + drow * FP + 4 * q);
 
-    const Vec4<T> old = load4<T>(edge_in + drow * FP + 4 * q);
-    Vec4<T> out;
+      // P'_d, centred
+      T pf[4], pc[4];
+      T sum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out.v[i] = acc_tanh(old.v[i] + c2.v[i] + c3.v[i]);
-    store4(edge_out + drow * FP + 4 * q, out);
+      for (int k = 0; k < 4; ++k) {
+        pf[k] = cur.pf.v[k] + cur.jf.v[k] + cur.kf.v[k];
+        pc[k] = cur.pc.v[k] + cur.jc.v[k] + cur.kc.v[k];
+        sum += pf[k] + pc[k];
+      }
+      const T mean = lg_sum<LG>(sum) * inv2n;
+      T sp = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pf[k] = (!PAD || k < nvalid) ? pf[k] - mean : (T)0;
+        pc[k] = (!PAD || k < nvalid) ? pc[k] - mean : (T)0;
+        sp += pf[k] * pf[k] + pc[k] * pc[k];
+      }
+      sp = lg_sum<LG>(sp);
+
+      const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+      T acc[4] = {0, 0, 0, 0};
+#pragma unroll 2
+      for (int t = 0; t < cnt; ++t) {
+        const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
+        const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
+        const Vec4<T> qf = load4<T>(qr);
+        const Vec4<T> qc = load4<T>(qr + FP);
+        T dot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dot += pf[k] * qf.v[k] + pc[k] * qc.v[k];
+        dot = lg_sum<LG>(dot);
+        T var = (sp + sq[r] + (T)2 * dot) * inv2n;
+        var = var > (T)0 ? var : (T)0;
+        const T rstd = fast_rsq(var + (T)1e-5);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const T yf = ((pf[k] + qf.v[k]) * rstd) * g3f[k] + b3f[k];
+          const T yc = ((pc[k] + qc.v[k]) * rstd) * g3c[k] + b3c[k];
+          acc[k] += gate_exp2(yf, yc);
+        }
+      }
+      const LnParams<T> p3n{load4<T>(s_c3n2g + 4 * q), load4<T>(s_c3n2b + 4 * q)};
+      const Vec4<T> c3 = ln_row<LG, PAD>(Vec4<T>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+
+      // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
+      const LnParams<T> p2f{load4<T>(s_c2n1g + 4 * q), load4<T>(s_c2n1b + 4 * q)};
+      const LnParams<T> p2c{load4<T>(s_c2n1g + FP + 4 * q), load4<T>(s_c2n1b + FP + 4 * q)};
+      const Vec4<T> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
+      const LnParams<T> p2n{load4<T>(s_c2n2g + 4 * q), load4<T>(s_c2n2b + 4 * q)};
+      const Vec4<T> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
+
+      Vec4<T> out;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out.v[k] = acc_tanh(old.v[k] + c2.v[k] + c3.v[k]);
+      store4(edge_out + drow * FP + 4 * q, out);
+      cur = nxt;
+      i = inext;
+    }
+    __syncthreads();  // qrows are restaged for the next frame
   }
 }
 
 size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem) {
-  return (size_t)g.max_tile_out_rows * 2 * d.FeP * elem + (size_t)g.max_tile_out_rows * 4;
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  return up((size_t)g.max_tile_out_rows * 2 * d.FeP * elem) + up((size_t)g.max_tile_out_rows * elem) +
+         up((size_t)8 * d.FeP * elem) + up((size_t)g.max_tile_out_rows * 4) +
+         up((size_t)g.max_tile_in_rows * 6 * 4);
 }
 
 template <typename T>
 void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in, T *edge_out,
                      int S, const Graph &g, Dims d, const PassW<T> &w, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
-  const unsigned blocks = (unsigned)S * (unsigned)g.num_tiles;
   const size_t lds = edge_agg_lds_bytes(g, d, sizeof(T));
+  // one workgroup per (tile, frame group); aim at ~4 resident workgroups per CU
+  int nsg = 1024 / g.num_tiles;
+  nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
+  const unsigned blocks = (unsigned)nsg * (unsigned)g.num_tiles;
   const bool pad = d.Fe != d.FeP;
 #define CALL(LGV, PADV)                                                                       \
   do {                                                                                        \

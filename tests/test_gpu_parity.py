@@ -162,3 +162,14 @@ def test_full_size_properties():
     from oracle import potgnn_oracle as O
     orc = O.calc_polarizabilities(wl["oracle"](), pos[:2], faithful=False)
     assert _rel_err(a[:2], orc) < REL
+
+
+def test_fused_edge_block_equals_unfused(monkeypatch):
+    """The fused EdgeBlock kernel (MFMA projections + triplet stage in one launch) and the
+    unfused kernel chain are two implementations of the same math."""
+    from bench import make_workload
+    wl = make_workload(num_cells=(2, 2, 2), frames=9, hparams="perf", seed=3)
+    fused = wl["model"]().calc_polarizabilities(wl["positions"])
+    monkeypatch.setenv("RN_POTGNN_FUSED", "0")
+    unfused = wl["model"]().calc_polarizabilities(wl["positions"])
+    assert _rel_err(fused, unfused) < 2e-6
