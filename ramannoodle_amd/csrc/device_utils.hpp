@@ -74,6 +74,13 @@ __device__ __forceinline__ float ssp(float x) {
   float sp = (x > 20.0f) ? x : log1pf(expf(x));
   return sp - 0.6931471805599453f;
 }
+// Same function from the hardware exp2/log2 (abs error ~1e-7): used in the projection
+// epilogues where the libm form made the kernel VALU-bound.
+__device__ __forceinline__ float ssp_fast(float x) {
+  const float t = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
+  const float sp = (x > 20.0f) ? x : 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + t);
+  return sp - 0.6931471805599453f;
+}
 __device__ __forceinline__ double ssp(double x) {
   double sp = (x > 20.0) ? x : log1p(exp(x));
   return sp - 0.6931471805599453;

@@ -57,30 +57,53 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
     sh[t] = (EPI >= 1) ? a.shift[ncol0 + t * 32 + l31] : 0.0f;
   }
 
-  const int64_t num_tiles = (a.M + BM - 1) / BM;
-  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * BM;
-    for (int i = tid; i < BM * C4; i += 256) {
+  // X rows of the NEXT tile are fetched into registers while the current tile is in the
+  // MFMA/store phase (issue-early / write-late staging), so global latency is off the
+  // critical path.  NPF float4 per thread; for amode 1 both gathered node rows are held.
+  constexpr int NPF = (BM * C4) / 256;
+  constexpr bool PREFETCH = (KP <= 64);
+  float4 pre[NPF], pre2[AMODE == 1 ? NPF : 1];
+  auto fetch = [&](int64_t row0) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int i = tid + j * 256;
       const int r = i / C4, c = (i % C4) * 4;
       const int64_t row = row0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == 1) pre2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < a.M) {
         if (AMODE == 0) {
-          v = *reinterpret_cast<const float4 *>(a.X + row * KP + c);
+          pre[j] = *reinterpret_cast<const float4 *>(a.X + row * KP + c);
         } else {
           const int64_t s = row / a.E;
           const int e = (int)(row % a.E);
-          const float4 nb =
-              *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_b[e]) * KP + c);
-          const float4 na =
-              *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_a[e]) * KP + c);
-          v = make_float4(nb.x * na.x, nb.y * na.y, nb.z * na.z, nb.w * na.w);
+          pre[j] = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_b[e]) * KP + c);
+          pre2[j] = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_a[e]) * KP + c);
         }
       }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int i = tid + j * 256;
+      const int r = i / C4, c = (i % C4) * 4;
+      float4 v = pre[j];
+      if (AMODE == 1)
+        v = make_float4(v.x * pre2[j].x, v.y * pre2[j].y, v.z * pre2[j].z, v.w * pre2[j].w);
       *reinterpret_cast<float4 *>(xs + r * LDA + c) = v;
     }
+  };
+
+  const int64_t num_tiles = (a.M + BM - 1) / BM;
+  if (PREFETCH && (int64_t)blockIdx.x < num_tiles) fetch((int64_t)blockIdx.x * BM);
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * BM;
+    if (!PREFETCH) fetch(row0);
+    commit();
     __syncthreads();
-#pragma unroll
+    if (PREFETCH && tile + gridDim.x < num_tiles) fetch((tile + gridDim.x) * BM);
+#pragma unroll 1
     for (int mt = wm; mt < BM / 32; mt += WM) {
       float afrag[KH];
       const float *ap = xs + (mt * 32 + l31) * LDA + h * KH;
@@ -111,7 +134,7 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
           if (row < a.M) {
             float v = acc[t][r];
             if (EPI == 1) v += sh[t];
-            if (EPI == 2) v = ssp(v * sc[t] + sh[t]);
+            if (EPI == 2) v = ssp_fast(v * sc[t] + sh[t]);
             a.Y[row * a.NOUT + col] = v;
           }
         }
