@@ -10,7 +10,8 @@ import os
 
 from ramannoodle_amd.exceptions import DeviceError
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librn_potgnn.so")
+_LIB_PATH = os.environ.get(
+    "RN_POTGNN_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "librn_potgnn.so"))
 
 RN_OK = 0
 RN_ERR_INVALID_ARGUMENT = -1

@@ -152,6 +152,8 @@ struct rn_potgnn {
   int64_t k_launches[K_COUNT] = {0};
   std::string error;
   hipEvent_t ev_start = nullptr;
+  hipEvent_t ev_g[2] = {nullptr, nullptr};  // "projection stage done" per lane (run_pair)
+  bool interleave = true;
 };
 
 namespace {
@@ -443,102 +445,178 @@ void resolve_timers(rn_potgnn *h) {
   h->timed.clear();
 }
 
-// One chunk of `S` frames on one lane.  Mirrors PotGNN.forward (_gnn.py:641-665).
+// One chunk of `S` frames on one lane, split into stages so that two chunks can be
+// interleaved (see forward_device).  Mirrors PotGNN.forward (_gnn.py:641-665).
 template <typename T>
-void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_alpha,
-               float *d_vec6, double *d_alpha_raw) {
-  Precision<T> &P = prec<T>(h);
-  const Graph &g = h->g;
-  const Dims d = h->d;
-  hipStream_t st = ln.stream;
-  const int64_t MN = (int64_t)S * g.N, ME = (int64_t)S * g.E;
-  T *node[2] = {ln.node[0].template as<T>(), ln.node[1].template as<T>()};
-  T *edge[2] = {ln.edge[0].template as<T>(), ln.edge[1].template as<T>()};
-  T *unit4 = ln.unit4.template as<T>();
-  T *npc1 = ln.npc1.template as<T>(), *np3 = ln.np3.template as<T>();
-  T *bufA = ln.bufA.template as<T>(), *bufB = ln.bufB.template as<T>();
-  const size_t nbytes = (size_t)MN * d.FnP * sizeof(T), ebytes = (size_t)ME * d.FeP * sizeof(T);
-
-  {
-    Timer t(h, st, K_GEOM);
-    launch_geom_rbf<T>(d_pos, S, g, P.lattice.template as<T>(), P.offsets,
-                       (T)h->cfg.gauss_coefficient, d, unit4, edge[0], st);
-  }
-  {
-    Timer t(h, st, K_NODE_INIT);
-    launch_node_init<T>(P.node_table, S, g, d, node[0], st);
-  }
-  if (h->keep_stages) {
-    HIP_TRY(hipMemcpyAsync(P.snap_node[0].p, node[0], nbytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(P.snap_edge[0].p, edge[0], ebytes, hipMemcpyDeviceToDevice, st));
-  }
+struct ChunkRun {
+  rn_potgnn *h;
+  Lane<T> *ln;
+  const double *d_pos;
+  int S;
+  double *d_alpha;
+  float *d_vec6;
+  double *d_alpha_raw;
   int cur = 0;
-  for (int p = 0; p < h->cfg.num_message_passes; ++p) {
-    const PassW<T> &w = P.pass[p];
+  T *node[2], *edge[2], *unit4, *npc1, *np3, *bufA, *bufB;
+  int64_t MN, ME;
+
+  ChunkRun(rn_potgnn *h_, Lane<T> &l, const double *pos, int S_, double *alpha, float *vec6,
+           double *alpha_raw)
+      : h(h_), ln(&l), d_pos(pos), S(S_), d_alpha(alpha), d_vec6(vec6), d_alpha_raw(alpha_raw) {
+    node[0] = l.node[0].template as<T>();
+    node[1] = l.node[1].template as<T>();
+    edge[0] = l.edge[0].template as<T>();
+    edge[1] = l.edge[1].template as<T>();
+    unit4 = l.unit4.template as<T>();
+    npc1 = l.npc1.template as<T>();
+    np3 = l.np3.template as<T>();
+    bufA = l.bufA.template as<T>();
+    bufB = l.bufB.template as<T>();
+    MN = (int64_t)S * h->g.N;
+    ME = (int64_t)S * h->g.E;
+  }
+  hipStream_t st() const { return ln->stream; }
+  void snapshot(int p) {
+    if (!h->keep_stages) return;
+    Precision<T> &P = prec<T>(h);
+    HIP_TRY(hipMemcpyAsync(P.snap_node[p].p, node[cur], (size_t)MN * h->d.FnP * sizeof(T),
+                           hipMemcpyDeviceToDevice, st()));
+    HIP_TRY(hipMemcpyAsync(P.snap_edge[p].p, edge[cur], (size_t)ME * h->d.FeP * sizeof(T),
+                           hipMemcpyDeviceToDevice, st()));
+  }
+
+  // geometry + radial basis, initial node embedding
+  void begin() {
+    Precision<T> &P = prec<T>(h);
+    {
+      Timer t(h, st(), K_GEOM);
+      launch_geom_rbf<T>(d_pos, S, h->g, P.lattice.template as<T>(), P.offsets,
+                         (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
+    }
+    {
+      Timer t(h, st(), K_NODE_INIT);
+      launch_node_init<T>(P.node_table, S, h->g, h->d, node[0], st());
+    }
+    cur = 0;
+    snapshot(0);
+  }
+
+  // "G" stage of pass p: NodeBlock + every dense projection the EdgeBlock needs
+  // (matrix pipe / HBM bound)
+  void stage_project(int p) {
+    const PassW<T> &w = prec<T>(h).pass[p];
+    const Graph &g = h->g;
+    const Dims d = h->d;
     const int nxt = cur ^ 1;
-    {  // NodeBlock
-      Timer t(h, st, K_PROJ_NODE);
+    {
+      Timer t(h, st(), K_PROJ_NODE);
       launch_rowgemm<T>(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, nullptr, w.c1_bias, false,
-                        0, nullptr, g, st);
+                        0, nullptr, g, st());
     }
     {
-      Timer t(h, st, K_PROJ_EDGE_C1);
+      Timer t(h, st(), K_PROJ_EDGE_C1);
       launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0,
-                        nullptr, g, st);
+                        nullptr, g, st());
     }
     {
-      Timer t(h, st, K_NODE_AGG);
-      launch_node_agg<T>(npc1, bufA, node[cur], node[nxt], S, g, d, w, st);
+      Timer t(h, st(), K_NODE_AGG);
+      launch_node_agg<T>(npc1, bufA, node[cur], node[nxt], S, g, d, w, st());
     }
-    {  // EdgeBlock (uses the UPDATED node embedding, _gnn.py:649-650)
-      Timer t(h, st, K_PROJ_NODE);
+    {  // EdgeBlock uses the UPDATED node embedding (_gnn.py:649-650)
+      Timer t(h, st(), K_PROJ_NODE);
       launch_rowgemm<T>(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, nullptr, w.c3_nshift, false,
-                        0, nullptr, g, st);
+                        0, nullptr, g, st());
     }
-    bool fused = false;
-    if constexpr (sizeof(T) == 4) {
-      if (h->use_fused) {
-        Timer t(h, st, K_EDGE_AGG);
-        launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, g, d, w, st);
-        fused = true;
-      }
-    }
-    if (!fused) {
+    if (!fused()) {
       {
-        Timer t(h, st, K_PROJ_EDGE_C3);
+        Timer t(h, st(), K_PROJ_EDGE_C3);
         launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false,
-                          0, nullptr, g, st);
+                          0, nullptr, g, st());
       }
       {
-        Timer t(h, st, K_PROJ_C2);
+        Timer t(h, st(), K_PROJ_C2);
         launch_rowgemm<T>(nullptr, ME, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1,
-                          node[nxt], g, st);
+                          node[nxt], g, st());
       }
-      {
-        Timer t(h, st, K_EDGE_AGG);
-        launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, g, d, w, st);
+    }
+  }
+
+  // "V" stage of pass p: triplet aggregation of the EdgeBlock (VALU bound)
+  void stage_aggregate(int p) {
+    const PassW<T> &w = prec<T>(h).pass[p];
+    const int nxt = cur ^ 1;
+    {
+      Timer t(h, st(), K_EDGE_AGG);
+      if constexpr (sizeof(T) == 4) {
+        if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, st());
+        else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, st());
+      } else {
+        launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, st());
       }
     }
     cur = nxt;
-    if (h->keep_stages) {
-      HIP_TRY(hipMemcpyAsync(P.snap_node[p + 1].p, node[cur], nbytes, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(P.snap_edge[p + 1].p, edge[cur], ebytes, hipMemcpyDeviceToDevice, st));
+    snapshot(p + 1);
+  }
+
+  // readout MLP (_gnn.py:532-539): bufA <- ssp(BN(L0 edge)), bufB <- ssp(L3 .), bufA <- L5 .
+  void finish() {
+    Precision<T> &P = prec<T>(h);
+    const Graph &g = h->g;
+    const Dims d = h->d;
+    {
+      Timer t(h, st(), K_READOUT_MLP);
+      const int HP = std::max(d.FeP, 32);
+      launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
+                        nullptr, g, st());
+      launch_rowgemm<T>(bufA, ME, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st());
+      launch_rowgemm<T>(bufB, ME, HP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g,
+                        st());
     }
+    {
+      Timer t(h, st(), K_READOUT_REDUCE);
+      const double *ms = h->d_mean_std.as<double>();
+      launch_readout_reduce<T>(bufA, unit4, S, g, ms, ms + 9, d_vec6, d_alpha, d_alpha_raw, st());
+    }
+    HIP_TRY(hipGetLastError());
   }
-  {  // readout MLP (_gnn.py:532-539): bufA <- ssp(BN(L0 edge)), bufB <- ssp(L3 .), bufA <- L5 .
-    Timer t(h, st, K_READOUT_MLP);
-    const int HP = std::max(d.FeP, 32);
-    launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
-                      nullptr, g, st);
-    launch_rowgemm<T>(bufA, ME, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
-    launch_rowgemm<T>(bufB, ME, HP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g, st);
+  bool fused() const { return sizeof(T) == 4 && h->use_fused; }
+};
+
+template <typename T>
+void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_alpha,
+               float *d_vec6, double *d_alpha_raw) {
+  ChunkRun<T> c(h, ln, d_pos, S, d_alpha, d_vec6, d_alpha_raw);
+  c.begin();
+  for (int p = 0; p < h->cfg.num_message_passes; ++p) {
+    c.stage_project(p);
+    c.stage_aggregate(p);
   }
-  {
-    Timer t(h, st, K_READOUT_REDUCE);
-    const double *ms = h->d_mean_std.as<double>();
-    launch_readout_reduce<T>(bufA, unit4, S, g, ms, ms + 9, d_vec6, d_alpha, d_alpha_raw, st);
+  c.finish();
+}
+
+// Two chunks A, B on the two lanes with their stages forced to alternate:
+//   lane A:  G_A(0)  V_A(0)  G_A(1)  V_A(1) ...
+//   lane B:          G_B(0)  V_B(0)  G_B(1) ...
+// G_B(p) waits for G_A(p) and G_A(p+1) waits for G_B(p), so the two G stages never run
+// together while each V stage (VALU-bound triplet loop) has the other chunk's G stage
+// (matrix pipe + HBM streams) as its only companion on the chip.
+template <typename T>
+void run_pair(rn_potgnn *h, ChunkRun<T> &a, ChunkRun<T> &b) {
+  const int P = h->cfg.num_message_passes;
+  a.begin();
+  b.begin();
+  for (int p = 0; p < P; ++p) {
+    if (p > 0) HIP_TRY(hipStreamWaitEvent(a.st(), h->ev_g[1], 0));  // after G_B(p-1)
+    a.stage_project(p);
+    HIP_TRY(hipEventRecord(h->ev_g[0], a.st()));
+    a.stage_aggregate(p);
+    HIP_TRY(hipStreamWaitEvent(b.st(), h->ev_g[0], 0));             // after G_A(p)
+    b.stage_project(p);
+    HIP_TRY(hipEventRecord(h->ev_g[1], b.st()));
+    b.stage_aggregate(p);
   }
-  HIP_TRY(hipGetLastError());
+  a.finish();
+  b.finish();
 }
 
 template <typename T>
@@ -550,16 +628,29 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
   HIP_TRY(hipEventRecord(h->ev_start, user));
   const int lanes = h->num_lanes;
   for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(P.lanes[l].stream, h->ev_start, 0));
+  auto make = [&](int lane, int64_t first, int s) {
+    return ChunkRun<T>(h, P.lanes[lane], d_pos + first * N * 3, s,
+                       d_alpha ? d_alpha + first * 9 : nullptr, d_vec6 ? d_vec6 + first * 6 : nullptr,
+                       d_alpha_raw ? d_alpha_raw + first * 9 : nullptr);
+  };
   int64_t done = 0;
-  int ci = 0;
   while (done < S) {
-    const int s = (int)std::min<int64_t>(h->chunk, S - done);
-    Lane<T> &ln = P.lanes[ci % lanes];
-    run_chunk<T>(h, ln, d_pos + done * N * 3, s, d_alpha ? d_alpha + done * 9 : nullptr,
-                 d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr);
-    h->last_chunk_structs = s;
-    done += s;
-    ++ci;
+    const int64_t left = S - done;
+    if (lanes == 2 && h->interleave && !h->keep_stages && left > 1) {
+      // split what is left of this round evenly over the two lanes
+      const int64_t both = std::min<int64_t>(left, 2 * (int64_t)h->chunk);
+      const int sa = (int)((both + 1) / 2), sb = (int)(both - sa);
+      ChunkRun<T> a = make(0, done, sa), b = make(1, done + sa, sb);
+      run_pair<T>(h, a, b);
+      h->last_chunk_structs = sa;
+      done += both;
+    } else {
+      const int s = (int)std::min<int64_t>(h->chunk, left);
+      run_chunk<T>(h, P.lanes[0], d_pos + done * N * 3, s, d_alpha ? d_alpha + done * 9 : nullptr,
+                   d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr);
+      h->last_chunk_structs = s;
+      done += s;
+    }
   }
   h->last_was_f64 = sizeof(T) == 8;
   for (int l = 0; l < lanes; ++l) {
@@ -675,6 +766,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   std::memcpy(h->stdv, stddev, sizeof(h->stdv));
   h->keep_stages = getenv("RN_POTGNN_KEEP_STAGES") && atoi(getenv("RN_POTGNN_KEEP_STAGES")) != 0;
   h->debug_sync = getenv("RN_POTGNN_DEBUG_SYNC") && atoi(getenv("RN_POTGNN_DEBUG_SYNC")) != 0;
+  if (const char *e = getenv("RN_POTGNN_INTERLEAVE")) h->interleave = atoi(e) != 0;
   if (const char *e = getenv("RN_POTGNN_LANES")) h->num_lanes = std::max(1, std::min(2, atoi(e)));
 
   // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets
@@ -699,7 +791,11 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   const Dims d = h->d;
   // node tiles: consecutive atoms whose outgoing-edge rows fit the LDS budget
   // (budget counted in float32 rows; the float64 path uses twice the bytes for the same tiles)
-  const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB")) : 36;
+  // 64 KiB tiles for wide embeddings (8 columns per lane: 32 destinations per round, two
+  // workgroups per CU), 36 KiB otherwise (three to four workgroups per CU)
+  const bool vpl8 = getenv("RN_POTGNN_VPL") && atoi(getenv("RN_POTGNN_VPL")) == 8;
+  const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB"))
+                                                     : ((d.FeP >= 64 && vpl8) ? 64 : 36);
   const size_t budget_rows = std::max<size_t>(1, tile_kb * 1024 / ((size_t)2 * d.FeP * sizeof(float)));
   const size_t cap_rows = (size_t)150 * 1024 / ((size_t)2 * d.FeP * sizeof(double) + 4);
   int max_rows = 0;
@@ -742,6 +838,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   int rc = guarded(nullptr, [&]() {
     HIP_TRY(hipSetDevice(cfg->device));
     HIP_TRY(hipEventCreateWithFlags(&hp->ev_start, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&hp->ev_g[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&hp->ev_g[1], hipEventDisableTiming));
     // upload all int arrays in one allocation
     std::vector<int> ints;
     auto push = [&](const std::vector<int> &v) {
@@ -770,9 +868,12 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.tile_begin = base + o_tb;
     g.max_tile_out_rows = max_rows;
     g.max_tile_in_rows = 0;
-    for (size_t t = 0; t + 1 < hp->tile_begin.size(); ++t)
+    g.max_tile_nodes = 0;
+    for (size_t t = 0; t + 1 < hp->tile_begin.size(); ++t) {
       g.max_tile_in_rows = std::max(g.max_tile_in_rows,
                                     hp->in_ptr[hp->tile_begin[t + 1]] - hp->in_ptr[hp->tile_begin[t]]);
+      g.max_tile_nodes = std::max(g.max_tile_nodes, hp->tile_begin[t + 1] - hp->tile_begin[t]);
+    }
     g.trip_off = base + o_to;
     g.T = hp->trip_off[E];
     double ms[18];
@@ -794,7 +895,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       chunk = std::min(chunk, 2048);
     }
     hp->chunk = chunk;
-    const bool want_fused = !(getenv("RN_POTGNN_FUSED") && atoi(getenv("RN_POTGNN_FUSED")) == 0);
+    // The single-launch fused EdgeBlock (kernels_fused.hip) is opt-in: on MI355X it is
+    // slower than projections + edge_agg (weights pinned in VGPRs cap it at 2 waves/SIMD).
+    const bool want_fused = getenv("RN_POTGNN_FUSED") && atoi(getenv("RN_POTGNN_FUSED")) != 0;
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
     ensure_precision<float>(hp);
   });
@@ -815,6 +918,8 @@ void rn_potgnn_destroy(rn_potgnn *h) {
     if (h->f64.lanes[l].done) (void)hipEventDestroy(h->f64.lanes[l].done);
   }
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  for (int i = 0; i < 2; ++i)
+    if (h->ev_g[i]) (void)hipEventDestroy(h->ev_g[i]);
   delete h;
 }
 

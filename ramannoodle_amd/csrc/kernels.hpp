@@ -20,6 +20,7 @@ struct Graph {
   const int *tile_begin;  // [num_tiles+1] node ranges
   int max_tile_out_rows;  // LDS rows needed by the largest tile
   int max_tile_in_rows;   // most destination edges entering one tile
+  int max_tile_nodes;     // most atoms in one tile
   // triplet enumeration
   const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
   int64_t T;

@@ -7,6 +7,9 @@
 // (16-byte loads/stores, LayerNorm statistics by DPP butterflies inside the group).
 // Gated rows are [filter | core] of width 2*FP; a lane holds filter columns 4q..4q+3
 // and the matching core columns FP+4q.., so sigmoid(filter)*tanh(core) is lane-local.
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -286,10 +289,18 @@ struct GateScale<double> {
   static constexpr double kC = 2.0 * 1.4426950408889634;
   static constexpr double kClamp = 115.0;  // tanh == 1 to 1e-34 there; exp2(115) finite
 };
+#ifndef RN_EXPERIMENT
+#define RN_EXPERIMENT 0
+#endif
 __device__ __forceinline__ float gate_exp2(float yf, float yc) {
   yc = fminf(fmaxf(yc, -GateScale<float>::kClamp), GateScale<float>::kClamp);
+#if RN_EXPERIMENT == 1  // timing-only: no transcendental instructions
+  const float e1 = yf * 0.5f + 1.0f, e2 = yc * 0.25f + 1.0f;
+  return (e2 - 1.0f) * ((1.0f + e1) * (1.0f + e2));
+#else
   const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
   return (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
+#endif
 }
 __device__ __forceinline__ double gate_exp2(double yf, double yc) {
   yc = fmin(fmax(yc, -GateScale<double>::kClamp), GateScale<double>::kClamp);
@@ -297,23 +308,54 @@ __device__ __forceinline__ double gate_exp2(double yf, double yc) {
   return (e2 - 1.0) / ((1.0 + e1) * (1.0 + e2));
 }
 
-template <typename T>
-struct DestRows {  // the three addends of P'_d (fetched one destination ahead)
-  Vec4<T> pf, pc, jf, jc, kf, kc;
-};
+// `VPL` = columns per lane and half row (4 or 8).  With 8, a lane group is half as wide, so
+// the per-triplet overhead (dot product, DPP reduction, variance, addressing) is
+// amortised over twice the gate evaluations per lane; used for Fe >= 64.
+template <int VPL, typename T>
+__device__ __forceinline__ void loadv(T (&dst)[VPL], const T *p) {
+#pragma unroll
+  for (int j = 0; j < VPL; j += 4) {
+    const Vec4<T> t = load4<T>(p + j);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[j + k] = t.v[k];
+  }
+}
+template <int VPL, typename T>
+__device__ __forceinline__ void storev(T *p, const T (&src)[VPL]) {
+#pragma unroll
+  for (int j = 0; j < VPL; j += 4) store4(p + j, Vec4<T>{{src[j], src[j + 1], src[j + 2], src[j + 3]}});
+}
 
-template <int LG, bool PAD, typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 3)) void edge_agg_kernel(const T *__restrict__ pq,
-                                                       const T *__restrict__ np3,
-                                                       const T *__restrict__ c2pre,
-                                                       const T *__restrict__ edge_in,
-                                                       T *__restrict__ edge_out, int S, Graph g,
-                                                       Dims d, PassW<T> w) {
-  constexpr int FP = LG * 4;
-  constexpr int G = 256 / LG;  // lane groups per workgroup
+// LayerNorm over a row of width F held VPL columns per lane by a lane group.
+template <int LG, int VPL, bool PAD, typename T>
+__device__ __forceinline__ void ln_rowv(T (&x)[VPL], const T *gam, const T *bet, T inv_n, int nvalid) {
+  T s = 0;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) s += x[k];
+  const T mean = lg_sum<LG>(s) * inv_n;
+  T qq = 0;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    x[k] = (!PAD || k < nvalid) ? x[k] - mean : (T)0;
+    qq += x[k] * x[k];
+  }
+  const T rstd = fast_rsq(lg_sum<LG>(qq) * inv_n + (T)1e-5);
+  T g[VPL], b[VPL];
+  loadv<VPL>(g, gam);
+  loadv<VPL>(b, bet);
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) x[k] = x[k] * rstd * g[k] + b[k];
+}
+
+template <int FP, int VPL, bool PAD, typename T>
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : 3))) void edge_agg_kernel(
+    const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
+    const T *__restrict__ edge_in, T *__restrict__ edge_out, int S, Graph g, Dims d, PassW<T> w) {
+  constexpr int LG = FP / VPL;   // lanes per row
+  constexpr int G = 256 / LG;    // lane groups (= destination edges in flight) per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // LDS carve-up (every region 16-byte aligned)
-  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows;
+  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     unsigned char *p = smem_raw + off;
@@ -322,13 +364,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 3)) void edge_agg_kernel
   };
   T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));  // centred Q' rows
   T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));               // |q|^2
+  T *nj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));      // Wj node[j] + bias
   // per-destination LayerNorm parameters (read once per destination: keep them out of VGPRs)
   T *lnp = reinterpret_cast<T *>(carve((size_t)8 * FP * sizeof(T)));
   T *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
     *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP;
   int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));                   // b_e
   int *dl = reinterpret_cast<int *>(carve((size_t)maxD * 6 * 4));               // topology
-  int *d_edge = dl, *d_a = dl + maxD, *d_b = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
+  int *d_edge = dl, *d_a = dl + maxD, *d_bl = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
       *d_cnt = dl + 4 * maxD, *d_skip = dl + 5 * maxD;
   for (int c = threadIdx.x; c < 2 * FP; c += 256) {
     s_c2n1g[c] = w.c2_norm_1.g[c];
@@ -356,7 +399,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 3)) void edge_agg_kernel
     const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
     d_edge[i] = dst;
     d_a[i] = ad;
-    d_b[i] = bd;
+    d_bl[i] = bd - j0;  // tile-local index of the destination atom
     d_rb[i] = rb;
     d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
     d_skip[i] = rev >= 0 ? rev - eo0 : re;
@@ -364,95 +407,103 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 3)) void edge_agg_kernel
   __syncthreads();
 
   const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
-  const int nvalid = min(max(d.Fe - 4 * q, 0), 4);
+  const int c0 = VPL * q;  // first column of this lane in either half
+  const int nvalid = min(max(d.Fe - c0, 0), VPL);
   const T inv2n = (T)1 / (T)(2 * d.Fe), invn = (T)1 / (T)d.Fe;
   // c3_norm_1 with the exp2 scale of the gate folded in
-  T g3f[4], b3f[4], g3c[4], b3c[4];
-  {
-    const Vec4<T> gf = load4<T>(w.c3_norm_1.g + 4 * q), bf = load4<T>(w.c3_norm_1.b + 4 * q);
-    const Vec4<T> gc = load4<T>(w.c3_norm_1.g + FP + 4 * q), bc = load4<T>(w.c3_norm_1.b + FP + 4 * q);
+  T g3f[VPL], b3f[VPL], g3c[VPL], b3c[VPL];
+  loadv<VPL>(g3f, w.c3_norm_1.g + c0);
+  loadv<VPL>(b3f, w.c3_norm_1.b + c0);
+  loadv<VPL>(g3c, w.c3_norm_1.g + FP + c0);
+  loadv<VPL>(b3c, w.c3_norm_1.b + FP + c0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      g3f[i] = GateScale<T>::kF * gf.v[i];
-      b3f[i] = GateScale<T>::kF * bf.v[i];
-      g3c[i] = GateScale<T>::kC * gc.v[i];
-      b3c[i] = GateScale<T>::kC * bc.v[i];
-    }
+  for (int k = 0; k < VPL; ++k) {
+    g3f[k] *= GateScale<T>::kF;
+    b3f[k] *= GateScale<T>::kF;
+    g3c[k] *= GateScale<T>::kC;
+    b3c[k] *= GateScale<T>::kC;
   }
-
-  auto load_dest = [&](int i, int64_t erow0, int64_t nrow0) {
-    DestRows<T> r;
-    const int64_t drow = erow0 + d_edge[i];
-    const T *pp = pq + drow * (4 * FP) + 4 * q;
-    const T *nj = np3 + (nrow0 + d_b[i]) * (6 * FP) + 2 * FP + 4 * q;
-    const T *nk = np3 + (nrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
-    r.pf = load4<T>(pp);
-    r.pc = load4<T>(pp + FP);
-    r.jf = load4<T>(nj);
-    r.jc = load4<T>(nj + FP);
-    r.kf = load4<T>(nk);
-    r.kc = load4<T>(nk + FP);
-    return r;
-  };
 
   for (int s = sg; s < S; s += nsg) {
     const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    // ---- per-atom part of P': Wj node[j] + bias for the tile's atoms
+    for (int i = threadIdx.x; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+      const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
+      store4(nj + (size_t)n * 2 * FP + c, load4<T>(np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + c));
+    }
     // ---- stage source rows: Q'_e = W5 edge_e + Wi node[b_e], centred, with |q|^2
     for (int r = grp; r < rows; r += G) {
-      const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
-      const T *np = np3 + (nrow0 + qb[r]) * (6 * FP) + 4 * q;
-      Vec4<T> f = load4<T>(qp), c = load4<T>(qp + FP);
-      const Vec4<T> nf = load4<T>(np), nc = load4<T>(np + FP);
+      const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + c0;
+      const T *np = np3 + (nrow0 + qb[r]) * (6 * FP) + c0;
+      T f[VPL], c[VPL], nf[VPL], nc[VPL];
+      loadv<VPL>(f, qp);
+      loadv<VPL>(c, qp + FP);
+      loadv<VPL>(nf, np);
+      loadv<VPL>(nc, np + FP);
       T sum = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f.v[i] += nf.v[i];
-        c.v[i] += nc.v[i];
-        sum += f.v[i] + c.v[i];
+      for (int k = 0; k < VPL; ++k) {
+        f[k] += nf[k];
+        c[k] += nc[k];
+        sum += f[k] + c[k];
       }
       const T mean = lg_sum<LG>(sum) * inv2n;
       T ss = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f.v[i] = (!PAD || i < nvalid) ? f.v[i] - mean : (T)0;
-        c.v[i] = (!PAD || i < nvalid) ? c.v[i] - mean : (T)0;
-        ss += f.v[i] * f.v[i] + c.v[i] * c.v[i];
+      for (int k = 0; k < VPL; ++k) {
+        f[k] = (!PAD || k < nvalid) ? f[k] - mean : (T)0;
+        c[k] = (!PAD || k < nvalid) ? c[k] - mean : (T)0;
+        ss += f[k] * f[k] + c[k] * c[k];
       }
       ss = lg_sum<LG>(ss);
-      store4(qrows + (size_t)r * 2 * FP + 4 * q, f);
-      store4(qrows + (size_t)r * 2 * FP + FP + 4 * q, c);
+      storev<VPL>(qrows + (size_t)r * 2 * FP + c0, f);
+      storev<VPL>(qrows + (size_t)r * 2 * FP + FP + c0, c);
       if (q == 0) sq[r] = ss;
     }
     __syncthreads();
 
     // ---- destination edges of the tile; the next destination's rows are fetched while the
     //      current one's triplets are evaluated
+    T nxt_pf[VPL], nxt_pc[VPL], nxt_kf[VPL], nxt_kc[VPL];
+    auto fetch = [&](int i) {
+      const T *pp = pq + (erow0 + d_edge[i]) * (4 * FP) + c0;
+      const T *nk = np3 + (nrow0 + d_a[i]) * (6 * FP) + 4 * FP + c0;
+      loadv<VPL>(nxt_pf, pp);
+      loadv<VPL>(nxt_pc, pp + FP);
+      loadv<VPL>(nxt_kf, nk);
+      loadv<VPL>(nxt_kc, nk + FP);
+    };
     int i = grp;
-    DestRows<T> cur;
-    if (i < dcount) cur = load_dest(i, erow0, nrow0);
+    if (i < dcount) fetch(i);
     while (i < dcount) {
+      // P'_d = W4 edge_d + Wk node[a_d] + (Wj node[b_d] + bias), centred
+      T pf[VPL], pc[VPL];
+      {
+        T jf[VPL], jc[VPL];
+        loadv<VPL>(jf, nj + (size_t)d_bl[i] * 2 * FP + c0);
+        loadv<VPL>(jc, nj + (size_t)d_bl[i] * 2 * FP + FP + c0);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+          pf[k] = nxt_pf[k] + nxt_kf[k] + jf[k];
+          pc[k] = nxt_pc[k] + nxt_kc[k] + jc[k];
+        }
+      }
       const int inext = i + G;
-      DestRows<T> nxt;
-      if (inext < dcount) nxt = load_dest(inext, erow0, nrow0);
+      if (inext < dcount) fetch(inext);
       // this destination's c2 pre-activation and old embedding arrive during the triplet loop
       const int64_t drow = erow0 + d_edge[i];
-      const Vec4<T> c2f = load4<T>(c2pre + drow * (2 * FP) + 4 * q);
-      const Vec4<T> c2c = load4<T>(c2pre + drow * (2 * FP) + FP + 4 * q);
-      const Vec4<T> old = load4<T>(edge_in + drow * FP + 4 * q);
+      T c2f[VPL], c2c[VPL], old[VPL];
+      loadv<VPL>(c2f, c2pre + drow * (2 * FP) + c0);
+      loadv<VPL>(c2c, c2pre + drow * (2 * FP) + FP + c0);
+      loadv<VPL>(old, edge_in + drow * FP + c0);
 
-      // P'_d, centred
-      T pf[4], pc[4];
       T sum = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        pf[k] = cur.pf.v[k] + cur.jf.v[k] + cur.kf.v[k];
-        pc[k] = cur.pc.v[k] + cur.jc.v[k] + cur.kc.v[k];
-        sum += pf[k] + pc[k];
-      }
+      for (int k = 0; k < VPL; ++k) sum += pf[k] + pc[k];
       const T mean = lg_sum<LG>(sum) * inv2n;
       T sp = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < VPL; ++k) {
         pf[k] = (!PAD || k < nvalid) ? pf[k] - mean : (T)0;
         pc[k] = (!PAD || k < nvalid) ? pc[k] - mean : (T)0;
         sp += pf[k] * pf[k] + pc[k] * pc[k];
@@ -460,45 +511,64 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 3)) void edge_agg_kernel
       sp = lg_sum<LG>(sp);
 
       const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
-      T acc[4] = {0, 0, 0, 0};
-#pragma unroll 2
+      T acc[VPL];
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) acc[k] = 0;
       for (int t = 0; t < cnt; ++t) {
         const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
-        const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
-        const Vec4<T> qf = load4<T>(qr);
-        const Vec4<T> qc = load4<T>(qr + FP);
+        const T *qr = qrows + (size_t)r * 2 * FP + c0;
+        T qf[VPL], qc[VPL];
+        loadv<VPL>(qf, qr);
+        loadv<VPL>(qc, qr + FP);
         T dot = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dot += pf[k] * qf.v[k] + pc[k] * qc.v[k];
+        for (int k = 0; k < VPL; ++k) dot += pf[k] * qf[k] + pc[k] * qc[k];
+#if RN_EXPERIMENT != 2  // timing-only variant 2: no cross-lane reduction
         dot = lg_sum<LG>(dot);
+#endif
         T var = (sp + sq[r] + (T)2 * dot) * inv2n;
         var = var > (T)0 ? var : (T)0;
         const T rstd = fast_rsq(var + (T)1e-5);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const T yf = ((pf[k] + qf.v[k]) * rstd) * g3f[k] + b3f[k];
-          const T yc = ((pc[k] + qc.v[k]) * rstd) * g3c[k] + b3c[k];
+        for (int k = 0; k < VPL; ++k) {
+          const T yf = ((pf[k] + qf[k]) * rstd) * g3f[k] + b3f[k];
+          const T yc = ((pc[k] + qc[k]) * rstd) * g3c[k] + b3c[k];
           acc[k] += gate_exp2(yf, yc);
         }
       }
-      const LnParams<T> p3n{load4<T>(s_c3n2g + 4 * q), load4<T>(s_c3n2b + 4 * q)};
-      const Vec4<T> c3 = ln_row<LG, PAD>(Vec4<T>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+      ln_rowv<LG, VPL, PAD>(acc, s_c3n2g + c0, s_c3n2b + c0, invn, nvalid);  // c3 (_gnn.py:291)
 
       // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
-      const LnParams<T> p2f{load4<T>(s_c2n1g + 4 * q), load4<T>(s_c2n1b + 4 * q)};
-      const LnParams<T> p2c{load4<T>(s_c2n1g + FP + 4 * q), load4<T>(s_c2n1b + FP + 4 * q)};
-      const Vec4<T> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
-      const LnParams<T> p2n{load4<T>(s_c2n2g + 4 * q), load4<T>(s_c2n2b + 4 * q)};
-      const Vec4<T> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
-
-      Vec4<T> out;
+      {
+        T sm = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) out.v[k] = acc_tanh(old.v[k] + c2.v[k] + c3.v[k]);
-      store4(edge_out + drow * FP + 4 * q, out);
-      cur = nxt;
+        for (int k = 0; k < VPL; ++k) sm += c2f[k] + c2c[k];
+        const T m2 = lg_sum<LG>(sm) * inv2n;
+        T q2 = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+          c2f[k] = (!PAD || k < nvalid) ? c2f[k] - m2 : (T)0;
+          c2c[k] = (!PAD || k < nvalid) ? c2c[k] - m2 : (T)0;
+          q2 += c2f[k] * c2f[k] + c2c[k] * c2c[k];
+        }
+        const T r2 = fast_rsq(lg_sum<LG>(q2) * inv2n + (T)1e-5);
+        T gf[VPL], bf[VPL], gc[VPL], bc[VPL];
+        loadv<VPL>(gf, s_c2n1g + c0);
+        loadv<VPL>(bf, s_c2n1b + c0);
+        loadv<VPL>(gc, s_c2n1g + FP + c0);
+        loadv<VPL>(bc, s_c2n1b + FP + c0);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+          c2f[k] = gate(c2f[k] * r2 * gf[k] + bf[k], c2c[k] * r2 * gc[k] + bc[k]);
+        ln_rowv<LG, VPL, PAD>(c2f, s_c2n2g + c0, s_c2n2b + c0, invn, nvalid);
+      }
+      T out[VPL];
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) out[k] = acc_tanh(old[k] + c2f[k] + acc[k]);
+      storev<VPL>(edge_out + drow * FP + c0, out);
       i = inext;
     }
-    __syncthreads();  // qrows are restaged for the next frame
+    __syncthreads();  // qrows / nj are restaged for the next frame
   }
 }
 
@@ -514,11 +584,48 @@ static int num_cus() {
   return n;
 }
 
+// Tunables (environment, read once).  Leaving VGPR/LDS room next to the persistent
+// aggregation workgroups lets the MFMA-bound projection kernels of the other stream run on
+// the same CUs at the same time (matrix pipe + HBM beside the VALU-bound triplet loop).
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int agg_wgs_per_cu_cap() {
+  static int v = env_int("RN_POTGNN_AGG_WGS_PER_CU", 2);
+  return v < 1 ? 1 : v;
+}
+static int agg_vpl() {
+  static int v = env_int("RN_POTGNN_VPL", 4);
+  return v;
+}
+
 size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   return up((size_t)g.max_tile_out_rows * 2 * d.FeP * elem) + up((size_t)g.max_tile_out_rows * elem) +
-         up((size_t)8 * d.FeP * elem) + up((size_t)g.max_tile_out_rows * 4) +
-         up((size_t)g.max_tile_in_rows * 6 * 4);
+         up((size_t)g.max_tile_nodes * 2 * d.FeP * elem) + up((size_t)8 * d.FeP * elem) +
+         up((size_t)g.max_tile_out_rows * 4) + up((size_t)g.max_tile_in_rows * 6 * 4);
+}
+
+template <int FP, int VPL, bool PAD, typename T>
+static void launch_edge_agg_cfg(const T *pq, const T *np3, const T *c2pre, const T *edge_in,
+                                T *edge_out, int S, const Graph &g, Dims d, const PassW<T> &w,
+                                size_t lds, hipStream_t st) {
+  // Persistent workgroups: one per (tile, frame group).  The grid is sized to exactly the
+  // number of workgroups the chip holds at once (a partial second round would leave two
+  // thirds of the CUs idle: measured 2.25 instead of 3 waves/SIMD).
+  auto kern = &edge_agg_kernel<FP, VPL, PAD, T>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  per_cu = std::min(per_cu, agg_wgs_per_cu_cap());
+  int nsg = per_cu * num_cus() / g.num_tiles;
+  nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)g.num_tiles, 256, lds, st>>>(pq, np3, c2pre, edge_in, edge_out, S,
+                                                                g, d, w);
 }
 
 template <typename T>
@@ -526,27 +633,20 @@ void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in
                      int S, const Graph &g, Dims d, const PassW<T> &w, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
   const size_t lds = edge_agg_lds_bytes(g, d, sizeof(T));
-  // Persistent workgroups: one per (tile, frame group).  The grid is sized to exactly the
-  // number of workgroups the chip holds at once (a partial second round would leave two
-  // thirds of the CUs idle: measured 2.25 instead of 3 waves/SIMD).
   const bool pad = d.Fe != d.FeP;
-#define CALL(LGV, PADV)                                                                       \
-  do {                                                                                        \
-    auto kern = &edge_agg_kernel<LGV, PADV, T>;                                               \
-    if (lds > 48 * 1024)                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-    int per_cu = 0;                                                                           \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || \
-        per_cu < 1)                                                                           \
-      per_cu = 1;                                                                             \
-    int nsg = per_cu * num_cus() / g.num_tiles;                                               \
-    nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);                                                  \
-    const unsigned blocks = (unsigned)nsg * (unsigned)g.num_tiles;                            \
-    kern<<<blocks, 256, lds, st>>>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w);            \
+#define RN_EA(FPV, VPLV)                                                                          \
+  do {                                                                                            \
+    if (pad) launch_edge_agg_cfg<FPV, VPLV, true, T>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w, lds, st); \
+    else launch_edge_agg_cfg<FPV, VPLV, false, T>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w, lds, st);    \
   } while (0)
-  RN_DISPATCH_LG(d.FeP, pad, CALL);
-#undef CALL
+  const bool wide = sizeof(T) == 4 && agg_vpl() == 8;  // 8 columns per lane: float32, opt-in
+  switch (d.FeP) {
+    case 16: RN_EA(16, 4); break;
+    case 32: RN_EA(32, 4); break;
+    case 64: if (wide) RN_EA(64, 8); else RN_EA(64, 4); break;
+    case 128: if (wide) RN_EA(128, 8); else RN_EA(128, 4); break;
+  }
+#undef RN_EA
 }
 template void launch_edge_agg<float>(const float *, const float *, const float *, const float *,
                                      float *, int, const Graph &, Dims, const PassW<float> &,

@@ -6,6 +6,8 @@
 // the weights live in registers as MFMA B-fragments for the whole kernel, X tiles are
 // staged through LDS, and the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 does
 // the arithmetic (result == an fp32 fma chain, so parity with the fp32 reference holds).
+#include <cstdlib>
+
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -165,7 +167,8 @@ static void launch_mfma_kp(const GemmArgs &a, int amode, int epi, hipStream_t st
   int slice = 32;
   if (a.NOUT % 64 == 0) slice = 64;
   if (a.NOUT % 128 == 0) slice = 128;
-  if (a.NOUT % 256 == 0 && KP <= 64) slice = 256;
+  static const int max_slice = getenv("RN_POTGNN_GEMM_MAXSLICE") ? atoi(getenv("RN_POTGNN_GEMM_MAXSLICE")) : 256;
+  if (a.NOUT % 256 == 0 && KP <= 64 && max_slice >= 256) slice = 256;
   const int64_t tiles = (a.M + 127) / 128;
   dim3 grid((unsigned)(tiles < 2048 ? tiles : 2048), (unsigned)(a.NOUT / slice));
   switch (slice) {

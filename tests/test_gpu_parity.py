@@ -165,11 +165,20 @@ def test_full_size_properties():
 
 
 def test_fused_edge_block_equals_unfused(monkeypatch):
-    """The fused EdgeBlock kernel (MFMA projections + triplet stage in one launch) and the
-    unfused kernel chain are two implementations of the same math."""
+    """The opt-in fused EdgeBlock kernel (MFMA projections + triplet stage in one launch) and
+    the default kernel chain are two implementations of the same math; so are the two lane
+    widths of the aggregation kernel and the interleaved / sequential schedules."""
     from bench import make_workload
     wl = make_workload(num_cells=(2, 2, 2), frames=9, hparams="perf", seed=3)
-    fused = wl["model"]().calc_polarizabilities(wl["positions"])
-    monkeypatch.setenv("RN_POTGNN_FUSED", "0")
     unfused = wl["model"]().calc_polarizabilities(wl["positions"])
+    monkeypatch.setenv("RN_POTGNN_FUSED", "1")
+    fused = wl["model"]().calc_polarizabilities(wl["positions"])
     assert _rel_err(fused, unfused) < 2e-6
+    monkeypatch.setenv("RN_POTGNN_FUSED", "0")
+    monkeypatch.setenv("RN_POTGNN_VPL", "8")
+    wide = wl["model"]().calc_polarizabilities(wl["positions"])
+    assert _rel_err(wide, unfused) < 2e-6
+    monkeypatch.setenv("RN_POTGNN_VPL", "4")
+    monkeypatch.setenv("RN_POTGNN_INTERLEAVE", "0")
+    seq = wl["model"]().calc_polarizabilities(wl["positions"])
+    np.testing.assert_array_equal(seq, unfused)
