@@ -127,6 +127,16 @@ def algorithmic_bytes_edge_block(n, e, fn, fe):
     return 4 * (n * fn + 2 * e * fe)
 
 
+def measured_traffic(n, e, fn, fe, frames, passes, steps, launches):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01/edge_agg_traffic.json), when they were taken on this workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "edge_agg_traffic.json")
+    if not (launches and os.path.exists(path) and (n, e, fn, fe) == (128, 2304, 64, 64)):
+        return None
+    per_structure_pass = json.load(open(path))["hbm_bytes_per_structure_pass"]
+    return per_structure_pass * frames * passes * steps / launches
+
+
 def cpu_baseline(workload, sample):
     """The oracle's faithful restatement of the reference CPU path, on `sample` frames."""
     from oracle import potgnn_oracle as O
@@ -153,7 +163,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
     ap.add_argument("--cells", type=str, default="4,2,2")
     ap.add_argument("--hparams", choices=list(HPARAMS), default="perf")
-    ap.add_argument("--cpu-sample", type=int, default=25)
+    ap.add_argument("--cpu-sample", type=int, default=100,
+                    help="frames for the CPU baseline (100 = one reference sub-batch)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--profile-all", action="store_true",
@@ -206,6 +217,11 @@ def main():
         elapsed = float(t.item())
     times = model.kernel_times()
     model.set_profiling(0)
+    # informational: the host-buffer entry point (adds PCIe H2D/D2H); never the headline value
+    host_pos = wl["positions"]
+    t1 = time.perf_counter()
+    model.calc_polarizabilities(host_pos)
+    host_rate = args.frames / (time.perf_counter() - t1)
 
     if rank == 0:
         agg_ms, agg_launches = times.get("edge_agg", (0.0, 0))
@@ -241,11 +257,15 @@ def main():
                 "peak": peak,
                 "unit": "GB/s",
                 "frac": achieved / peak if achieved else None,
-                "traffic": None,
+                "traffic": measured_traffic(n, e, fn, fe, args.frames, passes, args.steps, agg_launches),
                 "launches": agg_launches,
                 "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
                 "algorithmic_bytes_per_structure_pass": algorithmic_bytes_edge_block(n, e, fn, fe),
+                "note": "edge_agg is VALU/transcendental-bound (DESIGN.md section 5): ~22 VALU "
+                        "instructions incl. 3 transcendentals per (triplet, feature pair); "
+                        "achieved/peak are the HBM figures the metric asks for",
             },
+            "host_buffers_structures_per_s": host_rate,
         }
         if args.profile_all:
             result["kernel_ms"] = {k: round(v[0], 3) for k, v in times.items()}
