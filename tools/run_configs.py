@@ -48,7 +48,8 @@ zs = np.array([12 if k % 2 == 0 else 8 for k in range(n)])  # masses only scale 
 mass = np.where(zs == 12, 24.305, 15.999)
 disp = (qmat.T.reshape(3 * n, n, 3) / np.sqrt(mass)[None, :, None]) / np.diag(wl["lattice"])[None, None, :]
 wn = np.linspace(50.0, 900.0, 3 * n)
-ref = wl["positions"][0] * 0 + (np.round(wl["positions"][0] * 16) / 16)  # ideal rocksalt sites
+ref = wl["positions"][0]  # a thermally displaced frame: the ideal sites are inversion centres
+                           # (first-order Raman forbidden, all tensors vanish)
 ph = Phonons(ref, wn, disp)
 t = time.perf_counter()
 spec = ph.get_raman_spectrum(model)
