@@ -123,6 +123,24 @@ int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions,
                             const double *displacements, int64_t M, double delta,
                             double *raman);
 
+/*
+ * Jacobian of the standardised 6-vector (PotGNN.forward, eval mode) with respect to the
+ * fractional coordinates at one structure, by reverse-mode differentiation on the device:
+ *   jac[k][n][c] = d vec6_k / d x_{n,c},   jac is host f64[6*N*3].
+ * use_float64 != 0 evaluates forward and reverse passes in double precision.
+ */
+int rn_potgnn_alpha_jacobian(rn_potgnn *h, const double *positions, int use_float64, double *jac);
+
+/*
+ * Analytic counterpart of rn_potgnn_raman_tensors -- the d(alpha)/d(r) x phonon-eigenvector
+ * contraction: raman[m] = 2 * (d alpha / d r)|_ref . d_m   (factor 2: the reference divides
+ * its +-delta difference by delta, ramannoodle/dynamics/_phonon.py:106).  One forward and
+ * one reverse pass instead of 2M forward passes; differs from the finite difference by
+ * O(delta^2).
+ */
+int rn_potgnn_raman_tensors_analytic(rn_potgnn *h, const double *ref_positions,
+                                     const double *displacements, int64_t M, double *raman);
+
 /* ------------------------------------------------------------------ introspection */
 
 /* Number of edge triplets T of the frozen graph. */

@@ -333,14 +333,16 @@ def readout_mlp(sd, edge):
     return lin(sd, pre + "5", ssp(x))
 
 
-def forward(model: OracleModel, positions, faithful: bool = True, stages: dict | None = None):
+def forward(model: OracleModel, positions, faithful: bool = True, stages: dict | None = None,
+            grad: bool = False):
     """Standardised polarizability 6-vectors ``[S,6]``
-    (ramannoodle/pmodel/torch/_gnn.py:617-665)."""
+    (ramannoodle/pmodel/torch/_gnn.py:617-665).  ``grad=True`` keeps the autograd graph (used
+    to check the device's reverse-mode Jacobian d alpha / d r)."""
     positions = torch.as_tensor(positions).type(model.dtype)
     s = positions.size(0)
     e = model.num_edges
     sd = model.sd
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         unit, dist = geometry(model, positions, faithful)
         node = node_embedding(model, s)
         edge = gaussian_rbf(model, dist)
@@ -393,3 +395,14 @@ def raman_tensors_fd(model: OracleModel, ref_positions, displacements, delta=0.0
         minus = calc_polarizabilities(model, np.array([ref_positions - d * delta]))[0]
         out.append((plus - minus) / delta)
     return np.array(out)
+
+
+def jacobian(model: OracleModel, positions_one: np.ndarray) -> np.ndarray:
+    """``d vec6_k / d x`` at one structure by torch autograd, ``[6, N, 3]`` (float64 model)."""
+    x = torch.tensor(positions_one[None], dtype=model.dtype, requires_grad=True)
+    out = forward(model, x, faithful=False, grad=True)
+    rows = []
+    for k in range(6):
+        (g,) = torch.autograd.grad(out[0, k], x, retain_graph=True)
+        rows.append(g[0].numpy().copy())
+    return np.array(rows)

@@ -114,6 +114,10 @@ struct Precision {
   Lane<T> lanes[2];
   // stage snapshots (debug)
   std::vector<DeviceBuf> snap_node, snap_edge;
+  // forward tape + cotangent workspace of the reverse pass (Jacobian d alpha / d r)
+  std::vector<DeviceBuf> tape_node, tape_edge;
+  DeviceBuf bw[16];
+  bool tape_on = false;
 };
 
 struct TimedLaunch {
@@ -477,8 +481,14 @@ struct ChunkRun {
   }
   hipStream_t st() const { return ln->stream; }
   void snapshot(int p) {
-    if (!h->keep_stages) return;
     Precision<T> &P = prec<T>(h);
+    if (P.tape_on) {
+      HIP_TRY(hipMemcpyAsync(P.tape_node[p].p, node[cur], (size_t)MN * h->d.FnP * sizeof(T),
+                             hipMemcpyDeviceToDevice, st()));
+      HIP_TRY(hipMemcpyAsync(P.tape_edge[p].p, edge[cur], (size_t)ME * h->d.FeP * sizeof(T),
+                             hipMemcpyDeviceToDevice, st()));
+    }
+    if (!h->keep_stages) return;
     HIP_TRY(hipMemcpyAsync(P.snap_node[p].p, node[cur], (size_t)MN * h->d.FnP * sizeof(T),
                            hipMemcpyDeviceToDevice, st()));
     HIP_TRY(hipMemcpyAsync(P.snap_edge[p].p, edge[cur], (size_t)ME * h->d.FeP * sizeof(T),
@@ -661,6 +671,117 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
     HIP_TRY(hipStreamSynchronize(user));
     resolve_timers(h);
   }
+}
+
+// d(standardised 6-vector)/d(fractional positions) at ONE structure by reverse mode:
+// forward with a tape of the per-pass embeddings, then six cotangents (one per component)
+// pushed back through readout, P x (EdgeBlock, NodeBlock), radial basis and geometry.
+template <typename T>
+void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*/) {
+  ensure_precision<T>(h);
+  Precision<T> &P = prec<T>(h);
+  const Graph &g = h->g;
+  const Dims d = h->d;
+  const int N = g.N, E = g.E, NP = h->cfg.num_message_passes;
+  const int B = 6, C = 6;
+  const int HP = std::max(d.FeP, 32);
+  Lane<T> &ln = P.lanes[0];
+  hipStream_t st = ln.stream;
+
+  P.tape_node.resize(NP + 1);
+  P.tape_edge.resize(NP + 1);
+  for (int p = 0; p <= NP; ++p) {
+    P.tape_node[p].ensure((size_t)N * d.FnP * sizeof(T));
+    P.tape_edge[p].ensure((size_t)E * d.FeP * sizeof(T));
+  }
+  h->io_pos.ensure((size_t)N * 3 * sizeof(double));
+  HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice));
+
+  // ---- forward with tape (S = 1)
+  P.tape_on = true;
+  ChunkRun<T> c(h, ln, h->io_pos.as<double>(), 1, nullptr, nullptr, nullptr);
+  try {
+    c.begin();
+    for (int p = 0; p < NP; ++p) {
+      c.stage_project(p);
+      c.stage_aggregate(p);
+    }
+  } catch (...) {
+    P.tape_on = false;
+    throw;
+  }
+  P.tape_on = false;
+
+  // ---- cotangent workspace
+  enum { DE0, DE1, DN0, DN1, DNX, DPQ, DNP3, DC2, DPROD, DBC1, DNPC1, DPOL, DUNIT, DH, POL, DOUT };
+  const size_t ce = (size_t)C * E, cn = (size_t)C * N;
+  const size_t sizes[16] = {ce * d.FeP, ce * d.FeP, cn * d.FnP, cn * d.FnP, cn * d.FnP,
+                            ce * 4 * d.FeP, cn * 6 * d.FeP, ce * 2 * d.FeP, ce * d.FnP,
+                            ce * 2 * d.FnP, cn * 2 * d.FnP, ce * 32, ce * 4, ce * HP,
+                            (size_t)E * 32, (size_t)C * 6};
+  T *b[16];
+  for (int i = 0; i < 16; ++i) {
+    P.bw[i].ensure(sizes[i] * sizeof(T));
+    b[i] = P.bw[i].template as<T>();
+  }
+  DeviceBuf dposbuf;
+  dposbuf.ensure(cn * 3 * sizeof(double));
+  HIP_TRY(hipMemsetAsync(dposbuf.p, 0, cn * 3 * sizeof(double), st));
+  {
+    std::vector<T> eye(36, (T)0);
+    for (int k = 0; k < 6; ++k) eye[k * 6 + k] = (T)1;
+    HIP_TRY(hipMemcpyAsync(b[DOUT], eye.data(), sizeof(T) * 36, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  T *bufA = c.bufA, *bufB = c.bufB, *unit4 = c.unit4;
+
+  // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
+  const T *edgeP = P.tape_edge[NP].template as<T>();
+  launch_rowgemm<T>(edgeP, E, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0, nullptr, g, st);
+  launch_rowgemm<T>(bufA, E, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
+  launch_rowgemm<T>(bufB, E, HP, P.ro.W5T, 32, b[POL], nullptr, P.ro.b5, false, 0, nullptr, g, st);
+  launch_readout_bwd<T>(b[DOUT], b[POL], unit4, C, B, g, b[DPOL], b[DUNIT], st);
+  launch_gemm_nt<T>(b[DPOL], ce, 32, P.ro.W5T, 32, HP, b[DH], false, st);          // d h2
+  launch_ssp_bwd<T>(b[DH], bufB, nullptr, E, HP, C, B, st);                        // d z2
+  launch_gemm_nt<T>(b[DH], ce, HP, P.ro.W3T, HP, HP, b[DC2], false, st);  // d h1 (uses DC2 as scratch)
+  launch_ssp_bwd<T>(b[DC2], bufA, P.ro.scale0, E, HP, C, B, st);                   // d acc1
+  launch_gemm_nt<T>(b[DC2], ce, HP, P.ro.W0T, HP, d.FeP, b[DE0], false, st);       // d edge_P
+  HIP_TRY(hipMemsetAsync(b[DN0], 0, cn * d.FnP * sizeof(T), st));                  // d node_P = 0
+
+  int cur = 0;  // b[DE0 + cur], b[DN0 + cur] hold the cotangents of (edge, node)_{p+1}
+  for (int p = NP - 1; p >= 0; --p) {
+    const PassW<T> &w = P.pass[p];
+    const T *node0 = P.tape_node[p].template as<T>(), *node1 = P.tape_node[p + 1].template as<T>();
+    const T *edge0 = P.tape_edge[p].template as<T>(), *edge1 = P.tape_edge[p + 1].template as<T>();
+    T *de_next = b[DE0 + cur], *de_prev = b[DE0 + (cur ^ 1)];
+    T *dn_next = b[DN0 + cur], *dn_prev = b[DN0 + (cur ^ 1)];
+    // recompute this pass's projections from the tape
+    launch_rowgemm<T>(node0, N, d.FnP, w.c1_WnT, 2 * d.FnP, c.npc1, nullptr, w.c1_bias, false, 0, nullptr, g, st);
+    launch_rowgemm<T>(node1, N, d.FnP, w.c3_WnT, 6 * d.FeP, c.np3, nullptr, w.c3_nshift, false, 0, nullptr, g, st);
+    launch_rowgemm<T>(edge0, E, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0, nullptr, g, st);
+    launch_rowgemm<T>(nullptr, E, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1, node1, g, st);
+    // EdgeBlock
+    HIP_TRY(hipMemsetAsync(b[DPQ], 0, sizes[DPQ] * sizeof(T), st));
+    HIP_TRY(hipMemsetAsync(b[DNP3], 0, sizes[DNP3] * sizeof(T), st));
+    launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, de_next, de_prev, b[DPQ], b[DNP3], b[DC2], C, B, g, d, w, st);
+    launch_gemm_nt<T>(b[DPQ], ce, 4 * d.FeP, w.c3_WeT, 4 * d.FeP, d.FeP, de_prev, true, st);
+    // node_{p+1} cotangent: incoming + projections + c2 operand
+    HIP_TRY(hipMemcpyAsync(b[DNX], dn_next, cn * d.FnP * sizeof(T), hipMemcpyDeviceToDevice, st));
+    launch_gemm_nt<T>(b[DNP3], cn, 6 * d.FeP, w.c3_WnT, 6 * d.FeP, d.FnP, b[DNX], true, st);
+    launch_gemm_nt<T>(b[DC2], ce, 2 * d.FeP, w.c2_WT, 2 * d.FeP, d.FnP, b[DPROD], false, st);
+    launch_prod_bwd<T>(b[DPROD], node1, b[DNX], C, B, g, d, st);
+    // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
+    launch_rowgemm<T>(edge0, E, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
+    launch_node_bwd<T>(c.npc1, bufA, node1, b[DNX], dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w, st);
+    launch_gemm_nt<T>(b[DBC1], ce, 2 * d.FnP, w.c1_WeT, 2 * d.FnP, d.FeP, de_prev, true, st);
+    launch_gemm_nt<T>(b[DNPC1], cn, 2 * d.FnP, w.c1_WnT, 2 * d.FnP, d.FnP, dn_prev, true, st);
+    cur ^= 1;
+  }
+  launch_geom_bwd<T>(b[DE0 + cur], b[DUNIT], unit4, P.lattice.template as<T>(), P.offsets,
+                     (T)h->cfg.gauss_coefficient, C, B, g, d, dposbuf.as<double>(), st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpy(host_jac, dposbuf.p, cn * 3 * sizeof(double), hipMemcpyDeviceToHost));
 }
 
 int guarded(rn_potgnn *h, const std::function<void()> &fn) {
@@ -1002,6 +1123,45 @@ int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions, const dou
     for (int64_t m = 0; m < M; ++m)
       for (int i = 0; i < 9; ++i)
         raman[m * 9 + i] = (a[(2 * m) * 9 + i] - a[(2 * m + 1) * 9 + i]) / delta;  // _phonon.py:106
+  });
+}
+
+int rn_potgnn_alpha_jacobian(rn_potgnn *h, const double *positions, int use_float64, double *jac) {
+  if (!h || !positions || !jac) {
+    set_error(h, "invalid arguments to alpha_jacobian");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() {
+    if (use_float64) jacobian<double>(h, positions, jac);
+    else jacobian<float>(h, positions, jac);
+  });
+}
+
+int rn_potgnn_raman_tensors_analytic(rn_potgnn *h, const double *ref_positions,
+                                     const double *displacements, int64_t M, double *raman) {
+  if (!h || M < 0 || !ref_positions || (M > 0 && (!displacements || !raman))) {
+    set_error(h, "invalid arguments to raman_tensors_analytic");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0) return RN_OK;
+  return guarded(h, [&]() {
+    const size_t n3 = (size_t)h->cfg.num_atoms * 3;
+    std::vector<double> jac(6 * n3);
+    jacobian<double>(h, ref_positions, jac.data());
+    // R_m = 2 * sigma (.) (J d_m): the reference divides its +-delta difference by delta, not
+    // 2 delta (dynamics/_phonon.py:106), i.e. it returns twice the directional derivative
+    const int map[9] = {0, 3, 4, 3, 1, 5, 4, 5, 2};
+    for (int64_t m = 0; m < M; ++m) {
+      double v[6] = {0, 0, 0, 0, 0, 0};
+      const double *dm = displacements + m * n3;
+      for (int k = 0; k < 6; ++k) {
+        const double *j = jac.data() + k * n3;
+        double acc = 0;
+        for (size_t i = 0; i < n3; ++i) acc += j[i] * dm[i];
+        v[k] = acc;
+      }
+      for (int i = 0; i < 9; ++i) raman[m * 9 + i] = 2.0 * h->stdv[i] * v[map[i]];
+    }
   });
 }
 

@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
 mkdir -p "$here/build"
 pids=()
-for f in api kernels_agg kernels_gemm kernels_fused; do
+for f in api kernels_agg kernels_gemm kernels_fused kernels_bwd; do
   if [ ! -f "$here/build/$f.o" ] || [ "$here/$f.hip" -nt "$here/build/$f.o" ] || \
      [ "$here/kernels.hpp" -nt "$here/build/$f.o" ] || [ "$here/device_utils.hpp" -nt "$here/build/$f.o" ] || \
      [ "$here/../../include/rn_potgnn.h" -nt "$here/build/$f.o" ]; then
@@ -16,5 +16,5 @@ for f in api kernels_agg kernels_gemm kernels_fused; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "$here/build/api.o" "$here/build/kernels_agg.o" "$here/build/kernels_gemm.o" "$here/build/kernels_fused.o"
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "$here/build/api.o" "$here/build/kernels_agg.o" "$here/build/kernels_gemm.o" "$here/build/kernels_fused.o" "$here/build/kernels_bwd.o"
 echo "built $out"

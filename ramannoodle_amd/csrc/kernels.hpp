@@ -105,6 +105,32 @@ void launch_enum_triplets(const Graph &g, int *idx_i, int *idx_j, int *idx_k, in
 
 size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem);
 
+// ---- reverse mode w.r.t. activations / positions (kernels_bwd.hip).  C cotangent
+// instances, B per forward frame.
+template <typename T>
+void launch_gemm_nt(const T *X, int64_t R, int N, const T *W, int ldw, int K, T *Y, bool accumulate,
+                    hipStream_t st);
+template <typename T>
+void launch_readout_bwd(const T *dout6, const T *pol, const T *unit4, int C, int B, const Graph &g,
+                        T *dpol, T *dunit, hipStream_t st);
+template <typename T>
+void launch_ssp_bwd(T *d, const T *h, const T *scale, int64_t rows_per_frame, int width, int C,
+                    int B, hipStream_t st);
+template <typename T>
+void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
+                     const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3, T *dc2pre, int C, int B,
+                     const Graph &g, Dims d, const PassW<T> &w, hipStream_t st);
+template <typename T>
+void launch_prod_bwd(const T *dprod, const T *node, T *dnode, int C, int B, const Graph &g, Dims d,
+                     hipStream_t st);
+template <typename T>
+void launch_node_bwd(const T *npc1, const T *bc1, const T *node_next, const T *dnode_next,
+                     T *dnode_prev, T *dbc1, T *dnpc1, int C, int B, const Graph &g, Dims d,
+                     const PassW<T> &w, hipStream_t st);
+template <typename T>
+void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *lat, const T *offs,
+                     T coef, int C, int B, const Graph &g, Dims d, double *dpos, hipStream_t st);
+
 // Fused EdgeBlock (kernels_fused.hip): projections + triplet aggregation in one launch.
 bool edge_fused_supported(const Graph &g, Dims d);
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,

@@ -1,0 +1,598 @@
+// Reverse-mode kernels of the PotGNN forward pass with respect to ACTIVATIONS and atomic
+// positions (no weight gradients): they give d(alpha)/d(r), the quantity the Raman-tensor
+// contraction needs (the reference obtains it by finite differences,
+// ramannoodle/dynamics/_phonon.py:93-106).
+//
+// Correctness-first kernels (the Jacobian is taken at ONE structure per model, so they are
+// never on a throughput path): same lane-group row layout as the forward kernels, rows
+// read straight from global memory, cross-row accumulations by float/double atomics.
+//
+// Indexing: cotangent "instance" c in [0, C) belongs to forward frame s = c / B (B
+// cotangents per frame: 6 for the Jacobian of the six polarizability components).
+// Forward arrays are indexed by s, cotangent arrays by c.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace rn {
+
+template <typename T>
+__device__ __forceinline__ void atomic_add4(T *p, const Vec4<T> &v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) atomicAdd(p + k, v.v[k]);
+}
+
+// ---- LayerNorm pieces on the lane-group layout -------------------------------------------
+// forward: normalised values (padded columns -> 0) and 1/sigma of a [filter|core] row
+template <int LG, typename T>
+__device__ __forceinline__ T ln2_hat(Vec4<T> &xf, Vec4<T> &xc, T inv_n, int nvalid) {
+  T s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s += xf.v[k] + xc.v[k];
+  const T mean = lg_sum<LG>(s) * inv_n;
+  T q = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    xf.v[k] = k < nvalid ? xf.v[k] - mean : (T)0;
+    xc.v[k] = k < nvalid ? xc.v[k] - mean : (T)0;
+    q += xf.v[k] * xf.v[k] + xc.v[k] * xc.v[k];
+  }
+  const T rstd = (T)1 / sqrt(lg_sum<LG>(q) * inv_n + (T)1e-5);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    xf.v[k] *= rstd;
+    xc.v[k] *= rstd;
+  }
+  return rstd;
+}
+// backward: dxhat (= dy * gamma) -> dx, given xhat and 1/sigma
+template <int LG, typename T>
+__device__ __forceinline__ void ln2_bwd(Vec4<T> &df, Vec4<T> &dc, const Vec4<T> &hf,
+                                        const Vec4<T> &hc, T rstd, T inv_n, int nvalid) {
+  T a = 0, b = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= nvalid) { df.v[k] = 0; dc.v[k] = 0; }
+    a += df.v[k] + dc.v[k];
+    b += df.v[k] * hf.v[k] + dc.v[k] * hc.v[k];
+  }
+  a = lg_sum<LG>(a) * inv_n;
+  b = lg_sum<LG>(b) * inv_n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    df.v[k] = k < nvalid ? rstd * (df.v[k] - a - hf.v[k] * b) : (T)0;
+    dc.v[k] = k < nvalid ? rstd * (dc.v[k] - a - hc.v[k] * b) : (T)0;
+  }
+}
+template <int LG, typename T>
+__device__ __forceinline__ T ln1_hat(Vec4<T> &x, T inv_n, int nvalid) {
+  T s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s += x.v[k];
+  const T mean = lg_sum<LG>(s) * inv_n;
+  T q = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    x.v[k] = k < nvalid ? x.v[k] - mean : (T)0;
+    q += x.v[k] * x.v[k];
+  }
+  const T rstd = (T)1 / sqrt(lg_sum<LG>(q) * inv_n + (T)1e-5);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x.v[k] *= rstd;
+  return rstd;
+}
+template <int LG, typename T>
+__device__ __forceinline__ void ln1_bwd(Vec4<T> &d, const Vec4<T> &h, T rstd, T inv_n, int nvalid) {
+  T a = 0, b = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= nvalid) d.v[k] = 0;
+    a += d.v[k];
+    b += d.v[k] * h.v[k];
+  }
+  a = lg_sum<LG>(a) * inv_n;
+  b = lg_sum<LG>(b) * inv_n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d.v[k] = k < nvalid ? rstd * (d.v[k] - a - h.v[k] * b) : (T)0;
+}
+template <typename T>
+__device__ __forceinline__ T sigmoid_acc(T x) { return (T)1 / ((T)1 + exp(-x)); }
+
+// gate value and its partial derivatives for normalised, affine-transformed inputs
+template <typename T>
+__device__ __forceinline__ void gate_grad(T yf, T yc, T &g, T &dgf, T &dgc) {
+  const T sg = sigmoid_acc(yf), th = tanh(yc);
+  g = sg * th;
+  dgf = th * sg * ((T)1 - sg);
+  dgc = sg * ((T)1 - th * th);
+}
+
+// =========================================================================== small GEMM
+// Y[r][k] (+)= sum_n X[r][n] * W[k*ldw + n]   (W in the forward's [K][N] layout, so this is
+// the activation-gradient product dX = dY * W^T of Y = X * W).
+template <typename T>
+__global__ void gemm_nt_kernel(const T *__restrict__ X, int64_t R, int N, const T *__restrict__ W,
+                               int ldw, int K, T *__restrict__ Y, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * K) return;
+  const int64_t r = idx / K;
+  const int k = (int)(idx % K);
+  const T *x = X + r * N;
+  const T *w = W + (int64_t)k * ldw;
+  T acc = 0;
+  for (int n = 0; n < N; ++n) acc += x[n] * w[n];
+  if (accumulate) Y[idx] += acc;
+  else Y[idx] = acc;
+}
+template <typename T>
+void launch_gemm_nt(const T *X, int64_t R, int N, const T *W, int ldw, int K, T *Y, bool accumulate,
+                    hipStream_t st) {
+  if (R == 0) return;
+  const int64_t total = R * K;
+  gemm_nt_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(X, R, N, W, ldw, K, Y,
+                                                                     accumulate ? 1 : 0);
+}
+template void launch_gemm_nt<float>(const float *, int64_t, int, const float *, int, int, float *,
+                                    bool, hipStream_t);
+template void launch_gemm_nt<double>(const double *, int64_t, int, const double *, int, int,
+                                     double *, bool, hipStream_t);
+
+// =========================================================================== readout
+// out_k = (1/E) sum_e v_k(pol_e, unit_e) (closed form of _gnn.py:372-415).  Given dL/dout
+// (one 6-vector per cotangent instance) produce dL/dpol [C*E,32] and dL/dunit [C*E,4].
+template <typename T>
+__global__ void readout_bwd_kernel(const T *__restrict__ dout6, const T *__restrict__ pol,
+                                   const T *__restrict__ unit4, int C, int B, Graph g,
+                                   T *__restrict__ dpol, T *__restrict__ dunit) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)C * g.E) return;
+  const int c = (int)(idx / g.E), e = (int)(idx % g.E);
+  const int64_t frow = (int64_t)(c / B) * g.E + e;
+  const T inv = (T)1 / (T)g.E;
+  T dv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dv[k] = dout6[c * 6 + k] * inv;
+  const T ux = unit4[frow * 4], uy = unit4[frow * 4 + 1], uz = unit4[frow * 4 + 2];
+  const T *m = pol + frow * 32;
+  T *dp = dpol + idx * 32;
+  for (int k = 12; k < 32; ++k) dp[k] = 0;
+  // v3 = (m0-m1) ux uy ; v4 = (m2-m3) ux uz ; v5 = (m4-m5) uy uz
+  // v0 = m7 + (m6-m7) ux^2 ; v1 = m9 + (m8-m9) uy^2 ; v2 = m11 + (m10-m11) uz^2
+  dp[0] = dv[3] * ux * uy;  dp[1] = -dp[0];
+  dp[2] = dv[4] * ux * uz;  dp[3] = -dp[2];
+  dp[4] = dv[5] * uy * uz;  dp[5] = -dp[4];
+  dp[6] = dv[0] * ux * ux;  dp[7] = dv[0] * ((T)1 - ux * ux);
+  dp[8] = dv[1] * uy * uy;  dp[9] = dv[1] * ((T)1 - uy * uy);
+  dp[10] = dv[2] * uz * uz; dp[11] = dv[2] * ((T)1 - uz * uz);
+  const T a3 = m[0] - m[1], a4 = m[2] - m[3], a5 = m[4] - m[5];
+  const T a0 = m[6] - m[7], a1 = m[8] - m[9], a2 = m[10] - m[11];
+  T *du = dunit + idx * 4;
+  du[0] = dv[3] * a3 * uy + dv[4] * a4 * uz + (T)2 * dv[0] * a0 * ux;
+  du[1] = dv[3] * a3 * ux + dv[5] * a5 * uz + (T)2 * dv[1] * a1 * uy;
+  du[2] = dv[4] * a4 * ux + dv[5] * a5 * uy + (T)2 * dv[2] * a2 * uz;
+  du[3] = 0;
+}
+template <typename T>
+void launch_readout_bwd(const T *dout6, const T *pol, const T *unit4, int C, int B, const Graph &g,
+                        T *dpol, T *dunit, hipStream_t st) {
+  const int64_t total = (int64_t)C * g.E;
+  if (total == 0) return;
+  readout_bwd_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dout6, pol, unit4, C, B, g,
+                                                                         dpol, dunit);
+}
+template void launch_readout_bwd<float>(const float *, const float *, const float *, int, int,
+                                        const Graph &, float *, float *, hipStream_t);
+template void launch_readout_bwd<double>(const double *, const double *, const double *, int, int,
+                                         const Graph &, double *, double *, hipStream_t);
+
+// dz = dh * ssp'(z) * scale, with ssp'(z) = sigmoid(z) = 1 - exp(-(h + ln2)) expressed through
+// the stored activation h = ssp(z).  `h` is indexed by forward row, `d` by cotangent row.
+template <typename T>
+__global__ void ssp_bwd_kernel(T *__restrict__ d, const T *__restrict__ h, const T *__restrict__ scale,
+                               int64_t rows_per_frame, int width, int C, int B) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)C * rows_per_frame * width;
+  if (idx >= total) return;
+  const int col = (int)(idx % width);
+  const int64_t crow = idx / width;
+  const int c = (int)(crow / rows_per_frame);
+  const int64_t frow = (int64_t)(c / B) * rows_per_frame + crow % rows_per_frame;
+  const T hv = h[frow * width + col];
+  const T sg = (T)1 - (T)0.5 * exp(-hv);
+  d[idx] *= sg * (scale ? scale[col] : (T)1);
+}
+template <typename T>
+void launch_ssp_bwd(T *d, const T *h, const T *scale, int64_t rows_per_frame, int width, int C,
+                    int B, hipStream_t st) {
+  const int64_t total = (int64_t)C * rows_per_frame * width;
+  if (total == 0) return;
+  ssp_bwd_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d, h, scale, rows_per_frame,
+                                                                     width, C, B);
+}
+template void launch_ssp_bwd<float>(float *, const float *, const float *, int64_t, int, int, int,
+                                    hipStream_t);
+template void launch_ssp_bwd<double>(double *, const double *, const double *, int64_t, int, int, int,
+                                     hipStream_t);
+
+// =========================================================================== edge block
+// Reverse of _EdgeBlock.forward (_gnn.py:294-351) for one destination edge d per lane group.
+//   in : dedge_next [C*E,FP]  (cotangent of the block's output)
+//   out: dedge_prev [C*E,FP]  = residual part (the projection parts are added by GEMMs later)
+//        dpq [C*E,4FP] (first half written here, second half = dQ accumulated atomically)
+//        dnp3 [C*N,6FP] (atomic), dc2pre [C*E,2FP]
+template <int LG, typename T>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(
+    const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
+    const T *__restrict__ edge_next, const T *__restrict__ dedge_next, T *__restrict__ dedge_prev,
+    T *__restrict__ dpq, T *__restrict__ dnp3, T *__restrict__ dc2pre, int C, int B, Graph g, Dims d,
+    PassW<T> w) {
+  constexpr int FP = LG * 4;
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
+  const int q = threadIdx.x % LG;
+  if (gid >= (int64_t)C * g.E) return;
+  const int c = (int)(gid / g.E), dst = (int)(gid % g.E);
+  const int s = c / B;
+  const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+  const int64_t cerow0 = (int64_t)c * g.E, cnrow0 = (int64_t)c * g.N;
+  const int nvalid = min(max(d.Fe - 4 * q, 0), 4);
+  const T inv2n = (T)1 / (T)(2 * d.Fe), invn = (T)1 / (T)d.Fe;
+  const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+  const int64_t drow = erow0 + dst;
+
+  // tanh residual
+  const Vec4<T> e1 = load4<T>(edge_next + drow * FP + 4 * q);
+  Vec4<T> dz = load4<T>(dedge_next + (cerow0 + dst) * FP + 4 * q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dz.v[k] *= ((T)1 - e1.v[k] * e1.v[k]);
+  store4(dedge_prev + (cerow0 + dst) * FP + 4 * q, dz);
+
+  // P'_d
+  Vec4<T> pf = load4<T>(pq + drow * (4 * FP) + 4 * q), pc = load4<T>(pq + drow * (4 * FP) + FP + 4 * q);
+  {
+    const T *nj = np3 + (nrow0 + bd) * (6 * FP) + 2 * FP + 4 * q;
+    const T *nk = np3 + (nrow0 + ad) * (6 * FP) + 4 * FP + 4 * q;
+    const Vec4<T> jf = load4<T>(nj), jc = load4<T>(nj + FP), kf = load4<T>(nk), kc = load4<T>(nk + FP);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pf.v[k] += jf.v[k] + kf.v[k];
+      pc.v[k] += jc.v[k] + kc.v[k];
+    }
+  }
+  const Vec4<T> g1f = load4<T>(w.c3_norm_1.g + 4 * q), b1f = load4<T>(w.c3_norm_1.b + 4 * q);
+  const Vec4<T> g1c = load4<T>(w.c3_norm_1.g + FP + 4 * q), b1c = load4<T>(w.c3_norm_1.b + FP + 4 * q);
+  const int rb = g.out_ptr[bd], re = g.out_ptr[bd + 1];
+
+  auto source_row = [&](int e, Vec4<T> &xf, Vec4<T> &xc) {  // x = P'_d + Q'_e
+    const T *qp = pq + (erow0 + e) * (4 * FP) + 2 * FP + 4 * q;
+    const T *np = np3 + (nrow0 + g.edge_b[e]) * (6 * FP) + 4 * q;
+    const Vec4<T> qf = load4<T>(qp), qc = load4<T>(qp + FP), nf = load4<T>(np), nc = load4<T>(np + FP);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xf.v[k] = pf.v[k] + qf.v[k] + nf.v[k];
+      xc.v[k] = pc.v[k] + qc.v[k] + nc.v[k];
+    }
+  };
+
+  // ---- recompute the aggregated gate sum, then LayerNorm (c3_norm_2) backward
+  Vec4<T> agg{{0, 0, 0, 0}};
+  for (int e = rb; e < re; ++e) {
+    if (g.edge_b[e] == ad) continue;
+    Vec4<T> xf, xc;
+    source_row(e, xf, xc);
+    ln2_hat<LG>(xf, xc, inv2n, nvalid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T gv, a, b;
+      gate_grad(xf.v[k] * g1f.v[k] + b1f.v[k], xc.v[k] * g1c.v[k] + b1c.v[k], gv, a, b);
+      agg.v[k] += gv;
+    }
+  }
+  Vec4<T> dagg;
+  {
+    const Vec4<T> g2 = load4<T>(w.c3_norm_2.g + 4 * q);
+    Vec4<T> hat = agg;
+    const T rstd = ln1_hat<LG>(hat, invn, nvalid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dagg.v[k] = dz.v[k] * g2.v[k];
+    ln1_bwd<LG>(dagg, hat, rstd, invn, nvalid);
+  }
+  // ---- per triplet: gate + LayerNorm (c3_norm_1) backward; dx goes to P'_d and Q'_e
+  Vec4<T> dpf{{0, 0, 0, 0}}, dpc{{0, 0, 0, 0}};
+  for (int e = rb; e < re; ++e) {
+    if (g.edge_b[e] == ad) continue;
+    Vec4<T> xf, xc;
+    source_row(e, xf, xc);
+    const T rstd = ln2_hat<LG>(xf, xc, inv2n, nvalid);
+    Vec4<T> df, dc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T gv, a, b;
+      gate_grad(xf.v[k] * g1f.v[k] + b1f.v[k], xc.v[k] * g1c.v[k] + b1c.v[k], gv, a, b);
+      df.v[k] = dagg.v[k] * a * g1f.v[k];
+      dc.v[k] = dagg.v[k] * b * g1c.v[k];
+    }
+    ln2_bwd<LG>(df, dc, xf, xc, rstd, inv2n, nvalid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dpf.v[k] += df.v[k];
+      dpc.v[k] += dc.v[k];
+    }
+    T *dq = dpq + (cerow0 + e) * (4 * FP) + 2 * FP + 4 * q;  // dQ'_e: many destinations add here
+    atomic_add4(dq, df);
+    atomic_add4(dq + FP, dc);
+  }
+  store4(dpq + (cerow0 + dst) * (4 * FP) + 4 * q, dpf);
+  store4(dpq + (cerow0 + dst) * (4 * FP) + FP + 4 * q, dpc);
+  {
+    T *dj = dnp3 + (cnrow0 + bd) * (6 * FP) + 2 * FP + 4 * q;
+    T *dk = dnp3 + (cnrow0 + ad) * (6 * FP) + 4 * FP + 4 * q;
+    atomic_add4(dj, dpf);
+    atomic_add4(dj + FP, dpc);
+    atomic_add4(dk, dpf);
+    atomic_add4(dk + FP, dpc);
+  }
+  // ---- c2 = LN(gate(LN(c2pre)))  (_gnn.py:223-228)
+  {
+    Vec4<T> xf = load4<T>(c2pre + drow * (2 * FP) + 4 * q), xc = load4<T>(c2pre + drow * (2 * FP) + FP + 4 * q);
+    const T rstd1 = ln2_hat<LG>(xf, xc, inv2n, nvalid);
+    const Vec4<T> gf = load4<T>(w.c2_norm_1.g + 4 * q), bf = load4<T>(w.c2_norm_1.b + 4 * q);
+    const Vec4<T> gc = load4<T>(w.c2_norm_1.g + FP + 4 * q), bc = load4<T>(w.c2_norm_1.b + FP + 4 * q);
+    Vec4<T> gv, da, db;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      gate_grad(xf.v[k] * gf.v[k] + bf.v[k], xc.v[k] * gc.v[k] + bc.v[k], gv.v[k], da.v[k], db.v[k]);
+    Vec4<T> hat = gv;
+    const T rstd2 = ln1_hat<LG>(hat, invn, nvalid);
+    const Vec4<T> g22 = load4<T>(w.c2_norm_2.g + 4 * q);
+    Vec4<T> dg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dg.v[k] = dz.v[k] * g22.v[k];
+    ln1_bwd<LG>(dg, hat, rstd2, invn, nvalid);
+    Vec4<T> df, dc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      df.v[k] = dg.v[k] * da.v[k] * gf.v[k];
+      dc.v[k] = dg.v[k] * db.v[k] * gc.v[k];
+    }
+    ln2_bwd<LG>(df, dc, xf, xc, rstd1, inv2n, nvalid);
+    store4(dc2pre + (cerow0 + dst) * (2 * FP) + 4 * q, df);
+    store4(dc2pre + (cerow0 + dst) * (2 * FP) + FP + 4 * q, dc);
+  }
+}
+
+// dnp3[c, b_e][Wi block] += dQ'_e  (the node part of the source-row projection)
+template <int LG, typename T>
+__global__ void q_scatter_kernel(const T *__restrict__ dpq, T *__restrict__ dnp3, int C, Graph g) {
+  constexpr int FP = LG * 4;
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
+  const int q = threadIdx.x % LG;
+  if (gid >= (int64_t)C * g.E) return;
+  const int c = (int)(gid / g.E), e = (int)(gid % g.E);
+  const T *src = dpq + gid * (4 * FP) + 2 * FP + 4 * q;
+  T *dst = dnp3 + ((int64_t)c * g.N + g.edge_b[e]) * (6 * FP) + 4 * q;
+  atomic_add4(dst, load4<T>(src));
+  atomic_add4(dst + FP, load4<T>(src + FP));
+}
+
+// d(node[b]*node[a]) -> dnode[b], dnode[a]   (operand of c2_linear)
+template <int LG, typename T>
+__global__ void prod_bwd_kernel(const T *__restrict__ dprod, const T *__restrict__ node,
+                                T *__restrict__ dnode, int C, int B, Graph g) {
+  constexpr int FP = LG * 4;
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
+  const int q = threadIdx.x % LG;
+  if (gid >= (int64_t)C * g.E) return;
+  const int c = (int)(gid / g.E), e = (int)(gid % g.E);
+  const int64_t nrow0 = (int64_t)(c / B) * g.N, cnrow0 = (int64_t)c * g.N;
+  const int a = g.edge_a[e], b = g.edge_b[e];
+  const Vec4<T> dp = load4<T>(dprod + gid * FP + 4 * q);
+  const Vec4<T> nb = load4<T>(node + (nrow0 + b) * FP + 4 * q), na = load4<T>(node + (nrow0 + a) * FP + 4 * q);
+  Vec4<T> tb, ta;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    tb.v[k] = dp.v[k] * na.v[k];
+    ta.v[k] = dp.v[k] * nb.v[k];
+  }
+  atomic_add4(dnode + (cnrow0 + b) * FP + 4 * q, tb);
+  atomic_add4(dnode + (cnrow0 + a) * FP + 4 * q, ta);
+}
+
+// =========================================================================== node block
+// Reverse of _NodeBlock.forward (_gnn.py:141-151) for one atom b per lane group.
+template <int LG, typename T>
+__global__ __launch_bounds__(256) void node_bwd_kernel(
+    const T *__restrict__ npc1, const T *__restrict__ bc1, const T *__restrict__ node_next,
+    const T *__restrict__ dnode_next, T *__restrict__ dnode_prev, T *__restrict__ dbc1,
+    T *__restrict__ dnpc1, int C, int B, Graph g, Dims d, PassW<T> w) {
+  constexpr int FP = LG * 4;
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
+  const int q = threadIdx.x % LG;
+  if (gid >= (int64_t)C * g.N) return;
+  const int c = (int)(gid / g.N), b = (int)(gid % g.N);
+  const int s = c / B;
+  const int64_t frow = (int64_t)s * g.N + b;
+  const int nvalid = min(max(d.Fn - 4 * q, 0), 4);
+  const T inv2n = (T)1 / (T)(2 * d.Fn), invn = (T)1 / (T)d.Fn;
+  const Vec4<T> n1 = load4<T>(node_next + frow * FP + 4 * q);
+  Vec4<T> dz = load4<T>(dnode_next + gid * FP + 4 * q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dz.v[k] *= ((T)1 - n1.v[k] * n1.v[k]);
+  store4(dnode_prev + gid * FP + 4 * q, dz);
+
+  const Vec4<T> af = load4<T>(npc1 + frow * (2 * FP) + 4 * q), ac = load4<T>(npc1 + frow * (2 * FP) + FP + 4 * q);
+  const Vec4<T> gf = load4<T>(w.c1_norm.g + 4 * q), bf = load4<T>(w.c1_norm.b + 4 * q);
+  const Vec4<T> gc = load4<T>(w.c1_norm.g + FP + 4 * q), bc = load4<T>(w.c1_norm.b + FP + 4 * q);
+  const int beg = g.in_ptr[b], end = g.in_ptr[b + 1];
+  auto row = [&](int e, Vec4<T> &xf, Vec4<T> &xc) {
+    const T *p = bc1 + ((int64_t)s * g.E + e) * (2 * FP) + 4 * q;
+    xf = load4<T>(p);
+    xc = load4<T>(p + FP);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xf.v[k] += af.v[k];
+      xc.v[k] += ac.v[k];
+    }
+  };
+  Vec4<T> agg{{0, 0, 0, 0}};
+  for (int i = beg; i < end; ++i) {
+    Vec4<T> xf, xc;
+    row(g.in_edge[i], xf, xc);
+    ln2_hat<LG>(xf, xc, inv2n, nvalid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T gv, a, bb;
+      gate_grad(xf.v[k] * gf.v[k] + bf.v[k], xc.v[k] * gc.v[k] + bc.v[k], gv, a, bb);
+      agg.v[k] += gv;
+    }
+  }
+  Vec4<T> dagg;
+  {
+    const Vec4<T> g2 = load4<T>(w.final_norm.g + 4 * q);
+    Vec4<T> hat = agg;
+    const T rstd = ln1_hat<LG>(hat, invn, nvalid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dagg.v[k] = dz.v[k] * g2.v[k];
+    ln1_bwd<LG>(dagg, hat, rstd, invn, nvalid);
+  }
+  Vec4<T> sf{{0, 0, 0, 0}}, sc{{0, 0, 0, 0}};
+  for (int i = beg; i < end; ++i) {
+    const int e = g.in_edge[i];
+    Vec4<T> xf, xc;
+    row(e, xf, xc);
+    const T rstd = ln2_hat<LG>(xf, xc, inv2n, nvalid);
+    Vec4<T> df, dc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T gv, a, bb;
+      gate_grad(xf.v[k] * gf.v[k] + bf.v[k], xc.v[k] * gc.v[k] + bc.v[k], gv, a, bb);
+      df.v[k] = dagg.v[k] * a * gf.v[k];
+      dc.v[k] = dagg.v[k] * bb * gc.v[k];
+    }
+    ln2_bwd<LG>(df, dc, xf, xc, rstd, inv2n, nvalid);
+    T *o = dbc1 + ((int64_t)c * g.E + e) * (2 * FP) + 4 * q;  // every edge has exactly one b
+    store4(o, df);
+    store4(o + FP, dc);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sf.v[k] += df.v[k];
+      sc.v[k] += dc.v[k];
+    }
+  }
+  store4(dnpc1 + gid * (2 * FP) + 4 * q, sf);
+  store4(dnpc1 + gid * (2 * FP) + FP + 4 * q, sc);
+}
+
+// =========================================================================== geometry
+// RBF + geometry backward: d(edge0), d(unit) -> d(fractional positions), accumulated
+// atomically as float64 [C, N, 3].  (The minimum-image wrap is locally the identity.)
+template <typename T>
+__global__ void geom_bwd_kernel(const T *__restrict__ dedge0, const T *__restrict__ dunit,
+                                const T *__restrict__ unit4, const T *__restrict__ lat,
+                                const T *__restrict__ offs, T coef, int C, int B, Graph g, Dims d,
+                                double *__restrict__ dpos) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)C * g.E) return;
+  const int c = (int)(idx / g.E), e = (int)(idx % g.E);
+  const int64_t frow = (int64_t)(c / B) * g.E + e;
+  const T ux = unit4[frow * 4], uy = unit4[frow * 4 + 1], uz = unit4[frow * 4 + 2], dist = unit4[frow * 4 + 3];
+  T ddist = 0;
+  const T *de = dedge0 + idx * d.FeP;
+  for (int f = 0; f < d.Fe; ++f) {
+    const T x = dist - offs[f];
+    ddist += de[f] * exp(coef * x * x) * ((T)2 * coef * x);
+  }
+  const T dux = dunit[idx * 4], duy = dunit[idx * 4 + 1], duz = dunit[idx * 4 + 2];
+  const T proj = dux * ux + duy * uy + duz * uz;
+  const T dc[3] = {ddist * ux + (dux - proj * ux) / dist, ddist * uy + (duy - proj * uy) / dist,
+                   ddist * uz + (duz - proj * uz) / dist};
+  const int a = g.edge_a[e], b = g.edge_b[e];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // cart_k = sum_i frac_i L[i][k]
+    const T df = lat[3 * i] * dc[0] + lat[3 * i + 1] * dc[1] + lat[3 * i + 2] * dc[2];
+    atomicAdd(dpos + ((int64_t)c * g.N + b) * 3 + i, (double)df);
+    atomicAdd(dpos + ((int64_t)c * g.N + a) * 3 + i, -(double)df);
+  }
+}
+template <typename T>
+void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *lat, const T *offs,
+                     T coef, int C, int B, const Graph &g, Dims d, double *dpos, hipStream_t st) {
+  const int64_t total = (int64_t)C * g.E;
+  if (total == 0) return;
+  geom_bwd_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dedge0, dunit, unit4, lat, offs,
+                                                                      coef, C, B, g, d, dpos);
+}
+template void launch_geom_bwd<float>(const float *, const float *, const float *, const float *,
+                                     const float *, float, int, int, const Graph &, Dims, double *,
+                                     hipStream_t);
+template void launch_geom_bwd<double>(const double *, const double *, const double *, const double *,
+                                      const double *, double, int, int, const Graph &, Dims,
+                                      double *, hipStream_t);
+
+// =========================================================================== launchers
+#define RN_LG_SWITCH(FP, CALL)   \
+  switch ((FP) / 4) {            \
+    case 4: CALL(4); break;      \
+    case 8: CALL(8); break;      \
+    case 16: CALL(16); break;    \
+    case 32: CALL(32); break;    \
+  }
+
+template <typename T>
+void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
+                     const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3, T *dc2pre, int C, int B,
+                     const Graph &g, Dims d, const PassW<T> &w, hipStream_t st) {
+  const int lg = d.FeP / 4;
+  const int64_t threads = (int64_t)C * g.E * lg;
+  if (threads == 0) return;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+#define CALL(LGV)                                                                                  \
+  edge_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(pq, np3, c2pre, edge_next, dedge_next, dedge_prev, \
+                                                  dpq, dnp3, dc2pre, C, B, g, d, w);                \
+  q_scatter_kernel<LGV, T><<<blocks, 256, 0, st>>>(dpq, dnp3, C, g)
+  RN_LG_SWITCH(d.FeP, CALL)
+#undef CALL
+}
+template void launch_edge_bwd<float>(const float *, const float *, const float *, const float *,
+                                     const float *, float *, float *, float *, float *, int, int,
+                                     const Graph &, Dims, const PassW<float> &, hipStream_t);
+template void launch_edge_bwd<double>(const double *, const double *, const double *, const double *,
+                                      const double *, double *, double *, double *, double *, int, int,
+                                      const Graph &, Dims, const PassW<double> &, hipStream_t);
+
+template <typename T>
+void launch_prod_bwd(const T *dprod, const T *node, T *dnode, int C, int B, const Graph &g, Dims d,
+                     hipStream_t st) {
+  const int lg = d.FnP / 4;
+  const int64_t threads = (int64_t)C * g.E * lg;
+  if (threads == 0) return;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+#define CALL(LGV) prod_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(dprod, node, dnode, C, B, g)
+  RN_LG_SWITCH(d.FnP, CALL)
+#undef CALL
+}
+template void launch_prod_bwd<float>(const float *, const float *, float *, int, int, const Graph &,
+                                     Dims, hipStream_t);
+template void launch_prod_bwd<double>(const double *, const double *, double *, int, int,
+                                      const Graph &, Dims, hipStream_t);
+
+template <typename T>
+void launch_node_bwd(const T *npc1, const T *bc1, const T *node_next, const T *dnode_next,
+                     T *dnode_prev, T *dbc1, T *dnpc1, int C, int B, const Graph &g, Dims d,
+                     const PassW<T> &w, hipStream_t st) {
+  const int lg = d.FnP / 4;
+  const int64_t threads = (int64_t)C * g.N * lg;
+  if (threads == 0) return;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+#define CALL(LGV)                                                                                 \
+  node_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(npc1, bc1, node_next, dnode_next, dnode_prev, dbc1, \
+                                                  dnpc1, C, B, g, d, w)
+  RN_LG_SWITCH(d.FnP, CALL)
+#undef CALL
+}
+template void launch_node_bwd<float>(const float *, const float *, const float *, const float *,
+                                     float *, float *, float *, int, int, const Graph &, Dims,
+                                     const PassW<float> &, hipStream_t);
+template void launch_node_bwd<double>(const double *, const double *, const double *, const double *,
+                                      double *, double *, double *, int, int, const Graph &, Dims,
+                                      const PassW<double> &, hipStream_t);
+
+}  // namespace rn

@@ -289,18 +289,44 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
     __call__ = forward
 
     def calc_raman_tensors(self, ref_positions, displacements,
-                           delta: float = RAMAN_TENSOR_CENTRAL_DIFFERENCE) -> NDArray[np.float64]:
-        """``(alpha(r + delta d_m) - alpha(r - delta d_m)) / delta`` for all modes in one
-        float64 device batch (``dynamics/_phonon.py:93-106``)."""
+                           delta: float = RAMAN_TENSOR_CENTRAL_DIFFERENCE,
+                           method: str = "finite-difference") -> NDArray[np.float64]:
+        """Raman tensors of all modes in one device call.
+
+        ``method="finite-difference"`` (default, the reference's definition):
+        ``(alpha(r + delta d_m) - alpha(r - delta d_m)) / delta`` in one float64 batch of the
+        ``2M`` displaced cells (``dynamics/_phonon.py:93-106``).
+        ``method="analytic"``: ``2 (d alpha / d r) . d_m`` from one forward and one reverse
+        pass (equal up to ``O(delta^2)``).
+        """
         verify_ndarray_shape("ref_positions", ref_positions, (self.num_atoms, 3))
         verify_ndarray_shape("displacements", displacements, (None, self.num_atoms, 3))
         ref = np.ascontiguousarray(ref_positions, dtype=np.float64)
         disp = np.ascontiguousarray(displacements, dtype=np.float64)
         out = np.empty((disp.shape[0], 3, 3), dtype=np.float64)
         handle = self._ensure_handle()
-        rc = _lib.load().rn_potgnn_raman_tensors(handle, _ptr(ref), _ptr(disp), disp.shape[0],
-                                                 float(delta), _ptr(out))
-        _lib.check(rc, handle, "rn_potgnn_raman_tensors")
+        lib = _lib.load()
+        if method == "analytic":
+            rc = lib.rn_potgnn_raman_tensors_analytic(handle, _ptr(ref), _ptr(disp), disp.shape[0],
+                                                      _ptr(out))
+            _lib.check(rc, handle, "rn_potgnn_raman_tensors_analytic")
+        elif method == "finite-difference":
+            rc = lib.rn_potgnn_raman_tensors(handle, _ptr(ref), _ptr(disp), disp.shape[0],
+                                             float(delta), _ptr(out))
+            _lib.check(rc, handle, "rn_potgnn_raman_tensors")
+        else:
+            raise ValueError(f"unsupported method: {method}")
+        return out
+
+    def alpha_jacobian(self, positions, float64: bool = True) -> NDArray[np.float64]:
+        """``d vec6_k / d x_{n,c}`` of the standardised 6-vector at one structure,
+        ``(6, N, 3)``, by reverse-mode differentiation on the device."""
+        verify_ndarray_shape("positions", positions, (self.num_atoms, 3))
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        out = np.empty((6, self.num_atoms, 3), dtype=np.float64)
+        handle = self._ensure_handle()
+        rc = _lib.load().rn_potgnn_alpha_jacobian(handle, _ptr(pos), int(float64), _ptr(out))
+        _lib.check(rc, handle, "rn_potgnn_alpha_jacobian")
         return out
 
     # ------------------------------------------------------------------ introspection

@@ -238,3 +238,35 @@ def test_other_widths_and_graphs_against_oracle(case, cutoff, fn, fe, passes):
     std_got = (got - oracle.mean) / oracle.std
     std_want = (want - oracle.mean) / oracle.std
     assert _rel_err(std_got, std_want) < REL, (case, fn, fe)
+
+
+@pytest.mark.parametrize("case", ["triclinic20", "rocksalt64_parity", "rocksalt64_perf"])
+def test_reverse_mode_jacobian_against_autograd(case):
+    """d(vec6)/d(r): device reverse mode vs torch autograd through the float64 oracle."""
+    from oracle import potgnn_oracle as O
+    g = load_golden(case)
+    model = product_model_from_golden(g)
+    oracle = O.model_from_arrays(g).to(torch.float64)
+    oracle.coefficient = model.gauss_coefficient
+    pos = g["pos_batch"][1]
+    want = O.jacobian(oracle, pos)
+    got64 = model.alpha_jacobian(pos, float64=True)
+    scale = np.abs(want).max()
+    assert np.abs(got64 - want).max() < 1e-9 * scale, np.abs(got64 - want).max() / scale
+    got32 = model.alpha_jacobian(pos, float64=False)
+    assert np.abs(got32 - want).max() < 2e-5 * scale, np.abs(got32 - want).max() / scale
+    # translating every atom together changes nothing
+    assert np.abs(got64.sum(axis=1)).max() < 1e-9 * scale
+
+
+def test_analytic_raman_tensors_match_finite_differences():
+    """2 (d alpha/d r).d_m vs the reference's float64 +-delta fixture: equal up to O(delta^2)."""
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g)
+    ref = g["ph/raman_tensors"]
+    got = model.calc_raman_tensors(g["positions"], g["ph/displacements"], method="analytic")
+    assert _rel_err(got, ref) < 1e-5
+    fd = model.calc_raman_tensors(g["positions"], g["ph/displacements"])
+    assert _rel_err(fd, ref) < 1e-5
+    with pytest.raises(ValueError, match="unsupported method"):
+        model.calc_raman_tensors(g["positions"], g["ph/displacements"], method="magic")
