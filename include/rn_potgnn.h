@@ -141,6 +141,33 @@ int rn_potgnn_alpha_jacobian(rn_potgnn *h, const double *positions, int use_floa
 int rn_potgnn_raman_tensors_analytic(rn_potgnn *h, const double *ref_positions,
                                      const double *displacements, int64_t M, double *raman);
 
+/* ------------------------------------------------------------------ training
+ * Replaces the forward/backward of one optimisation step of train_single_epoch
+ * (ramannoodle/pmodel/torch/_train.py:63-76); the optimiser itself stays with the caller
+ * (torch.optim works on the host copies of the parameters).
+ */
+
+/* Replace the parameters of an existing evaluator (same layout as rn_potgnn_create). */
+int rn_potgnn_set_weights(rn_potgnn *h, const float *weights, size_t num_weights);
+
+/*
+ * PotGNN.forward in TRAINING mode (_gnn.py:617-665 with BatchNorm1d using the statistics of
+ * all S*E rows of this batch, _gnn.py:534) on S <= max_chunk_structures frames; keeps the
+ * tape for rn_potgnn_train_backward.  Returns the standardised 6-vectors and the batch
+ * mean / biased variance of the BatchNorm input (host f32[Fe] each) so that the caller can
+ * update running_mean / running_var as torch does.
+ */
+int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, float *vec6,
+                            float *batch_mean, float *batch_var);
+
+/*
+ * Gradient of a scalar loss with respect to every parameter, given dL/dvec6 (host f32[S*6])
+ * for the batch of the preceding rn_potgnn_train_forward.  `grads` (host f32, length
+ * rn_potgnn_weight_count) has the layout of `weights`; entries of buffers
+ * (Gaussian offsets, running statistics) are zero.
+ */
+int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads);
+
 /* ------------------------------------------------------------------ introspection */
 
 /* Number of edge triplets T of the frozen graph. */

@@ -322,19 +322,23 @@ def edge_block(sd, p, node, edge, i, j, t_i, t_j, t_k, slot5, slot6):
     return (edge + c2 + c3).tanh()
 
 
-def readout_mlp(sd, edge):
-    """Linear -> BatchNorm1d(eval) -> ssp -> Linear -> ssp -> Linear(12)
-    (ramannoodle/pmodel/torch/_gnn.py:532-539)."""
+def readout_mlp(sd, edge, train: bool = False):
+    """Linear -> BatchNorm1d -> ssp -> Linear -> ssp -> Linear(12)
+    (ramannoodle/pmodel/torch/_gnn.py:532-539).  ``train=True`` normalises with the batch
+    statistics over all rows, as ``model.train()`` does in ``_train.py:63``."""
     pre = "_to_polarizability_embedding."
     x = lin(sd, pre + "0", edge)
-    x = F.batch_norm(x, sd[pre + "1.running_mean"], sd[pre + "1.running_var"],
-                     sd[pre + "1.weight"], sd[pre + "1.bias"], False, 0.0, 1e-5)
+    if train:
+        x = F.batch_norm(x, None, None, sd[pre + "1.weight"], sd[pre + "1.bias"], True, 0.0, 1e-5)
+    else:
+        x = F.batch_norm(x, sd[pre + "1.running_mean"], sd[pre + "1.running_var"],
+                         sd[pre + "1.weight"], sd[pre + "1.bias"], False, 0.0, 1e-5)
     x = lin(sd, pre + "3", ssp(x))
     return lin(sd, pre + "5", ssp(x))
 
 
 def forward(model: OracleModel, positions, faithful: bool = True, stages: dict | None = None,
-            grad: bool = False):
+            grad: bool = False, train: bool = False):
     """Standardised polarizability 6-vectors ``[S,6]``
     (ramannoodle/pmodel/torch/_gnn.py:617-665).  ``grad=True`` keeps the autograd graph (used
     to check the device's reverse-mode Jacobian d alpha / d r)."""
@@ -355,7 +359,7 @@ def forward(model: OracleModel, positions, faithful: bool = True, stages: dict |
             if stages is not None:
                 stages[f"node{p + 1}"] = node
                 stages[f"edge{p + 1}"] = edge
-        emb = readout_mlp(sd, edge)
+        emb = readout_mlp(sd, edge, train)
         vec = edge_polarizability_vectors(emb, unit)
         if stages is not None:
             stages["pol_emb"] = emb
@@ -406,3 +410,19 @@ def jacobian(model: OracleModel, positions_one: np.ndarray) -> np.ndarray:
         (g,) = torch.autograd.grad(out[0, k], x, retain_graph=True)
         rows.append(g[0].numpy().copy())
     return np.array(rows)
+
+
+def train_gradients(model: OracleModel, positions: np.ndarray, targets: np.ndarray):
+    """One training step's forward/backward (``_train.py:63-73`` with ``MSELoss``): returns
+    ``(out [S,6], loss, {parameter name: gradient})`` by torch autograd."""
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(
+        ("offset", "running_mean", "running_var")) else v) for k, v in model.sd.items()}
+    m = OracleModel(model.lattice, model.atomic_numbers, model.edges, model.trip, model.atom_type_map,
+                    sd, model.coefficient, model.fn, model.fe, model.passes, model.mean, model.std,
+                    model.dtype)
+    out = forward(m, positions, faithful=False, grad=True, train=True)
+    loss = F.mse_loss(out, torch.as_tensor(targets).type(out.dtype))
+    loss.backward()
+    grads = {k: v.grad.detach().numpy().copy() for k, v in sd.items()
+             if v.is_floating_point() and v.requires_grad}
+    return out.detach().numpy(), float(loss.detach()), grads

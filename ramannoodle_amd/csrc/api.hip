@@ -85,7 +85,7 @@ struct PackedLayout {
     size_t c3_WnT, c3_nshift, c3_WeT, c3n1_g, c3n1_b, c3n2_g, c3n2_b;
   };
   std::vector<Pass> pass;
-  size_t W0T, W3T, b3, W5T, b5, ones;
+  size_t W0T, W3T, b3, W5T, b5, ones, b0p;
   // device-computed
   size_t node_table, scale0, shift0;
   size_t total = 0;
@@ -116,7 +116,8 @@ struct Precision {
   std::vector<DeviceBuf> snap_node, snap_edge;
   // forward tape + cotangent workspace of the reverse pass (Jacobian d alpha / d r)
   std::vector<DeviceBuf> tape_node, tape_edge;
-  DeviceBuf bw[16];
+  DeviceBuf bw[17];
+  DeviceBuf tape_z1, bn_stats, grad;  // training: pre-BatchNorm activations, batch sums, gradient blob
   bool tape_on = false;
 };
 
@@ -148,6 +149,7 @@ struct rn_potgnn {
   // cached I/O staging for the host entry points
   DeviceBuf io_pos, io_alpha, io_vec6;
   int last_chunk_structs = 0;
+  int train_S = 0;  // frames of the pending train_forward (0 = none)
   bool last_was_f64 = false;
   // profiling
   int profiling = 0;
@@ -223,6 +225,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
   L.W5T = L.take((size_t)HP * 32);
   L.b5 = L.take(32);
   L.ones = L.take(HP);
+  L.b0p = L.take(HP);  // bias of readout Linear 0, padded (training-mode forward)
   L.node_table = L.take((size_t)K * FnP);
   L.scale0 = L.take(HP);
   L.shift0 = L.take(HP);
@@ -304,6 +307,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
       for (int k = 0; k < Fe; ++k) o[L.W0T + (size_t)k * HP + r] = W0[r * Fe + k];
     c += (size_t)Fe * Fe;
     copy(L.b0, Fe);
+    std::memcpy(&o[L.b0p], &o[L.b0], Fe * sizeof(float));
     copy(L.bn_w, Fe);
     copy(L.bn_b, Fe);
     copy(L.bn_rm, Fe);
@@ -334,6 +338,22 @@ size_t per_structure_elems(const rn_potgnn *h) {
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
   const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
   return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA + E * 4 * FeP;
+}
+
+template <typename T>
+void upload_weights(rn_potgnn *h) {  // (re)upload the packed weights and redo the device precompute
+  Precision<T> &P = prec<T>(h);
+  const PackedLayout &L = h->lay;
+  std::vector<T> host(h->packed.size());
+  for (size_t i = 0; i < host.size(); ++i) host[i] = (T)h->packed[i];
+  P.weights.ensure(host.size() * sizeof(T));
+  HIP_TRY(hipMemcpy(P.weights.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  T *w = P.weights.template as<T>();
+  launch_setup<T>(w + L.emb, w + L.W2, w + L.b2, w + L.W4, w + L.b4, h->cfg.num_atom_types, h->d,
+                  w + L.node_table, w + L.b0, w + L.bn_w, w + L.bn_b, w + L.bn_rm, w + L.bn_rv,
+                  w + L.scale0, w + L.shift0, P.lanes[0].stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(P.lanes[0].stream));
 }
 
 template <typename T>
@@ -673,36 +693,157 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
   }
 }
 
-// d(standardised 6-vector)/d(fractional positions) at ONE structure by reverse mode:
-// forward with a tape of the per-pass embeddings, then six cotangents (one per component)
-// pushed back through readout, P x (EdgeBlock, NodeBlock), radial basis and geometry.
+// Reverse pass over a taped forward of S frames with B cotangents per frame.
+//   d_dout6   device [S*B, 6]  cotangents of the standardised 6-vectors
+//   d_dpos    device f64 [S*B, N, 3] or null   -> d / d(fractional positions)
+//   grad      device packed-layout gradient blob or null -> parameter gradients (training)
+//   train_bn  readout BatchNorm used batch statistics (z1 / bn_stats hold the taped values)
 template <typename T>
-void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*/) {
-  ensure_precision<T>(h);
+struct Reverse {
+  int S, B;
+  const T *d_dout6;
+  double *d_dpos;
+  T *grad;
+  bool train_bn;
+};
+
+enum { DE0, DE1, DN0, DN1, DNX, DPQ, DNP3, DC2, DPROD, DBC1, DNPC1, DPOL, DUNIT, DH, POL, DOUT, BWN };
+
+template <typename T>
+void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   Precision<T> &P = prec<T>(h);
+  const PackedLayout &L = h->lay;
   const Graph &g = h->g;
   const Dims d = h->d;
   const int N = g.N, E = g.E, NP = h->cfg.num_message_passes;
-  const int B = 6, C = 6;
+  const int S = rv.S, B = rv.B, C = S * B;
   const int HP = std::max(d.FeP, 32);
-  Lane<T> &ln = P.lanes[0];
-  hipStream_t st = ln.stream;
+  hipStream_t st = c.st();
+  const size_t ce = (size_t)C * E, cn = (size_t)C * N, fe = (size_t)S * E, fn = (size_t)S * N;
+  const size_t sizes[BWN] = {ce * d.FeP, ce * d.FeP, cn * d.FnP, cn * d.FnP, cn * d.FnP,
+                             ce * 4 * d.FeP, cn * 6 * d.FeP, ce * std::max(2 * d.FeP, HP), ce * d.FnP,
+                             ce * 2 * d.FnP, cn * 2 * d.FnP, ce * 32, ce * 4, ce * HP, fe * 32,
+                             (size_t)C * 6};
+  T *b[BWN];
+  for (int i = 0; i < BWN; ++i) {
+    P.bw[i].ensure(sizes[i] * sizeof(T));
+    b[i] = P.bw[i].template as<T>();
+  }
+  T *bufA = c.bufA, *bufB = c.bufB, *unit4 = c.unit4;
+  T *G = rv.grad;
+  T *Wd = P.weights.template as<T>();
 
+  // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
+  const T *edgeP = P.tape_edge[NP].template as<T>();
+  if (rv.train_bn) {
+    launch_bn_train_fwd<T>(P.tape_z1.template as<T>(), fe, HP, d.Fe, P.bn_stats.template as<double>(),
+                           Wd + L.bn_w, Wd + L.bn_b, bufA, b[DH] /*scratch for mean/var*/, st);
+  } else {
+    launch_rowgemm<T>(edgeP, fe, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0, nullptr, g, st);
+  }
+  launch_rowgemm<T>(bufA, fe, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
+  launch_rowgemm<T>(bufB, fe, HP, P.ro.W5T, 32, b[POL], nullptr, P.ro.b5, false, 0, nullptr, g, st);
+  launch_readout_bwd<T>(rv.d_dout6, b[POL], unit4, C, B, g, b[DPOL], b[DUNIT], st);
+  if (G) launch_gemm_tn<T>(bufB, HP, b[DPOL], 32, ce, HP, 32, G + L.W5T, 32, G + L.b5, 0, nullptr, g, st);
+  launch_gemm_nt<T>(b[DPOL], ce, 32, P.ro.W5T, 32, HP, b[DH], false, st);          // d h2
+  launch_ssp_bwd<T>(b[DH], bufB, nullptr, E, HP, C, B, st);                        // d z2
+  if (G) launch_gemm_tn<T>(bufA, HP, b[DH], HP, ce, HP, HP, G + L.W3T, HP, G + L.b3, 0, nullptr, g, st);
+  launch_gemm_nt<T>(b[DH], ce, HP, P.ro.W3T, HP, HP, b[DC2], false, st);           // d h1
+  if (rv.train_bn) {
+    launch_ssp_bwd<T>(b[DC2], bufA, nullptr, E, HP, C, B, st);                     // d (BN output)
+    launch_bn_train_bwd<T>(b[DC2], P.tape_z1.template as<T>(), fe, HP, d.Fe,
+                           P.bn_stats.template as<double>(), P.bn_stats.template as<double>() + 2 * HP,
+                           Wd + L.bn_w, G + L.bn_w, G + L.bn_b, st);               // d z1
+    launch_gemm_tn<T>(edgeP, d.FeP, b[DC2], HP, ce, d.FeP, HP, G + L.W0T, HP, G + L.b0p, 0, nullptr, g, st);
+  } else {
+    launch_ssp_bwd<T>(b[DC2], bufA, P.ro.scale0, E, HP, C, B, st);                 // d acc1
+  }
+  launch_gemm_nt<T>(b[DC2], ce, HP, P.ro.W0T, HP, d.FeP, b[DE0], false, st);       // d edge_P
+  HIP_TRY(hipMemsetAsync(b[DN0], 0, cn * d.FnP * sizeof(T), st));                  // d node_P = 0
+
+  int cur = 0;  // b[DE0 + cur], b[DN0 + cur] hold the cotangents of (edge, node)_{p+1}
+  for (int p = NP - 1; p >= 0; --p) {
+    const PassW<T> &w = P.pass[p];
+    PassW<T> gw = w;  // the same offsets inside the gradient blob
+    if (G) {
+      const auto &q = L.pass[p];
+      gw.c1_norm = {G + q.c1n_g, G + q.c1n_b};
+      gw.final_norm = {G + q.fin_g, G + q.fin_b};
+      gw.c2_norm_1 = {G + q.c2n1_g, G + q.c2n1_b};
+      gw.c2_norm_2 = {G + q.c2n2_g, G + q.c2n2_b};
+      gw.c3_norm_1 = {G + q.c3n1_g, G + q.c3n1_b};
+      gw.c3_norm_2 = {G + q.c3n2_g, G + q.c3n2_b};
+    }
+    const T *node0 = P.tape_node[p].template as<T>(), *node1 = P.tape_node[p + 1].template as<T>();
+    const T *edge0 = P.tape_edge[p].template as<T>(), *edge1 = P.tape_edge[p + 1].template as<T>();
+    T *de_next = b[DE0 + cur], *de_prev = b[DE0 + (cur ^ 1)];
+    T *dn_next = b[DN0 + cur], *dn_prev = b[DN0 + (cur ^ 1)];
+    // recompute this pass's projections from the tape
+    launch_rowgemm<T>(node0, fn, d.FnP, w.c1_WnT, 2 * d.FnP, c.npc1, nullptr, w.c1_bias, false, 0, nullptr, g, st);
+    launch_rowgemm<T>(node1, fn, d.FnP, w.c3_WnT, 6 * d.FeP, c.np3, nullptr, w.c3_nshift, false, 0, nullptr, g, st);
+    launch_rowgemm<T>(edge0, fe, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0, nullptr, g, st);
+    launch_rowgemm<T>(nullptr, fe, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1, node1, g, st);
+    // EdgeBlock
+    HIP_TRY(hipMemsetAsync(b[DPQ], 0, sizes[DPQ] * sizeof(T), st));
+    HIP_TRY(hipMemsetAsync(b[DNP3], 0, sizes[DNP3] * sizeof(T), st));
+    launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, de_next, de_prev, b[DPQ], b[DNP3], b[DC2], C, B, g, d, w,
+                       G ? &gw : nullptr, st);
+    launch_gemm_nt<T>(b[DPQ], ce, 4 * d.FeP, w.c3_WeT, 4 * d.FeP, d.FeP, de_prev, true, st);
+    // node_{p+1} cotangent: incoming + projections + c2 operand
+    HIP_TRY(hipMemcpyAsync(b[DNX], dn_next, cn * d.FnP * sizeof(T), hipMemcpyDeviceToDevice, st));
+    launch_gemm_nt<T>(b[DNP3], cn, 6 * d.FeP, w.c3_WnT, 6 * d.FeP, d.FnP, b[DNX], true, st);
+    launch_gemm_nt<T>(b[DC2], ce, 2 * d.FeP, w.c2_WT, 2 * d.FeP, d.FnP, b[DPROD], false, st);
+    launch_prod_bwd<T>(b[DPROD], node1, b[DNX], C, B, g, d, st);
+    if (G) {
+      const auto &q = L.pass[p];
+      launch_gemm_tn<T>(edge0, d.FeP, b[DPQ], 4 * d.FeP, ce, d.FeP, 4 * d.FeP, G + q.c3_WeT, 4 * d.FeP, nullptr, 0, nullptr, g, st);
+      launch_gemm_tn<T>(node1, d.FnP, b[DNP3], 6 * d.FeP, cn, d.FnP, 6 * d.FeP, G + q.c3_WnT, 6 * d.FeP, G + q.c3_nshift, 0, nullptr, g, st);
+      launch_gemm_tn<T>(nullptr, d.FnP, b[DC2], 2 * d.FeP, ce, d.FnP, 2 * d.FeP, G + q.c2_WT, 2 * d.FeP, G + q.c2_bias, 1, node1, g, st);
+    }
+    // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
+    launch_rowgemm<T>(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
+    launch_node_bwd<T>(c.npc1, bufA, node1, b[DNX], dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w,
+                       G ? &gw : nullptr, st);
+    launch_gemm_nt<T>(b[DBC1], ce, 2 * d.FnP, w.c1_WeT, 2 * d.FnP, d.FeP, de_prev, true, st);
+    launch_gemm_nt<T>(b[DNPC1], cn, 2 * d.FnP, w.c1_WnT, 2 * d.FnP, d.FnP, dn_prev, true, st);
+    if (G) {
+      const auto &q = L.pass[p];
+      launch_gemm_tn<T>(edge0, d.FeP, b[DBC1], 2 * d.FnP, ce, d.FeP, 2 * d.FnP, G + q.c1_WeT, 2 * d.FnP, nullptr, 0, nullptr, g, st);
+      launch_gemm_tn<T>(node0, d.FnP, b[DNPC1], 2 * d.FnP, cn, d.FnP, 2 * d.FnP, G + q.c1_WnT, 2 * d.FnP, G + q.c1_bias, 0, nullptr, g, st);
+    }
+    cur ^= 1;
+  }
+  if (G)
+    launch_node_embed_bwd<T>(b[DN0 + cur], S, g, d, h->cfg.num_atom_types, Wd + L.emb, Wd + L.W2, Wd + L.b2,
+                             Wd + L.W4, G + L.emb, G + L.W2, G + L.b2, G + L.W4, G + L.b4, st);
+  if (rv.d_dpos)
+    launch_geom_bwd<T>(b[DE0 + cur], b[DUNIT], unit4, P.lattice.template as<T>(), P.offsets,
+                       (T)h->cfg.gauss_coefficient, C, B, g, d, rv.d_dpos, st);
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename T>
+void ensure_tape(rn_potgnn *h, int S) {
+  Precision<T> &P = prec<T>(h);
+  const int NP = h->cfg.num_message_passes;
   P.tape_node.resize(NP + 1);
   P.tape_edge.resize(NP + 1);
   for (int p = 0; p <= NP; ++p) {
-    P.tape_node[p].ensure((size_t)N * d.FnP * sizeof(T));
-    P.tape_edge[p].ensure((size_t)E * d.FeP * sizeof(T));
+    P.tape_node[p].ensure((size_t)S * h->g.N * h->d.FnP * sizeof(T));
+    P.tape_edge[p].ensure((size_t)S * h->g.E * h->d.FeP * sizeof(T));
   }
-  h->io_pos.ensure((size_t)N * 3 * sizeof(double));
-  HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice));
+}
 
-  // ---- forward with tape (S = 1)
+// forward of S frames on lane 0 with the per-pass embeddings recorded
+template <typename T>
+ChunkRun<T> taped_forward(rn_potgnn *h, const double *d_pos, int S) {
+  Precision<T> &P = prec<T>(h);
+  ensure_tape<T>(h, S);
   P.tape_on = true;
-  ChunkRun<T> c(h, ln, h->io_pos.as<double>(), 1, nullptr, nullptr, nullptr);
+  ChunkRun<T> c(h, P.lanes[0], d_pos, S, nullptr, nullptr, nullptr);
   try {
     c.begin();
-    for (int p = 0; p < NP; ++p) {
+    for (int p = 0; p < h->cfg.num_message_passes; ++p) {
       c.stage_project(p);
       c.stage_aggregate(p);
     }
@@ -711,77 +852,174 @@ void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*
     throw;
   }
   P.tape_on = false;
+  return c;
+}
 
-  // ---- cotangent workspace
-  enum { DE0, DE1, DN0, DN1, DNX, DPQ, DNP3, DC2, DPROD, DBC1, DNPC1, DPOL, DUNIT, DH, POL, DOUT };
-  const size_t ce = (size_t)C * E, cn = (size_t)C * N;
-  const size_t sizes[16] = {ce * d.FeP, ce * d.FeP, cn * d.FnP, cn * d.FnP, cn * d.FnP,
-                            ce * 4 * d.FeP, cn * 6 * d.FeP, ce * 2 * d.FeP, ce * d.FnP,
-                            ce * 2 * d.FnP, cn * 2 * d.FnP, ce * 32, ce * 4, ce * HP,
-                            (size_t)E * 32, (size_t)C * 6};
-  T *b[16];
-  for (int i = 0; i < 16; ++i) {
-    P.bw[i].ensure(sizes[i] * sizeof(T));
-    b[i] = P.bw[i].template as<T>();
-  }
-  DeviceBuf dposbuf;
-  dposbuf.ensure(cn * 3 * sizeof(double));
-  HIP_TRY(hipMemsetAsync(dposbuf.p, 0, cn * 3 * sizeof(double), st));
-  {
-    std::vector<T> eye(36, (T)0);
-    for (int k = 0; k < 6; ++k) eye[k * 6 + k] = (T)1;
-    HIP_TRY(hipMemcpyAsync(b[DOUT], eye.data(), sizeof(T) * 36, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
-  T *bufA = c.bufA, *bufB = c.bufB, *unit4 = c.unit4;
+// d(standardised 6-vector)/d(fractional positions) at ONE structure: six cotangents (one
+// per component) pushed back through readout, P x (EdgeBlock, NodeBlock), radial basis and
+// geometry.
+template <typename T>
+void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*/) {
+  ensure_precision<T>(h);
+  Precision<T> &P = prec<T>(h);
+  const int N = h->g.N;
+  h->io_pos.ensure((size_t)N * 3 * sizeof(double));
+  HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice));
+  ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), 1);
+  hipStream_t st = c.st();
+  DeviceBuf dposbuf, seeds;
+  dposbuf.ensure((size_t)6 * N * 3 * sizeof(double));
+  seeds.ensure(36 * sizeof(T));
+  HIP_TRY(hipMemsetAsync(dposbuf.p, 0, (size_t)6 * N * 3 * sizeof(double), st));
+  std::vector<T> eye(36, (T)0);
+  for (int k = 0; k < 6; ++k) eye[k * 6 + k] = (T)1;
+  HIP_TRY(hipMemcpyAsync(seeds.p, eye.data(), sizeof(T) * 36, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  Reverse<T> rv{1, 6, seeds.as<T>(), dposbuf.as<double>(), nullptr, false};
+  reverse_pass<T>(h, c, rv);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpy(host_jac, dposbuf.p, (size_t)6 * N * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)P;
+}
 
-  // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
-  const T *edgeP = P.tape_edge[NP].template as<T>();
-  launch_rowgemm<T>(edgeP, E, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0, nullptr, g, st);
-  launch_rowgemm<T>(bufA, E, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
-  launch_rowgemm<T>(bufB, E, HP, P.ro.W5T, 32, b[POL], nullptr, P.ro.b5, false, 0, nullptr, g, st);
-  launch_readout_bwd<T>(b[DOUT], b[POL], unit4, C, B, g, b[DPOL], b[DUNIT], st);
-  launch_gemm_nt<T>(b[DPOL], ce, 32, P.ro.W5T, 32, HP, b[DH], false, st);          // d h2
-  launch_ssp_bwd<T>(b[DH], bufB, nullptr, E, HP, C, B, st);                        // d z2
-  launch_gemm_nt<T>(b[DH], ce, HP, P.ro.W3T, HP, HP, b[DC2], false, st);  // d h1 (uses DC2 as scratch)
-  launch_ssp_bwd<T>(b[DC2], bufA, P.ro.scale0, E, HP, C, B, st);                   // d acc1
-  launch_gemm_nt<T>(b[DC2], ce, HP, P.ro.W0T, HP, d.FeP, b[DE0], false, st);       // d edge_P
-  HIP_TRY(hipMemsetAsync(b[DN0], 0, cn * d.FnP * sizeof(T), st));                  // d node_P = 0
-
-  int cur = 0;  // b[DE0 + cur], b[DN0 + cur] hold the cotangents of (edge, node)_{p+1}
-  for (int p = NP - 1; p >= 0; --p) {
-    const PassW<T> &w = P.pass[p];
-    const T *node0 = P.tape_node[p].template as<T>(), *node1 = P.tape_node[p + 1].template as<T>();
-    const T *edge0 = P.tape_edge[p].template as<T>(), *edge1 = P.tape_edge[p + 1].template as<T>();
-    T *de_next = b[DE0 + cur], *de_prev = b[DE0 + (cur ^ 1)];
-    T *dn_next = b[DN0 + cur], *dn_prev = b[DN0 + (cur ^ 1)];
-    // recompute this pass's projections from the tape
-    launch_rowgemm<T>(node0, N, d.FnP, w.c1_WnT, 2 * d.FnP, c.npc1, nullptr, w.c1_bias, false, 0, nullptr, g, st);
-    launch_rowgemm<T>(node1, N, d.FnP, w.c3_WnT, 6 * d.FeP, c.np3, nullptr, w.c3_nshift, false, 0, nullptr, g, st);
-    launch_rowgemm<T>(edge0, E, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0, nullptr, g, st);
-    launch_rowgemm<T>(nullptr, E, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1, node1, g, st);
-    // EdgeBlock
-    HIP_TRY(hipMemsetAsync(b[DPQ], 0, sizes[DPQ] * sizeof(T), st));
-    HIP_TRY(hipMemsetAsync(b[DNP3], 0, sizes[DNP3] * sizeof(T), st));
-    launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, de_next, de_prev, b[DPQ], b[DNP3], b[DC2], C, B, g, d, w, st);
-    launch_gemm_nt<T>(b[DPQ], ce, 4 * d.FeP, w.c3_WeT, 4 * d.FeP, d.FeP, de_prev, true, st);
-    // node_{p+1} cotangent: incoming + projections + c2 operand
-    HIP_TRY(hipMemcpyAsync(b[DNX], dn_next, cn * d.FnP * sizeof(T), hipMemcpyDeviceToDevice, st));
-    launch_gemm_nt<T>(b[DNP3], cn, 6 * d.FeP, w.c3_WnT, 6 * d.FeP, d.FnP, b[DNX], true, st);
-    launch_gemm_nt<T>(b[DC2], ce, 2 * d.FeP, w.c2_WT, 2 * d.FeP, d.FnP, b[DPROD], false, st);
-    launch_prod_bwd<T>(b[DPROD], node1, b[DNX], C, B, g, d, st);
-    // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
-    launch_rowgemm<T>(edge0, E, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
-    launch_node_bwd<T>(c.npc1, bufA, node1, b[DNX], dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w, st);
-    launch_gemm_nt<T>(b[DBC1], ce, 2 * d.FnP, w.c1_WeT, 2 * d.FnP, d.FeP, de_prev, true, st);
-    launch_gemm_nt<T>(b[DNPC1], cn, 2 * d.FnP, w.c1_WnT, 2 * d.FnP, d.FnP, dn_prev, true, st);
-    cur ^= 1;
-  }
-  launch_geom_bwd<T>(b[DE0 + cur], b[DUNIT], unit4, P.lattice.template as<T>(), P.offsets,
-                     (T)h->cfg.gauss_coefficient, C, B, g, d, dposbuf.as<double>(), st);
+// ---- training (float32): forward with batch-statistics BatchNorm, then parameter gradients
+void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, float *batch_mean,
+                   float *batch_var) {
+  typedef float T;
+  ensure_precision<T>(h);
+  Precision<T> &P = h->f32;
+  const PackedLayout &L = h->lay;
+  const Graph &g = h->g;
+  const Dims d = h->d;
+  const int HP = std::max(d.FeP, 32);
+  const size_t pb = (size_t)S * g.N * 3 * sizeof(double);
+  h->io_pos.ensure(pb);
+  HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, pb, hipMemcpyHostToDevice));
+  ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), S);
+  hipStream_t st = c.st();
+  const int64_t R = (int64_t)S * g.E;
+  T *Wd = P.weights.as<T>();
+  P.tape_z1.ensure((size_t)R * HP * sizeof(T));
+  P.bn_stats.ensure(sizeof(double) * 4 * HP);
+  DeviceBuf mv;
+  mv.ensure(sizeof(T) * 2 * HP);
+  const T *edgeP = P.tape_edge[h->cfg.num_message_passes].as<T>();
+  // z1 = edge W0^T + b0 ; h1 = ssp(BN_batch(z1)) ; then the rest of the readout as in eval
+  launch_rowgemm<T>(edgeP, R, d.FeP, P.ro.W0T, HP, P.tape_z1.as<T>(), nullptr, Wd + L.b0p, false, 0,
+                    nullptr, g, st);
+  launch_bn_train_fwd<T>(P.tape_z1.as<T>(), R, HP, d.Fe, P.bn_stats.as<double>(), Wd + L.bn_w, Wd + L.bn_b,
+                         c.bufA, mv.as<T>(), st);
+  launch_rowgemm<T>(c.bufA, R, HP, P.ro.W3T, HP, c.bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
+  launch_rowgemm<T>(c.bufB, R, HP, P.ro.W5T, 32, c.bufA, nullptr, P.ro.b5, false, 0, nullptr, g, st);
+  h->io_vec6.ensure((size_t)S * 6 * sizeof(float));
+  const double *ms = h->d_mean_std.as<double>();
+  launch_readout_reduce<T>(c.bufA, c.unit4, S, g, ms, ms + 9, h->io_vec6.as<float>(), nullptr, nullptr, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipMemcpy(host_jac, dposbuf.p, cn * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<T> mvh(2 * HP);
+  HIP_TRY(hipMemcpy(mvh.data(), mv.p, sizeof(T) * 2 * HP, hipMemcpyDeviceToHost));
+  for (int k = 0; k < d.Fe; ++k) {
+    batch_mean[k] = mvh[k];
+    batch_var[k] = mvh[HP + k];
+  }
+  h->train_S = S;
+}
+
+void unpack_grads(const rn_potgnn *h, const float *gp, float *out);
+
+void train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
+  typedef float T;
+  Precision<T> &P = h->f32;
+  const int S = h->train_S;
+  if (S <= 0) throw HipError{hipErrorInvalidValue, "train_backward without train_forward"};
+  ChunkRun<T> c(h, P.lanes[0], h->io_pos.as<double>(), S, nullptr, nullptr, nullptr);
+  hipStream_t st = c.st();
+  DeviceBuf seeds;
+  seeds.ensure((size_t)S * 6 * sizeof(T));
+  HIP_TRY(hipMemcpy(seeds.p, dvec6, (size_t)S * 6 * sizeof(T), hipMemcpyHostToDevice));
+  P.grad.ensure(h->lay.total * sizeof(T));
+  HIP_TRY(hipMemsetAsync(P.grad.p, 0, h->lay.total * sizeof(T), st));
+  Reverse<T> rv{S, 1, seeds.as<T>(), nullptr, P.grad.as<T>(), true};
+  reverse_pass<T>(h, c, rv);
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<float> gp(h->lay.total);
+  HIP_TRY(hipMemcpy(gp.data(), P.grad.p, gp.size() * sizeof(float), hipMemcpyDeviceToHost));
+  unpack_grads(h, gp.data(), grads);
+  h->train_S = 0;
+}
+
+// inverse of pack_weights for a gradient blob in the packed layout -> state_dict order
+void unpack_grads(const rn_potgnn *h, const float *gp, float *out) {
+  const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP, FeP = h->d.FeP,
+            P = h->cfg.num_message_passes;
+  const int HP = std::max(FeP, 32);
+  const PackedLayout &L = h->lay;
+  float *c = out;
+  auto copy = [&](size_t src, size_t n) {
+    std::memcpy(c, gp + src, n * sizeof(float));
+    c += n;
+  };
+  auto zeros = [&](size_t n) {
+    std::memset(c, 0, n * sizeof(float));
+    c += n;
+  };
+  copy(L.emb, (size_t)K * Fn);
+  copy(L.W2, (size_t)Fn * Fn);
+  copy(L.b2, Fn);
+  copy(L.W4, (size_t)Fn * Fn);
+  copy(L.b4, Fn);
+  zeros(Fe);  // "_edge_embedding.offset" is a buffer
+  for (int p = 0; p < P; ++p) {
+    const auto &q = L.pass[p];
+    for (int r = 0; r < 2 * Fn; ++r) {
+      const int col = gated_col(r, Fn, FnP);
+      for (int k = 0; k < Fn; ++k) *c++ = gp[q.c1_WnT + (size_t)k * 2 * FnP + col];
+      for (int k = 0; k < Fe; ++k) *c++ = gp[q.c1_WeT + (size_t)k * 2 * FnP + col];
+    }
+    for (int r = 0; r < 2 * Fn; ++r) *c++ = gp[q.c1_bias + gated_col(r, Fn, FnP)];
+    for (int r = 0; r < 2 * Fn; ++r) *c++ = gp[q.c1n_g + gated_col(r, Fn, FnP)];
+    for (int r = 0; r < 2 * Fn; ++r) *c++ = gp[q.c1n_b + gated_col(r, Fn, FnP)];
+    copy(q.fin_g, Fn);
+    copy(q.fin_b, Fn);
+  }
+  for (int p = 0; p < P; ++p) {
+    const auto &q = L.pass[p];
+    for (int r = 0; r < 2 * Fe; ++r) {
+      const int col = gated_col(r, Fe, FeP);
+      for (int k = 0; k < Fn; ++k) *c++ = gp[q.c2_WT + (size_t)k * 2 * FeP + col];
+    }
+    for (int r = 0; r < 2 * Fe; ++r) *c++ = gp[q.c2_bias + gated_col(r, Fe, FeP)];
+    for (int r = 0; r < 2 * Fe; ++r) {
+      const int col = gated_col(r, Fe, FeP);
+      for (int blk = 0; blk < 3; ++blk)
+        for (int k = 0; k < Fn; ++k) *c++ = gp[q.c3_WnT + (size_t)k * 6 * FeP + blk * 2 * FeP + col];
+      for (int blk = 0; blk < 2; ++blk)
+        for (int k = 0; k < Fe; ++k) *c++ = gp[q.c3_WeT + (size_t)k * 4 * FeP + blk * 2 * FeP + col];
+    }
+    for (int r = 0; r < 2 * Fe; ++r) *c++ = gp[q.c3_nshift + 2 * FeP + gated_col(r, Fe, FeP)];
+    for (int r = 0; r < 2 * Fe; ++r) *c++ = gp[q.c2n1_g + gated_col(r, Fe, FeP)];
+    for (int r = 0; r < 2 * Fe; ++r) *c++ = gp[q.c2n1_b + gated_col(r, Fe, FeP)];
+    for (int r = 0; r < 2 * Fe; ++r) *c++ = gp[q.c3n1_g + gated_col(r, Fe, FeP)];
+    for (int r = 0; r < 2 * Fe; ++r) *c++ = gp[q.c3n1_b + gated_col(r, Fe, FeP)];
+    copy(q.c2n2_g, Fe);
+    copy(q.c2n2_b, Fe);
+    copy(q.c3n2_g, Fe);
+    copy(q.c3n2_b, Fe);
+  }
+  for (int r = 0; r < Fe; ++r)
+    for (int k = 0; k < Fe; ++k) *c++ = gp[L.W0T + (size_t)k * HP + r];
+  copy(L.b0p, Fe);
+  copy(L.bn_w, Fe);
+  copy(L.bn_b, Fe);
+  zeros(Fe);  // running_mean
+  zeros(Fe);  // running_var
+  for (int r = 0; r < Fe; ++r)
+    for (int k = 0; k < Fe; ++k) *c++ = gp[L.W3T + (size_t)k * HP + r];
+  copy(L.b3, Fe);
+  for (int r = 0; r < 12; ++r)
+    for (int k = 0; k < Fe; ++k) *c++ = gp[L.W5T + (size_t)k * 32 + r];
+  copy(L.b5, 12);
 }
 
 int guarded(rn_potgnn *h, const std::function<void()> &fn) {
@@ -1163,6 +1401,45 @@ int rn_potgnn_raman_tensors_analytic(rn_potgnn *h, const double *ref_positions,
       for (int i = 0; i < 9; ++i) raman[m * 9 + i] = 2.0 * h->stdv[i] * v[map[i]];
     }
   });
+}
+
+int rn_potgnn_set_weights(rn_potgnn *h, const float *weights, size_t num_weights) {
+  if (!h || !weights || num_weights != rn_potgnn_weight_count(&h->cfg)) {
+    set_error(h, "invalid arguments to set_weights");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() {
+    HIP_TRY(hipDeviceSynchronize());
+    pack_weights(h, weights);
+    if (h->f32.ready) upload_weights<float>(h);
+    if (h->f64.ready) upload_weights<double>(h);
+  });
+}
+
+int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, float *vec6,
+                            float *batch_mean, float *batch_var) {
+  if (!h || S <= 0 || !positions || !vec6 || !batch_mean || !batch_var) {
+    set_error(h, "invalid arguments to train_forward");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S > h->chunk) {
+    set_error(h, "training batch of %lld frames exceeds max_chunk_structures = %d", (long long)S,
+              h->chunk);
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_forward(h, positions, (int)S, vec6, batch_mean, batch_var); });
+}
+
+int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
+  if (!h || !dvec6 || !grads) {
+    set_error(h, "invalid arguments to train_backward");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (h->train_S <= 0) {
+    set_error(h, "train_backward needs a preceding train_forward");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_backward(h, dvec6, grads); });
 }
 
 int64_t rn_potgnn_num_triplets(const rn_potgnn *h) { return h ? h->g.T : -1; }

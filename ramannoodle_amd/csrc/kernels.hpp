@@ -119,14 +119,29 @@ void launch_ssp_bwd(T *d, const T *h, const T *scale, int64_t rows_per_frame, in
 template <typename T>
 void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
                      const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3, T *dc2pre, int C, int B,
-                     const Graph &g, Dims d, const PassW<T> &w, hipStream_t st);
+                     const Graph &g, Dims d, const PassW<T> &w, const PassW<T> *grad_w,
+                     hipStream_t st);  // grad_w: same layout as w inside the gradient blob, or null
 template <typename T>
 void launch_prod_bwd(const T *dprod, const T *node, T *dnode, int C, int B, const Graph &g, Dims d,
                      hipStream_t st);
 template <typename T>
 void launch_node_bwd(const T *npc1, const T *bc1, const T *node_next, const T *dnode_next,
                      T *dnode_prev, T *dbc1, T *dnpc1, int C, int B, const Graph &g, Dims d,
-                     const PassW<T> &w, hipStream_t st);
+                     const PassW<T> &w, const PassW<T> *grad_w, hipStream_t st);
+// ---- training pieces (weight gradients, BatchNorm in training mode, embedding MLP)
+template <typename T>
+void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
+                    int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st);
+template <typename T>
+void launch_bn_train_fwd(const T *z, int64_t R, int W, int F, double *stats, const T *gamma,
+                         const T *beta, T *h, T *mv, hipStream_t st);
+template <typename T>
+void launch_bn_train_bwd(T *d, const T *z, int64_t R, int W, int F, const double *stats, double *sums,
+                         const T *gamma, T *dgamma, T *dbeta, hipStream_t st);
+template <typename T>
+void launch_node_embed_bwd(const T *dnode0, int S, const Graph &g, Dims d, int K, const T *emb,
+                           const T *W2, const T *b2, const T *W4, T *demb, T *dW2, T *db2, T *dW4,
+                           T *db4, hipStream_t st);
 template <typename T>
 void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *lat, const T *offs,
                      T coef, int C, int B, const Graph &g, Dims d, double *dpos, hipStream_t st);

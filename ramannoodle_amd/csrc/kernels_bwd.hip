@@ -224,12 +224,15 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
     const T *__restrict__ edge_next, const T *__restrict__ dedge_next, T *__restrict__ dedge_prev,
     T *__restrict__ dpq, T *__restrict__ dnp3, T *__restrict__ dc2pre, int C, int B, Graph g, Dims d,
-    PassW<T> w) {
+    PassW<T> w, PassW<T> gw, int want_param_grads) {
   constexpr int FP = LG * 4;
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
   const int q = threadIdx.x % LG;
   if (gid >= (int64_t)C * g.E) return;
   const int c = (int)(gid / g.E), dst = (int)(gid % g.E);
+  // LayerNorm parameter gradients of this lane's columns (training only)
+  Vec4<T> G31f{{0, 0, 0, 0}}, B31f = G31f, G31c = G31f, B31c = G31f, G32 = G31f, B32 = G31f;
+  Vec4<T> G21f = G31f, B21f = G31f, G21c = G31f, B21c = G31f, G22 = G31f, B22 = G31f;
   const int s = c / B;
   const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
   const int64_t cerow0 = (int64_t)c * g.E, cnrow0 = (int64_t)c * g.N;
@@ -292,7 +295,11 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
     Vec4<T> hat = agg;
     const T rstd = ln1_hat<LG>(hat, invn, nvalid);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dagg.v[k] = dz.v[k] * g2.v[k];
+    for (int k = 0; k < 4; ++k) {
+      dagg.v[k] = dz.v[k] * g2.v[k];
+      B32.v[k] += dz.v[k];
+      G32.v[k] += dz.v[k] * hat.v[k];
+    }
     ln1_bwd<LG>(dagg, hat, rstd, invn, nvalid);
   }
   // ---- per triplet: gate + LayerNorm (c3_norm_1) backward; dx goes to P'_d and Q'_e
@@ -307,8 +314,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
     for (int k = 0; k < 4; ++k) {
       T gv, a, b;
       gate_grad(xf.v[k] * g1f.v[k] + b1f.v[k], xc.v[k] * g1c.v[k] + b1c.v[k], gv, a, b);
-      df.v[k] = dagg.v[k] * a * g1f.v[k];
-      dc.v[k] = dagg.v[k] * b * g1c.v[k];
+      const T dyf = dagg.v[k] * a, dyc = dagg.v[k] * b;
+      B31f.v[k] += dyf;
+      G31f.v[k] += dyf * xf.v[k];
+      B31c.v[k] += dyc;
+      G31c.v[k] += dyc * xc.v[k];
+      df.v[k] = dyf * g1f.v[k];
+      dc.v[k] = dyc * g1c.v[k];
     }
     ln2_bwd<LG>(df, dc, xf, xc, rstd, inv2n, nvalid);
 #pragma unroll
@@ -345,17 +357,40 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
     const Vec4<T> g22 = load4<T>(w.c2_norm_2.g + 4 * q);
     Vec4<T> dg;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dg.v[k] = dz.v[k] * g22.v[k];
+    for (int k = 0; k < 4; ++k) {
+      dg.v[k] = dz.v[k] * g22.v[k];
+      B22.v[k] += dz.v[k];
+      G22.v[k] += dz.v[k] * hat.v[k];
+    }
     ln1_bwd<LG>(dg, hat, rstd2, invn, nvalid);
     Vec4<T> df, dc;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      df.v[k] = dg.v[k] * da.v[k] * gf.v[k];
-      dc.v[k] = dg.v[k] * db.v[k] * gc.v[k];
+      const T dyf = dg.v[k] * da.v[k], dyc = dg.v[k] * db.v[k];
+      B21f.v[k] += dyf;
+      G21f.v[k] += dyf * xf.v[k];
+      B21c.v[k] += dyc;
+      G21c.v[k] += dyc * xc.v[k];
+      df.v[k] = dyf * gf.v[k];
+      dc.v[k] = dyc * gc.v[k];
     }
     ln2_bwd<LG>(df, dc, xf, xc, rstd1, inv2n, nvalid);
     store4(dc2pre + (cerow0 + dst) * (2 * FP) + 4 * q, df);
     store4(dc2pre + (cerow0 + dst) * (2 * FP) + FP + 4 * q, dc);
+  }
+  if (want_param_grads) {  // gw mirrors w: same offsets inside the gradient blob
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.g) + 4 * q, G31f);
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.b) + 4 * q, B31f);
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.g) + FP + 4 * q, G31c);
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.b) + FP + 4 * q, B31c);
+    atomic_add4(const_cast<T *>(gw.c3_norm_2.g) + 4 * q, G32);
+    atomic_add4(const_cast<T *>(gw.c3_norm_2.b) + 4 * q, B32);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.g) + 4 * q, G21f);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.b) + 4 * q, B21f);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.g) + FP + 4 * q, G21c);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.b) + FP + 4 * q, B21c);
+    atomic_add4(const_cast<T *>(gw.c2_norm_2.g) + 4 * q, G22);
+    atomic_add4(const_cast<T *>(gw.c2_norm_2.b) + 4 * q, B22);
   }
 }
 
@@ -402,11 +437,13 @@ template <int LG, typename T>
 __global__ __launch_bounds__(256) void node_bwd_kernel(
     const T *__restrict__ npc1, const T *__restrict__ bc1, const T *__restrict__ node_next,
     const T *__restrict__ dnode_next, T *__restrict__ dnode_prev, T *__restrict__ dbc1,
-    T *__restrict__ dnpc1, int C, int B, Graph g, Dims d, PassW<T> w) {
+    T *__restrict__ dnpc1, int C, int B, Graph g, Dims d, PassW<T> w, PassW<T> gw,
+    int want_param_grads) {
   constexpr int FP = LG * 4;
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
   const int q = threadIdx.x % LG;
   if (gid >= (int64_t)C * g.N) return;
+  Vec4<T> G1f{{0, 0, 0, 0}}, B1f = G1f, G1c = G1f, B1c = G1f, G2 = G1f, B2 = G1f;
   const int c = (int)(gid / g.N), b = (int)(gid % g.N);
   const int s = c / B;
   const int64_t frow = (int64_t)s * g.N + b;
@@ -450,7 +487,11 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(
     Vec4<T> hat = agg;
     const T rstd = ln1_hat<LG>(hat, invn, nvalid);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dagg.v[k] = dz.v[k] * g2.v[k];
+    for (int k = 0; k < 4; ++k) {
+      dagg.v[k] = dz.v[k] * g2.v[k];
+      B2.v[k] += dz.v[k];
+      G2.v[k] += dz.v[k] * hat.v[k];
+    }
     ln1_bwd<LG>(dagg, hat, rstd, invn, nvalid);
   }
   Vec4<T> sf{{0, 0, 0, 0}}, sc{{0, 0, 0, 0}};
@@ -464,8 +505,13 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(
     for (int k = 0; k < 4; ++k) {
       T gv, a, bb;
       gate_grad(xf.v[k] * gf.v[k] + bf.v[k], xc.v[k] * gc.v[k] + bc.v[k], gv, a, bb);
-      df.v[k] = dagg.v[k] * a * gf.v[k];
-      dc.v[k] = dagg.v[k] * bb * gc.v[k];
+      const T dyf = dagg.v[k] * a, dyc = dagg.v[k] * bb;
+      B1f.v[k] += dyf;
+      G1f.v[k] += dyf * xf.v[k];
+      B1c.v[k] += dyc;
+      G1c.v[k] += dyc * xc.v[k];
+      df.v[k] = dyf * gf.v[k];
+      dc.v[k] = dyc * gc.v[k];
     }
     ln2_bwd<LG>(df, dc, xf, xc, rstd, inv2n, nvalid);
     T *o = dbc1 + ((int64_t)c * g.E + e) * (2 * FP) + 4 * q;  // every edge has exactly one b
@@ -479,6 +525,14 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(
   }
   store4(dnpc1 + gid * (2 * FP) + 4 * q, sf);
   store4(dnpc1 + gid * (2 * FP) + FP + 4 * q, sc);
+  if (want_param_grads) {
+    atomic_add4(const_cast<T *>(gw.c1_norm.g) + 4 * q, G1f);
+    atomic_add4(const_cast<T *>(gw.c1_norm.b) + 4 * q, B1f);
+    atomic_add4(const_cast<T *>(gw.c1_norm.g) + FP + 4 * q, G1c);
+    atomic_add4(const_cast<T *>(gw.c1_norm.b) + FP + 4 * q, B1c);
+    atomic_add4(const_cast<T *>(gw.final_norm.g) + 4 * q, G2);
+    atomic_add4(const_cast<T *>(gw.final_norm.b) + 4 * q, B2);
+  }
 }
 
 // =========================================================================== geometry
@@ -539,24 +593,28 @@ template void launch_geom_bwd<double>(const double *, const double *, const doub
 template <typename T>
 void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
                      const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3, T *dc2pre, int C, int B,
-                     const Graph &g, Dims d, const PassW<T> &w, hipStream_t st) {
+                     const Graph &g, Dims d, const PassW<T> &w, const PassW<T> *gw, hipStream_t st) {
   const int lg = d.FeP / 4;
+  const PassW<T> gwv = gw ? *gw : w;
+  const int want = gw ? 1 : 0;
   const int64_t threads = (int64_t)C * g.E * lg;
   if (threads == 0) return;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define CALL(LGV)                                                                                  \
   edge_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(pq, np3, c2pre, edge_next, dedge_next, dedge_prev, \
-                                                  dpq, dnp3, dc2pre, C, B, g, d, w);                \
+                                                  dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want);    \
   q_scatter_kernel<LGV, T><<<blocks, 256, 0, st>>>(dpq, dnp3, C, g)
   RN_LG_SWITCH(d.FeP, CALL)
 #undef CALL
 }
 template void launch_edge_bwd<float>(const float *, const float *, const float *, const float *,
                                      const float *, float *, float *, float *, float *, int, int,
-                                     const Graph &, Dims, const PassW<float> &, hipStream_t);
+                                     const Graph &, Dims, const PassW<float> &, const PassW<float> *,
+                                     hipStream_t);
 template void launch_edge_bwd<double>(const double *, const double *, const double *, const double *,
                                       const double *, double *, double *, double *, double *, int, int,
-                                      const Graph &, Dims, const PassW<double> &, hipStream_t);
+                                      const Graph &, Dims, const PassW<double> &,
+                                      const PassW<double> *, hipStream_t);
 
 template <typename T>
 void launch_prod_bwd(const T *dprod, const T *node, T *dnode, int C, int B, const Graph &g, Dims d,
@@ -577,22 +635,281 @@ template void launch_prod_bwd<double>(const double *, const double *, double *, 
 template <typename T>
 void launch_node_bwd(const T *npc1, const T *bc1, const T *node_next, const T *dnode_next,
                      T *dnode_prev, T *dbc1, T *dnpc1, int C, int B, const Graph &g, Dims d,
-                     const PassW<T> &w, hipStream_t st) {
+                     const PassW<T> &w, const PassW<T> *gw, hipStream_t st) {
   const int lg = d.FnP / 4;
+  const PassW<T> gwv = gw ? *gw : w;
+  const int want = gw ? 1 : 0;
   const int64_t threads = (int64_t)C * g.N * lg;
   if (threads == 0) return;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define CALL(LGV)                                                                                 \
   node_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(npc1, bc1, node_next, dnode_next, dnode_prev, dbc1, \
-                                                  dnpc1, C, B, g, d, w)
+                                                  dnpc1, C, B, g, d, w, gwv, want)
   RN_LG_SWITCH(d.FnP, CALL)
 #undef CALL
 }
 template void launch_node_bwd<float>(const float *, const float *, const float *, const float *,
                                      float *, float *, float *, int, int, const Graph &, Dims,
-                                     const PassW<float> &, hipStream_t);
+                                     const PassW<float> &, const PassW<float> *, hipStream_t);
 template void launch_node_bwd<double>(const double *, const double *, const double *, const double *,
                                       double *, double *, double *, int, int, const Graph &, Dims,
-                                      const PassW<double> &, hipStream_t);
+                                      const PassW<double> &, const PassW<double> *, hipStream_t);
+
+}  // namespace rn
+
+// ================================================================================ training
+// Weight-gradient and BatchNorm(train) pieces (correctness-first; config 5 of BASELINE.json).
+namespace rn {
+
+// dWT[k][n] += sum_r X[r][k] * dY[r][n]   (WT = the forward's [K][N] layout), plus optional
+// column sums of dY (bias gradient).  amode 1: X row r = node[b_e] * node[a_e] (c2 operand).
+// One thread per (k, n) and row chunk; partial sums meet in global atomics.
+template <typename T>
+__global__ void gemm_tn_kernel(const T *__restrict__ X, int ldx, const T *__restrict__ dY, int ldy,
+                               int64_t R, int K, int N, T *__restrict__ dWT, int ldw,
+                               T *__restrict__ dbias, int amode, const T *__restrict__ node, Graph g,
+                               int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < K * N; idx += gridDim.x * blockDim.x) {
+    const int k = idx / N, n = idx % N;
+    T acc = 0, bsum = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+      T x;
+      if (amode == 0) {
+        x = X[r * ldx + k];
+      } else {
+        const int64_t s = r / g.E;
+        const int e = (int)(r % g.E);
+        x = node[(s * g.N + g.edge_b[e]) * ldx + k] * node[(s * g.N + g.edge_a[e]) * ldx + k];
+      }
+      const T dy = dY[r * ldy + n];
+      acc += x * dy;
+      bsum += dy;
+    }
+    atomicAdd(dWT + (int64_t)k * ldw + n, acc);
+    if (dbias && k == 0) atomicAdd(dbias + n, bsum);
+  }
+}
+template <typename T>
+void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
+                    int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st) {
+  if (R == 0) return;
+  const int rows_per_block = 512;
+  dim3 grid((unsigned)((K * N + 255) / 256), (unsigned)((R + rows_per_block - 1) / rows_per_block));
+  if (grid.x > 64) grid.x = 64;
+  gemm_tn_kernel<T><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g,
+                                          rows_per_block);
+}
+template void launch_gemm_tn<float>(const float *, int, const float *, int, int64_t, int, int,
+                                    float *, int, float *, int, const float *, const Graph &,
+                                    hipStream_t);
+template void launch_gemm_tn<double>(const double *, int, const double *, int, int64_t, int, int,
+                                     double *, int, double *, int, const double *, const Graph &,
+                                     hipStream_t);
+
+// ---- BatchNorm1d in training mode over all R rows (_gnn.py:534; batch statistics)
+// stats[c] = sum z, stats[W + c] = sum z^2 (float64 accumulators)
+template <typename T>
+__global__ void col_sums_kernel(const T *__restrict__ z, int64_t R, int W, double *__restrict__ stats,
+                                int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  for (int c = threadIdx.x; c < W; c += blockDim.x) {
+    double s = 0, q = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+      const double v = (double)z[r * W + c];
+      s += v;
+      q += v * v;
+    }
+    atomicAdd(stats + c, s);
+    atomicAdd(stats + W + c, q);
+  }
+}
+// h = ssp(gamma * (z - mean) * rstd + beta);  mean/rstd derived from the sums; also writes
+// batch mean and biased variance (for the running-statistics update) into mv[0:W], mv[W:2W].
+template <typename T>
+__global__ void bn_train_fwd_kernel(const T *__restrict__ z, int64_t R, int W, int F,
+                                    const double *__restrict__ stats, const T *__restrict__ gamma,
+                                    const T *__restrict__ beta, T *__restrict__ h,
+                                    T *__restrict__ mv) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * W) return;
+  const int c = (int)(idx % W);
+  T out = 0;
+  if (c < F) {
+    const double mean = stats[c] / (double)R;
+    double var = stats[W + c] / (double)R - mean * mean;
+    var = var > 0 ? var : 0;
+    const T rstd = (T)(1.0 / sqrt(var + 1e-5));
+    out = ssp(gamma[c] * ((z[idx] - (T)mean) * rstd) + beta[c]);
+    if (idx < W) {
+      mv[c] = (T)mean;
+      mv[W + c] = (T)var;
+    }
+  }
+  h[idx] = out;
+}
+// BatchNorm backward.  dy (cotangent of the BN output, i.e. already through ssp') in `d`:
+//   pass 1 (bn_bwd_sums): sums[c] = sum dy, sums[W+c] = sum dy * zhat      (also = dbeta, dgamma)
+//   pass 2 (bn_bwd_apply): d <- gamma * rstd * (dy - mean(dy) - zhat * mean(dy zhat))
+template <typename T>
+__global__ void bn_bwd_sums_kernel(const T *__restrict__ dy, const T *__restrict__ z, int64_t R, int W,
+                                   int F, const double *__restrict__ stats, double *__restrict__ sums,
+                                   int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  for (int c = threadIdx.x; c < F; c += blockDim.x) {
+    const double mean = stats[c] / (double)R;
+    double var = stats[W + c] / (double)R - mean * mean;
+    var = var > 0 ? var : 0;
+    const double rstd = 1.0 / sqrt(var + 1e-5);
+    double a = 0, b = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+      const double g = (double)dy[r * W + c];
+      a += g;
+      b += g * ((double)z[r * W + c] - mean) * rstd;
+    }
+    atomicAdd(sums + c, a);
+    atomicAdd(sums + W + c, b);
+  }
+}
+template <typename T>
+__global__ void bn_bwd_apply_kernel(T *__restrict__ d, const T *__restrict__ z, int64_t R, int W, int F,
+                                    const double *__restrict__ stats, const double *__restrict__ sums,
+                                    const T *__restrict__ gamma, T *__restrict__ dgamma,
+                                    T *__restrict__ dbeta) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * W) return;
+  const int c = (int)(idx % W);
+  if (c >= F) {
+    d[idx] = 0;
+    return;
+  }
+  const double mean = stats[c] / (double)R;
+  double var = stats[W + c] / (double)R - mean * mean;
+  var = var > 0 ? var : 0;
+  const double rstd = 1.0 / sqrt(var + 1e-5);
+  const double zhat = ((double)z[idx] - mean) * rstd;
+  const double ma = sums[c] / (double)R, mb = sums[W + c] / (double)R;
+  d[idx] = (T)((double)gamma[c] * rstd * ((double)d[idx] - ma - zhat * mb));
+  if (idx < W) {
+    dbeta[c] += (T)sums[c];
+    dgamma[c] += (T)sums[W + c];
+  }
+}
+
+template <typename T>
+void launch_bn_train_fwd(const T *z, int64_t R, int W, int F, double *stats, const T *gamma,
+                         const T *beta, T *h, T *mv, hipStream_t st) {
+  if (R == 0) return;
+  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * W, st);
+  const int rpb = 256;
+  col_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(z, R, W, stats, rpb);
+  bn_train_fwd_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(z, R, W, F, stats, gamma, beta,
+                                                                          h, mv);
+}
+template <typename T>
+void launch_bn_train_bwd(T *d, const T *z, int64_t R, int W, int F, const double *stats, double *sums,
+                         const T *gamma, T *dgamma, T *dbeta, hipStream_t st) {
+  if (R == 0) return;
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * W, st);
+  const int rpb = 256;
+  bn_bwd_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(d, z, R, W, F, stats, sums, rpb);
+  bn_bwd_apply_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(d, z, R, W, F, stats, sums,
+                                                                          gamma, dgamma, dbeta);
+}
+template void launch_bn_train_fwd<float>(const float *, int64_t, int, int, double *, const float *,
+                                         const float *, float *, float *, hipStream_t);
+template void launch_bn_train_fwd<double>(const double *, int64_t, int, int, double *, const double *,
+                                          const double *, double *, double *, hipStream_t);
+template void launch_bn_train_bwd<double>(double *, const double *, int64_t, int, int, const double *,
+                                          double *, const double *, double *, double *, hipStream_t);
+template void launch_bn_train_bwd<float>(float *, const float *, int64_t, int, int, const double *,
+                                         double *, const float *, float *, float *, hipStream_t);
+
+// ---- node embedding MLP (Embedding -> ssp -> Linear -> ssp -> Linear, _gnn.py:508-514):
+// gradient of the K x Fn table rows w.r.t. emb, W2, b2, W4, b4.  dnode0 [S*N, FnP] is first
+// summed per atom type.  One workgroup; K and Fn are tiny.
+template <typename T>
+__global__ void node_embed_bwd_kernel(const T *__restrict__ dnode0, int S, Graph g, Dims d, int K,
+                                      const T *__restrict__ emb, const T *__restrict__ W2,
+                                      const T *__restrict__ b2, const T *__restrict__ W4,
+                                      T *__restrict__ demb, T *__restrict__ dW2, T *__restrict__ db2,
+                                      T *__restrict__ dW4, T *__restrict__ db4) {
+  extern __shared__ unsigned char smem_raw[];
+  const int Fn = d.Fn;
+  T *dt = reinterpret_cast<T *>(smem_raw);  // [K*Fn] d table
+  T *a1 = dt + K * Fn;                      // ssp(emb)
+  T *z2 = a1 + K * Fn;                      // pre-activation of the first Linear
+  T *dz2 = z2 + K * Fn;
+  for (int i = threadIdx.x; i < K * Fn; i += blockDim.x) {
+    const int k = i / Fn, o = i % Fn;
+    T s = 0;
+    for (int64_t r = 0; r < (int64_t)S * g.N; ++r)
+      if (g.atom_type[r % g.N] == k) s += dnode0[r * d.FnP + o];
+    dt[i] = s;
+    a1[i] = ssp(emb[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * Fn; i += blockDim.x) {
+    const int k = i / Fn, o = i % Fn;
+    T acc = b2[o];
+    for (int c = 0; c < Fn; ++c) acc += a1[k * Fn + c] * W2[o * Fn + c];
+    z2[i] = acc;
+  }
+  __syncthreads();
+  // table = W4 ssp(z2) + b4
+  for (int i = threadIdx.x; i < Fn * Fn; i += blockDim.x) {
+    const int o = i / Fn, c = i % Fn;
+    T acc = 0;
+    for (int k = 0; k < K; ++k) acc += dt[k * Fn + o] * ssp(z2[k * Fn + c]);
+    dW4[i] += acc;
+  }
+  for (int o = threadIdx.x; o < Fn; o += blockDim.x) {
+    T acc = 0;
+    for (int k = 0; k < K; ++k) acc += dt[k * Fn + o];
+    db4[o] += acc;
+  }
+  for (int i = threadIdx.x; i < K * Fn; i += blockDim.x) {
+    const int k = i / Fn, c = i % Fn;
+    T acc = 0;
+    for (int o = 0; o < Fn; ++o) acc += dt[k * Fn + o] * W4[o * Fn + c];
+    dz2[i] = acc * sigmoid_acc(z2[i]);  // ssp' = sigmoid
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Fn * Fn; i += blockDim.x) {
+    const int o = i / Fn, c = i % Fn;
+    T acc = 0;
+    for (int k = 0; k < K; ++k) acc += dz2[k * Fn + o] * a1[k * Fn + c];
+    dW2[i] += acc;
+  }
+  for (int o = threadIdx.x; o < Fn; o += blockDim.x) {
+    T acc = 0;
+    for (int k = 0; k < K; ++k) acc += dz2[k * Fn + o];
+    db2[o] += acc;
+  }
+  for (int i = threadIdx.x; i < K * Fn; i += blockDim.x) {
+    const int k = i / Fn, c = i % Fn;
+    T acc = 0;
+    for (int o = 0; o < Fn; ++o) acc += dz2[k * Fn + o] * W2[o * Fn + c];
+    demb[i] += acc * sigmoid_acc(emb[i]);
+  }
+}
+template <typename T>
+void launch_node_embed_bwd(const T *dnode0, int S, const Graph &g, Dims d, int K, const T *emb,
+                           const T *W2, const T *b2, const T *W4, T *demb, T *dW2, T *db2, T *dW4,
+                           T *db4, hipStream_t st) {
+  const size_t lds = (size_t)4 * K * d.Fn * sizeof(T);
+  node_embed_bwd_kernel<T><<<1, 256, lds, st>>>(dnode0, S, g, d, K, emb, W2, b2, W4, demb, dW2, db2, dW4,
+                                                db4);
+}
+template void launch_node_embed_bwd<float>(const float *, int, const Graph &, Dims, int, const float *,
+                                           const float *, const float *, const float *, float *,
+                                           float *, float *, float *, float *, hipStream_t);
+template void launch_node_embed_bwd<double>(const double *, int, const Graph &, Dims, int,
+                                            const double *, const double *, const double *,
+                                            const double *, double *, double *, double *, double *,
+                                            double *, hipStream_t);
 
 }  // namespace rn

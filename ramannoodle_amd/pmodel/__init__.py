@@ -5,4 +5,7 @@ from ramannoodle_amd.pmodel.potgnn import (  # noqa: F401
     polarizability_vectors_to_tensors,
 )
 
-__all__ = ["PotGNN", "polarizability_vectors_to_tensors", "polarizability_tensors_to_vectors"]
+from ramannoodle_amd.pmodel.train import train_single_epoch  # noqa: F401
+
+__all__ = ["PotGNN", "train_single_epoch", "polarizability_vectors_to_tensors",
+           "polarizability_tensors_to_vectors"]

@@ -124,9 +124,14 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         add("_to_polarizability_embedding.1", torch.nn.BatchNorm1d(fe))
         add("_to_polarizability_embedding.3", torch.nn.Linear(fe, fe))
         add("_to_polarizability_embedding.5", torch.nn.Linear(fe, 12))
-        self._state = state
+        # trainable entries become torch Parameters (so torch.optim works on them); buffers
+        # (Gaussian offsets, BatchNorm running statistics) stay plain tensors
+        self._state = OrderedDict(
+            (k, torch.nn.Parameter(v) if self._is_trainable(k) else v) for k, v in state.items())
         self._handle = None
         self._profiling = 0
+        self._uploaded_version = None
+        self.training = True  # like a fresh torch Module; calc_polarizabilities switches to eval
 
     # ------------------------------------------------------------------ properties
     @property
@@ -151,9 +156,26 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         return self._gauss_coefficient
 
     # ------------------------------------------------------------------ parameters
+    _BUFFER_SUFFIXES = ("_edge_embedding.offset", "running_mean", "running_var", "num_batches_tracked")
+
+    @classmethod
+    def _is_trainable(cls, key: str) -> bool:
+        return not key.endswith(cls._BUFFER_SUFFIXES)
+
+    def parameters(self):
+        """Trainable parameters (``torch.nn.Parameter``), in ``state_dict`` order."""
+        return [v for k, v in self._state.items() if self._is_trainable(k)]
+
+    def named_parameters(self):
+        return [(k, v) for k, v in self._state.items() if self._is_trainable(k)]
+
+    def zero_grad(self) -> None:
+        for p in self.parameters():
+            p.grad = None
+
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         """Same keys, shapes and order as the reference's ``state_dict()``."""
-        return OrderedDict((k, v.clone()) for k, v in self._state.items())
+        return OrderedDict((k, v.detach().clone()) for k, v in self._state.items())
 
     def load_state_dict(self, state) -> None:
         """Load parameters (torch tensors or numpy arrays); keys and shapes must match."""
@@ -169,27 +191,57 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
                 raise RuntimeError(f"size mismatch for {key}: {tuple(value.shape)} != "
                                    f"{tuple(old.shape)}")
             new[key] = value.to(old.dtype).clone()
-        self._state = new
-        self._release()
+        with torch.no_grad():  # in place: Parameter objects (and optimisers holding them) stay valid
+            for key, value in new.items():
+                self._state[key].copy_(value)
 
     def eval(self) -> "PotGNN":
-        """Evaluation mode is the only mode of this implementation."""
+        """Evaluation mode: BatchNorm uses its running statistics."""
+        self.training = False
         return self
 
     def train(self, mode: bool = True) -> "PotGNN":
-        if mode:
-            raise NotImplementedError("training (batch-statistics BatchNorm, backward) is not "
-                                      "part of the device evaluation path yet")
+        """Training mode: ``forward`` records a tape, BatchNorm uses batch statistics and
+        the returned tensor back-propagates into ``parameters()``."""
+        self.training = bool(mode)
         return self
+
+    def apply(self, fn):
+        """``torch.nn.Module.apply`` stand-in for the notebook's weight initialisers: ``fn``
+        is called with light-weight views that look like the Linear / Embedding modules."""
+        for prefix, kind in self._module_kinds():
+            fn(_ModuleView(self._state, prefix, kind))
+        return self
+
+    def _module_kinds(self):
+        out = [("_node_embedding.0", torch.nn.Embedding), ("_node_embedding.2", torch.nn.Linear),
+               ("_node_embedding.4", torch.nn.Linear)]
+        for p in range(self._passes):
+            out.append((f"_node_blocks.{p}.c1_linear", torch.nn.Linear))
+        for p in range(self._passes):
+            out += [(f"_edge_blocks.{p}.c2_linear", torch.nn.Linear),
+                    (f"_edge_blocks.{p}.c3_linear", torch.nn.Linear)]
+        out += [("_to_polarizability_embedding.0", torch.nn.Linear),
+                ("_to_polarizability_embedding.3", torch.nn.Linear),
+                ("_to_polarizability_embedding.5", torch.nn.Linear)]
+        return out
 
     # ------------------------------------------------------------------ device handle
     def _weights_blob(self) -> np.ndarray:
-        parts = [v.numpy().astype(np.float32).ravel() for v in self._state.values()
+        parts = [v.detach().numpy().astype(np.float32).ravel() for v in self._state.values()
                  if v.is_floating_point()]
         return np.ascontiguousarray(np.concatenate(parts))
 
+    def _version(self) -> int:
+        return sum(int(v._version) for v in self._state.values())  # bumped by in-place updates
+
     def _ensure_handle(self):
         if self._handle is not None:
+            if self._uploaded_version != self._version():  # e.g. after optimizer.step()
+                blob = self._weights_blob()
+                rc = _lib.load().rn_potgnn_set_weights(self._handle, _ptr(blob), blob.size)
+                _lib.check(rc, self._handle, "rn_potgnn_set_weights")
+                self._uploaded_version = self._version()
             return self._handle
         lib = _lib.load()
         device = self._device
@@ -214,6 +266,7 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
                                   C.byref(handle))
         _lib.check(rc, None, "rn_potgnn_create")
         self._handle = handle
+        self._uploaded_version = self._version()
         if self._profiling:
             lib.rn_potgnn_set_profiling(handle, self._profiling)
         return handle
@@ -238,6 +291,7 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         """Polarizabilities ``(S,3,3)`` for fractional positions ``(S,N,3)``
         (``_gnn.py:667-721``): host arrays in, host arrays out."""
         pos = self._check_positions(positions_batch)
+        self.eval()  # as the reference does (_gnn.py:686)
         out = np.empty((pos.shape[0], 3, 3), dtype=np.float64)
         handle = self._ensure_handle()
         rc = _lib.load().rn_potgnn_calc_polarizabilities(handle, _ptr(pos), pos.shape[0], _ptr(out))
@@ -280,11 +334,50 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
                     np.asarray(self._ref_structure.atomic_numbers), zs.shape))):
             raise NotImplementedError("per-sample lattices / species that differ from the "
                                       "reference structure are not supported")
+        if self.training:
+            return _TrainStep.apply(self, pos, *self.parameters())
         out = np.empty((pos.shape[0], 6), dtype=np.float32)
         handle = self._ensure_handle()
         rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), pos.shape[0], _ptr(out))
         _lib.check(rc, handle, "rn_potgnn_forward")
         return torch.from_numpy(out)
+
+    # -- training step pieces used by _TrainStep ------------------------------------------
+    def _train_forward(self, pos: np.ndarray) -> np.ndarray:
+        handle = self._ensure_handle()
+        out = np.empty((pos.shape[0], 6), dtype=np.float32)
+        mean = np.empty(self._fe, dtype=np.float32)
+        var = np.empty(self._fe, dtype=np.float32)
+        rc = _lib.load().rn_potgnn_train_forward(handle, _ptr(pos), pos.shape[0], _ptr(out),
+                                                 _ptr(mean), _ptr(var))
+        _lib.check(rc, handle, "rn_potgnn_train_forward")
+        # BatchNorm1d running statistics, torch semantics (momentum 0.1, unbiased variance)
+        rows = pos.shape[0] * self.num_edges
+        pre = "_to_polarizability_embedding.1."
+        with torch.no_grad():
+            self._state[pre + "running_mean"].mul_(0.9).add_(torch.from_numpy(mean) * 0.1)
+            unbiased = torch.from_numpy(var) * (rows / max(rows - 1, 1))
+            self._state[pre + "running_var"].mul_(0.9).add_(unbiased * 0.1)
+            self._state[pre + "num_batches_tracked"].add_(1)
+        self._uploaded_version = None  # buffers changed: re-upload before the next evaluation
+        return out
+
+    def _train_backward(self, dvec6: np.ndarray):
+        handle = self._handle
+        lib = _lib.load()
+        blob = np.empty(sum(v.numel() for v in self._state.values() if v.is_floating_point()),
+                        dtype=np.float32)
+        rc = lib.rn_potgnn_train_backward(handle, _ptr(dvec6), _ptr(blob))
+        _lib.check(rc, handle, "rn_potgnn_train_backward")
+        grads, offset = [], 0
+        for key, value in self._state.items():
+            if not value.is_floating_point():
+                continue
+            n = value.numel()
+            if self._is_trainable(key):
+                grads.append(torch.from_numpy(blob[offset:offset + n].reshape(tuple(value.shape)).copy()))
+            offset += n
+        return grads
 
     __call__ = forward
 
@@ -382,3 +475,35 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         launches = (C.c_int64 * 16)()
         n = lib.rn_potgnn_kernel_times(handle, names, ms, launches, 16)
         return {names[i].decode(): (ms[i], launches[i]) for i in range(max(n, 0))}
+
+
+class _ModuleView:
+    """What ``model.apply(fn)`` hands to ``fn``: ``isinstance(view, torch.nn.Linear)`` style
+    checks are answered through ``__class__`` and ``weight`` / ``bias`` are the model's own
+    Parameters, so ``torch.nn.init.*_(view.weight)`` initialises the model in place."""
+
+    def __init__(self, state, prefix, kind):
+        self._kind = kind
+        self.weight = state[prefix + ".weight"]
+        self.bias = state.get(prefix + ".bias")
+
+    @property
+    def __class__(self):  # noqa: D401 - makes isinstance(view, torch.nn.Linear) true
+        return self._kind
+
+
+class _TrainStep(torch.autograd.Function):
+    """``PotGNN.forward`` in training mode: forward and backward both run on the device
+    (``rn_potgnn_train_forward`` / ``rn_potgnn_train_backward``); autograd only routes the
+    parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, model, pos, *params):  # pylint: disable=arguments-differ
+        ctx.model = model
+        return torch.from_numpy(model._train_forward(pos))
+
+    @staticmethod
+    def backward(ctx, grad_out):  # pylint: disable=arguments-differ
+        dvec6 = np.ascontiguousarray(grad_out.detach().cpu().numpy(), dtype=np.float32)
+        grads = ctx.model._train_backward(dvec6)
+        return (None, None, *grads)

@@ -232,6 +232,43 @@ def phonon_md_extras(data, rng, ref, model, model64):
     data["md/int_corr"] = i1
 
 
+def train_step_extras(data, rng, ref, model, model64):
+    """One optimisation step's forward/backward through the REFERENCE in train mode
+    (batch-statistics BatchNorm): outputs, loss, every parameter gradient, running stats."""
+    import copy
+    m = copy.deepcopy(model)
+    m.train()
+    s = 4
+    pos = data["pos_batch"][:s]
+    target = torch.tensor(rng.normal(size=(s, 6)), dtype=torch.float32)
+    lat = torch.tensor(ref.lattice, dtype=torch.float32).unsqueeze(0).expand(s, -1, -1)
+    zz = torch.tensor(ref.atomic_numbers, dtype=torch.int).unsqueeze(0).expand(s, -1)
+    out = m.forward(lat, zz, torch.tensor(pos, dtype=torch.float32))
+    loss = torch.nn.MSELoss()(out, target)
+    loss.backward()
+    data["train/target"] = target.numpy()
+    data["train/out"] = out.detach().numpy()
+    data["train/loss"] = np.float64(loss.item())
+    for k, p in m.named_parameters():
+        data["train/grad/" + k] = p.grad.detach().numpy().copy()
+    bn = m._to_polarizability_embedding[1]
+    data["train/running_mean"] = bn.running_mean.numpy().copy()
+    data["train/running_var"] = bn.running_var.numpy().copy()
+    # the reference's dataset class on random polarizabilities
+    from ramannoodle.dataset.torch import PolarizabilityDataset
+    alpha = rng.normal(size=(7, 3, 3))
+    alpha = alpha + np.swapaxes(alpha, 1, 2) + np.diag([30.0, 31.0, 29.0])
+    ds = PolarizabilityDataset(ref.lattice, ref.atomic_numbers, data["pos_batch"][:1].repeat(7, 0), alpha)
+    data["ds/alpha"] = alpha
+    data["ds/scaled"] = ds.scaled_polarizabilities
+    data["ds/mean"] = ds.mean_polarizability
+    data["ds/std"] = ds.stddev_polarizability
+    item = ds[3]
+    data["ds/item3_target"] = item[3].numpy()
+    ds.scale_polarizabilities(data["mean"], data["std"])
+    data["ds/rescaled"] = ds.scaled_polarizabilities
+
+
 def main():
     parity = dict(cutoff=2.0, fn=5, fe=14, passes=4, g0=0.0, g1=5.0)
     all_stages = ["unit", "dist", "node0", "edge0"] + [
@@ -259,6 +296,15 @@ def main():
     keep = ["unit", "dist", "node0", "edge0", "node1", "edge1", "node2", "edge2", "pol_emb"]
     make_case("triclinic20", lat, pos, zs, hp, seed=404, style="soft", s=5, keep=keep,
               extras=phonon_md_extras)
+
+    # C'. the same model through one training step of the reference (gradients of all weights)
+    def both(data, rng_, ref_, model_, model64_):
+        train_step_extras(data, rng_, ref_, model_, model64_)
+    hp2 = dict(cutoff=3.0, fn=8, fe=12, passes=2, g0=0.0, g1=4.0)
+    rng2 = np.random.default_rng(404)
+    lat2, pos2, zs2 = triclinic(rng2)
+    make_case("triclinic20_train", lat2, pos2, zs2, hp2, seed=404, style="soft", s=5, keep=[],
+              extras=both)
 
     # D. sub-batch boundary: S=205 frames through calc_polarizabilities (100-frame chunks).
     lat, pos, zs = rocksalt(2, 2, 2)
