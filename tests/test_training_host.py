@@ -19,8 +19,9 @@ def test_oracle_training_step_matches_reference():
     assert set(names) == set(grads)
     for k in names:
         ref = g["train/grad/" + k]
-        # fp32 accumulation order differs (lean vs materialised data flow): 2e-4 of the tensor's scale
-        np.testing.assert_allclose(grads[k], ref, rtol=0, atol=2e-4 * np.abs(ref).max() + 1e-7,
+        # fp32 accumulation order differs (lean vs materialised data flow): 2e-4 of the tensor's scale;
+        # 1e-6 floor: the bias in front of BatchNorm has an exactly-zero gradient (pure round-off)
+        np.testing.assert_allclose(grads[k], ref, rtol=0, atol=2e-4 * np.abs(ref).max() + 1e-6,
                                    err_msg=k)
 
 
