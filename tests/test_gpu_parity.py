@@ -50,6 +50,7 @@ def test_stages_match_reference(golden, staged):
     s = pos.shape[0]
     lat = torch.tensor(g["lattice"]).expand(s, 3, 3)
     zs = torch.tensor(g["atomic_numbers"]).expand(s, -1)
+    model.eval()  # a fresh model is in training mode, like a torch Module
     out = model.forward(lat, zs, torch.tensor(pos)).numpy()
     n, e = model.num_atoms, model.num_edges
     if "f32/unit" in g.files:
