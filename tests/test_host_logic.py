@@ -276,3 +276,39 @@ def test_apply_pbc():
     np.testing.assert_allclose(apply_pbc(x), [[0.75, 0.5, 0.0]])
     with pytest.raises(TypeError):
         apply_pbc("nope")
+
+
+def test_parameters_apply_and_modes():
+    """torch-facing surface of the model shell: Parameters for torch.optim, the notebook's
+    `model.apply(init_fn)` idiom (machine-learning.ipynb:198-206), train/eval flags."""
+    model = product_model_from_golden(load_golden("triclinic20"))
+    params = model.parameters()
+    assert all(isinstance(p, torch.nn.Parameter) for p in params)
+    assert sum(p.numel() for p in params) == 4500  # the reference's parameter count for this model
+    names = [k for k, _ in model.named_parameters()]
+    assert "_edge_embedding.offset" not in names and "_to_polarizability_embedding.1.running_mean" not in names
+
+    def init_biases(m):
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.uniform_(m.bias, -0.5, 0.5)
+
+    def init_weights(m):
+        if isinstance(m, torch.nn.Linear) or isinstance(m, torch.nn.Embedding):
+            torch.nn.init.normal_(m.weight, mean=0, std=1)
+
+    before = model.state_dict()
+    torch.manual_seed(1)
+    model.apply(init_biases).apply(init_weights)
+    after = model.state_dict()
+    assert not torch.equal(before["_node_embedding.0.weight"], after["_node_embedding.0.weight"])
+    assert not torch.equal(before["_edge_blocks.1.c3_linear.bias"], after["_edge_blocks.1.c3_linear.bias"])
+    assert torch.equal(before["_node_blocks.0.c1_norm.weight"], after["_node_blocks.0.c1_norm.weight"])
+    assert float(after["_to_polarizability_embedding.5.bias"].abs().max()) <= 0.5
+    # load_state_dict keeps the Parameter objects (optimisers stay valid)
+    model.load_state_dict(before)
+    assert all(a is b for a, b in zip(params, model.parameters()))
+    assert model.training and not model.eval().training and model.train().training
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    model.parameters()[0].grad = torch.ones_like(model.parameters()[0])
+    opt.step()
+    assert not torch.equal(model.state_dict()["_node_embedding.0.weight"], before["_node_embedding.0.weight"])
