@@ -83,9 +83,10 @@ struct PackedLayout {
     size_t c1_WnT, c1_WeT, c1_bias, c1n_g, c1n_b, fin_g, fin_b;
     size_t c2_WT, c2_bias, c2n1_g, c2n1_b, c2n2_g, c2n2_b;
     size_t c3_WnT, c3_nshift, c3_WeT, c3n1_g, c3n1_b, c3n2_g, c3n2_b;
+    size_t t_c3We, t_c3Wn, t_c2W, t_c1We, t_c1Wn;  // transposed copies [N][K] (reverse pass)
   };
   std::vector<Pass> pass;
-  size_t W0T, W3T, b3, W5T, b5, ones, b0p;
+  size_t W0T, W3T, b3, W5T, b5, ones, b0p, t_W0, t_W3, t_W5;
   // device-computed
   size_t node_table, scale0, shift0;
   size_t total = 0;
@@ -115,9 +116,9 @@ struct Precision {
   // stage snapshots (debug)
   std::vector<DeviceBuf> snap_node, snap_edge;
   // forward tape + cotangent workspace of the reverse pass (Jacobian d alpha / d r)
-  std::vector<DeviceBuf> tape_node, tape_edge;
+  std::vector<DeviceBuf> tape_node, tape_edge, tape_agg;
   DeviceBuf bw[17];
-  DeviceBuf tape_z1, bn_stats, grad;  // training: pre-BatchNorm activations, batch sums, gradient blob
+  DeviceBuf tape_z1, bn_stats, grad, seeds, mv;  // training: pre-BatchNorm activations, batch sums, gradient blob
   bool tape_on = false;
 };
 
@@ -212,6 +213,11 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3n1_b = L.take(2 * FeP);
     p.c3n2_g = L.take(FeP);
     p.c3n2_b = L.take(FeP);
+    p.t_c3We = L.take((size_t)4 * FeP * FeP);
+    p.t_c3Wn = L.take((size_t)6 * FeP * FnP);
+    p.t_c2W = L.take((size_t)2 * FeP * FnP);
+    p.t_c1We = L.take((size_t)2 * FnP * FeP);
+    p.t_c1Wn = L.take((size_t)2 * FnP * FnP);
   }
   const int HP = std::max(FeP, 32);  // readout hidden width: projections emit 32-column tiles
   L.W0T = L.take((size_t)FeP * HP);
@@ -226,6 +232,9 @@ void pack_weights(rn_potgnn *h, const float *w) {
   L.b5 = L.take(32);
   L.ones = L.take(HP);
   L.b0p = L.take(HP);  // bias of readout Linear 0, padded (training-mode forward)
+  L.t_W0 = L.take((size_t)HP * FeP);
+  L.t_W3 = L.take((size_t)HP * HP);
+  L.t_W5 = L.take((size_t)32 * HP);
   L.node_table = L.take((size_t)K * FnP);
   L.scale0 = L.take(HP);
   L.shift0 = L.take(HP);
@@ -324,6 +333,21 @@ void pack_weights(rn_potgnn *h, const float *w) {
     copy(L.b5, 12);
   }
   for (int i = 0; i < HP; ++i) o[L.ones + i] = 1.0f;
+  // transposed copies: src [K][N] (row stride N) -> dst [N][K]
+  auto transpose = [&](size_t src, int Kd, int Nd, size_t dst) {
+    for (int k = 0; k < Kd; ++k)
+      for (int n = 0; n < Nd; ++n) o[dst + (size_t)n * Kd + k] = o[src + (size_t)k * Nd + n];
+  };
+  for (auto &q : L.pass) {
+    transpose(q.c3_WeT, FeP, 4 * FeP, q.t_c3We);
+    transpose(q.c3_WnT, FnP, 6 * FeP, q.t_c3Wn);
+    transpose(q.c2_WT, FnP, 2 * FeP, q.t_c2W);
+    transpose(q.c1_WeT, FeP, 2 * FnP, q.t_c1We);
+    transpose(q.c1_WnT, FnP, 2 * FnP, q.t_c1Wn);
+  }
+  transpose(L.W0T, FeP, HP, L.t_W0);
+  transpose(L.W3T, HP, HP, L.t_W3);
+  transpose(L.W5T, HP, 32, L.t_W5);
 }
 
 template <typename T>
@@ -579,9 +603,9 @@ struct ChunkRun {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
         if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, st());
-        else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, st());
+        else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
-        launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, st());
+        launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       }
     }
     cur = nxt;
@@ -609,7 +633,11 @@ struct ChunkRun {
     }
     HIP_TRY(hipGetLastError());
   }
-  bool fused() const { return sizeof(T) == 4 && h->use_fused; }
+  bool fused() const { return sizeof(T) == 4 && h->use_fused && !prec<T>(h).tape_on; }
+  T *tape_agg(int p) {  // where the EdgeBlock's pre-LayerNorm sums are recorded (taped runs only)
+    Precision<T> &P = prec<T>(h);
+    return P.tape_on ? P.tape_agg[p].template as<T>() : nullptr;
+  }
 };
 
 template <typename T>
@@ -732,6 +760,15 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   T *bufA = c.bufA, *bufB = c.bufB, *unit4 = c.unit4;
   T *G = rv.grad;
   T *Wd = P.weights.template as<T>();
+  // dX[R, K] (+)= dY[R, N] * W^T with W = the forward's [K][N] matrix at `w_off`, its
+  // transposed copy at `t_off`: MFMA projection kernel in float32, simple kernel otherwise
+  auto back_gemm = [&](const T *dY, int64_t R, int N, size_t w_off, size_t t_off, int K, T *dX,
+                       bool accumulate) {
+    if constexpr (sizeof(T) == 4) {
+      if (launch_rowgemm_blocks(dY, N, N, R, Wd + t_off, K, dX, accumulate, g, st)) return;
+    }
+    launch_gemm_nt<T>(dY, R, N, Wd + w_off, N, K, dX, accumulate, st);
+  };
 
   // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
   const T *edgeP = P.tape_edge[NP].template as<T>();
@@ -745,10 +782,10 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   launch_rowgemm<T>(bufB, fe, HP, P.ro.W5T, 32, b[POL], nullptr, P.ro.b5, false, 0, nullptr, g, st);
   launch_readout_bwd<T>(rv.d_dout6, b[POL], unit4, C, B, g, b[DPOL], b[DUNIT], st);
   if (G) launch_gemm_tn<T>(bufB, HP, b[DPOL], 32, ce, HP, 32, G + L.W5T, 32, G + L.b5, 0, nullptr, g, st);
-  launch_gemm_nt<T>(b[DPOL], ce, 32, P.ro.W5T, 32, HP, b[DH], false, st);          // d h2
+  back_gemm(b[DPOL], ce, 32, L.W5T, L.t_W5, HP, b[DH], false);                     // d h2
   launch_ssp_bwd<T>(b[DH], bufB, nullptr, E, HP, C, B, st);                        // d z2
   if (G) launch_gemm_tn<T>(bufA, HP, b[DH], HP, ce, HP, HP, G + L.W3T, HP, G + L.b3, 0, nullptr, g, st);
-  launch_gemm_nt<T>(b[DH], ce, HP, P.ro.W3T, HP, HP, b[DC2], false, st);           // d h1
+  back_gemm(b[DH], ce, HP, L.W3T, L.t_W3, HP, b[DC2], false);                      // d h1
   if (rv.train_bn) {
     launch_ssp_bwd<T>(b[DC2], bufA, nullptr, E, HP, C, B, st);                     // d (BN output)
     launch_bn_train_bwd<T>(b[DC2], P.tape_z1.template as<T>(), fe, HP, d.Fe,
@@ -758,7 +795,7 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   } else {
     launch_ssp_bwd<T>(b[DC2], bufA, P.ro.scale0, E, HP, C, B, st);                 // d acc1
   }
-  launch_gemm_nt<T>(b[DC2], ce, HP, P.ro.W0T, HP, d.FeP, b[DE0], false, st);       // d edge_P
+  back_gemm(b[DC2], ce, HP, L.W0T, L.t_W0, d.FeP, b[DE0], false);                  // d edge_P
   HIP_TRY(hipMemsetAsync(b[DN0], 0, cn * d.FnP * sizeof(T), st));                  // d node_P = 0
 
   int cur = 0;  // b[DE0 + cur], b[DN0 + cur] hold the cotangents of (edge, node)_{p+1}
@@ -786,13 +823,13 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     // EdgeBlock
     HIP_TRY(hipMemsetAsync(b[DPQ], 0, sizes[DPQ] * sizeof(T), st));
     HIP_TRY(hipMemsetAsync(b[DNP3], 0, sizes[DNP3] * sizeof(T), st));
-    launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, de_next, de_prev, b[DPQ], b[DNP3], b[DC2], C, B, g, d, w,
-                       G ? &gw : nullptr, st);
-    launch_gemm_nt<T>(b[DPQ], ce, 4 * d.FeP, w.c3_WeT, 4 * d.FeP, d.FeP, de_prev, true, st);
+    launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, P.tape_agg[p].template as<T>(), de_next, de_prev, b[DPQ],
+                       b[DNP3], b[DC2], C, B, g, d, w, G ? &gw : nullptr, st);
+    back_gemm(b[DPQ], ce, 4 * d.FeP, L.pass[p].c3_WeT, L.pass[p].t_c3We, d.FeP, de_prev, true);
     // node_{p+1} cotangent: incoming + projections + c2 operand
     HIP_TRY(hipMemcpyAsync(b[DNX], dn_next, cn * d.FnP * sizeof(T), hipMemcpyDeviceToDevice, st));
-    launch_gemm_nt<T>(b[DNP3], cn, 6 * d.FeP, w.c3_WnT, 6 * d.FeP, d.FnP, b[DNX], true, st);
-    launch_gemm_nt<T>(b[DC2], ce, 2 * d.FeP, w.c2_WT, 2 * d.FeP, d.FnP, b[DPROD], false, st);
+    back_gemm(b[DNP3], cn, 6 * d.FeP, L.pass[p].c3_WnT, L.pass[p].t_c3Wn, d.FnP, b[DNX], true);
+    back_gemm(b[DC2], ce, 2 * d.FeP, L.pass[p].c2_WT, L.pass[p].t_c2W, d.FnP, b[DPROD], false);
     launch_prod_bwd<T>(b[DPROD], node1, b[DNX], C, B, g, d, st);
     if (G) {
       const auto &q = L.pass[p];
@@ -804,8 +841,8 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     launch_rowgemm<T>(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
     launch_node_bwd<T>(c.npc1, bufA, node1, b[DNX], dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w,
                        G ? &gw : nullptr, st);
-    launch_gemm_nt<T>(b[DBC1], ce, 2 * d.FnP, w.c1_WeT, 2 * d.FnP, d.FeP, de_prev, true, st);
-    launch_gemm_nt<T>(b[DNPC1], cn, 2 * d.FnP, w.c1_WnT, 2 * d.FnP, d.FnP, dn_prev, true, st);
+    back_gemm(b[DBC1], ce, 2 * d.FnP, L.pass[p].c1_WeT, L.pass[p].t_c1We, d.FeP, de_prev, true);
+    back_gemm(b[DNPC1], cn, 2 * d.FnP, L.pass[p].c1_WnT, L.pass[p].t_c1Wn, d.FnP, dn_prev, true);
     if (G) {
       const auto &q = L.pass[p];
       launch_gemm_tn<T>(edge0, d.FeP, b[DBC1], 2 * d.FnP, ce, d.FeP, 2 * d.FnP, G + q.c1_WeT, 2 * d.FnP, nullptr, 0, nullptr, g, st);
@@ -828,9 +865,11 @@ void ensure_tape(rn_potgnn *h, int S) {
   const int NP = h->cfg.num_message_passes;
   P.tape_node.resize(NP + 1);
   P.tape_edge.resize(NP + 1);
+  P.tape_agg.resize(NP + 1);
   for (int p = 0; p <= NP; ++p) {
     P.tape_node[p].ensure((size_t)S * h->g.N * h->d.FnP * sizeof(T));
     P.tape_edge[p].ensure((size_t)S * h->g.E * h->d.FeP * sizeof(T));
+    P.tape_agg[p].ensure((size_t)S * h->g.E * h->d.FeP * sizeof(T));
   }
 }
 
@@ -901,7 +940,7 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, flo
   T *Wd = P.weights.as<T>();
   P.tape_z1.ensure((size_t)R * HP * sizeof(T));
   P.bn_stats.ensure(sizeof(double) * 4 * HP);
-  DeviceBuf mv;
+  DeviceBuf &mv = P.mv;
   mv.ensure(sizeof(T) * 2 * HP);
   const T *edgeP = P.tape_edge[h->cfg.num_message_passes].as<T>();
   // z1 = edge W0^T + b0 ; h1 = ssp(BN_batch(z1)) ; then the rest of the readout as in eval
@@ -935,7 +974,7 @@ void train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
   if (S <= 0) throw HipError{hipErrorInvalidValue, "train_backward without train_forward"};
   ChunkRun<T> c(h, P.lanes[0], h->io_pos.as<double>(), S, nullptr, nullptr, nullptr);
   hipStream_t st = c.st();
-  DeviceBuf seeds;
+  DeviceBuf &seeds = P.seeds;
   seeds.ensure((size_t)S * 6 * sizeof(T));
   HIP_TRY(hipMemcpy(seeds.p, dvec6, (size_t)S * 6 * sizeof(T), hipMemcpyHostToDevice));
   P.grad.ensure(h->lay.total * sizeof(T));

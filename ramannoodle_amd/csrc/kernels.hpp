@@ -86,6 +86,10 @@ void launch_rowgemm(const T *X, int64_t M, int KP, const T *WT, int NOUT, T *Y,
                     const T *scale, const T *shift, bool act, int amode, const T *node,
                     const Graph &g, hipStream_t st);
 
+// float32 only: Y (+)= X[:, 0:N] * Wt[N, NOUT] on the MFMA kernel; false if the shape is unsupported
+bool launch_rowgemm_blocks(const float *X, int ldx, int N, int64_t M, const float *Wt, int NOUT,
+                           float *Y, bool accumulate, const Graph &g, hipStream_t st);
+
 template <typename T>
 void launch_node_agg(const T *npc1, const T *bc1, const T *node_in, T *node_out, int S,
                      const Graph &g, Dims d, const PassW<T> &w, hipStream_t st);
@@ -93,6 +97,7 @@ void launch_node_agg(const T *npc1, const T *bc1, const T *node_in, T *node_out,
 template <typename T>
 void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in,
                      T *edge_out, int S, const Graph &g, Dims d, const PassW<T> &w,
+                     T *agg_out /* optional tape of the pre-LayerNorm triplet sums */,
                      hipStream_t st);
 
 template <typename T>
@@ -118,6 +123,7 @@ void launch_ssp_bwd(T *d, const T *h, const T *scale, int64_t rows_per_frame, in
                     int B, hipStream_t st);
 template <typename T>
 void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
+                     const T *agg /* taped pre-LayerNorm triplet sums [S*E, FeP] */,
                      const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3, T *dc2pre, int C, int B,
                      const Graph &g, Dims d, const PassW<T> &w, const PassW<T> *grad_w,
                      hipStream_t st);  // grad_w: same layout as w inside the gradient blob, or null

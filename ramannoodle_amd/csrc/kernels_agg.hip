@@ -347,10 +347,14 @@ __device__ __forceinline__ void ln_rowv(T (&x)[VPL], const T *gam, const T *bet,
   for (int k = 0; k < VPL; ++k) x[k] = x[k] * rstd * g[k] + b[k];
 }
 
+#ifndef RN_AGG_WAVES
+#define RN_AGG_WAVES 3
+#endif
 template <int FP, int VPL, bool PAD, typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : 3))) void edge_agg_kernel(
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_WAVES))) void edge_agg_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
-    const T *__restrict__ edge_in, T *__restrict__ edge_out, int S, Graph g, Dims d, PassW<T> w) {
+    const T *__restrict__ edge_in, T *__restrict__ edge_out, int S, Graph g, Dims d, PassW<T> w,
+    T *__restrict__ agg_out /* training tape: pre-LayerNorm triplet sums [S*E, FP], or null */) {
   constexpr int LG = FP / VPL;   // lanes per row
   constexpr int G = 256 / LG;    // lane groups (= destination edges in flight) per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -489,7 +493,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : 3))) voi
         }
       }
       const int inext = i + G;
+#if RN_AGG_WAVES < 4   // (at 4 waves/SIMD there are no registers for the look-ahead)
       if (inext < dcount) fetch(inext);
+#endif
       // this destination's c2 pre-activation and old embedding arrive during the triplet loop
       const int64_t drow = erow0 + d_edge[i];
       T c2f[VPL], c2c[VPL], old[VPL];
@@ -536,6 +542,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : 3))) voi
           acc[k] += gate_exp2(yf, yc);
         }
       }
+      if (agg_out) storev<VPL>(agg_out + (erow0 + d_edge[i]) * FP + c0, acc);
       ln_rowv<LG, VPL, PAD>(acc, s_c3n2g + c0, s_c3n2b + c0, invn, nvalid);  // c3 (_gnn.py:291)
 
       // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
@@ -567,6 +574,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : 3))) voi
       for (int k = 0; k < VPL; ++k) out[k] = acc_tanh(old[k] + c2f[k] + acc[k]);
       storev<VPL>(edge_out + drow * FP + c0, out);
       i = inext;
+#if RN_AGG_WAVES >= 4
+      if (i < dcount) fetch(i);
+#endif
     }
     __syncthreads();  // qrows / nj are restaged for the next frame
   }
@@ -610,7 +620,7 @@ size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem) {
 template <int FP, int VPL, bool PAD, typename T>
 static void launch_edge_agg_cfg(const T *pq, const T *np3, const T *c2pre, const T *edge_in,
                                 T *edge_out, int S, const Graph &g, Dims d, const PassW<T> &w,
-                                size_t lds, hipStream_t st) {
+                                size_t lds, T *agg_out, hipStream_t st) {
   // Persistent workgroups: one per (tile, frame group).  The grid is sized to exactly the
   // number of workgroups the chip holds at once (a partial second round would leave two
   // thirds of the CUs idle: measured 2.25 instead of 3 waves/SIMD).
@@ -625,19 +635,19 @@ static void launch_edge_agg_cfg(const T *pq, const T *np3, const T *c2pre, const
   int nsg = per_cu * num_cus() / g.num_tiles;
   nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
   kern<<<(unsigned)nsg * (unsigned)g.num_tiles, 256, lds, st>>>(pq, np3, c2pre, edge_in, edge_out, S,
-                                                                g, d, w);
+                                                                g, d, w, agg_out);
 }
 
 template <typename T>
 void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in, T *edge_out,
-                     int S, const Graph &g, Dims d, const PassW<T> &w, hipStream_t st) {
+                     int S, const Graph &g, Dims d, const PassW<T> &w, T *agg_out, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
   const size_t lds = edge_agg_lds_bytes(g, d, sizeof(T));
   const bool pad = d.Fe != d.FeP;
 #define RN_EA(FPV, VPLV)                                                                          \
   do {                                                                                            \
-    if (pad) launch_edge_agg_cfg<FPV, VPLV, true, T>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w, lds, st); \
-    else launch_edge_agg_cfg<FPV, VPLV, false, T>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w, lds, st);    \
+    if (pad) launch_edge_agg_cfg<FPV, VPLV, true, T>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w, lds, agg_out, st); \
+    else launch_edge_agg_cfg<FPV, VPLV, false, T>(pq, np3, c2pre, edge_in, edge_out, S, g, d, w, lds, agg_out, st); \
   } while (0)
   const bool wide = sizeof(T) == 4 && agg_vpl() == 8;  // 8 columns per lane: float32, opt-in
   switch (d.FeP) {
@@ -650,10 +660,10 @@ void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in
 }
 template void launch_edge_agg<float>(const float *, const float *, const float *, const float *,
                                      float *, int, const Graph &, Dims, const PassW<float> &,
-                                     hipStream_t);
+                                     float *, hipStream_t);
 template void launch_edge_agg<double>(const double *, const double *, const double *,
                                       const double *, double *, int, const Graph &, Dims,
-                                      const PassW<double> &, hipStream_t);
+                                      const PassW<double> &, double *, hipStream_t);
 
 // ============================================================================ readout
 // Edge 6-vectors from the 12-wide readout embedding and the bond direction, closed form of

@@ -10,6 +10,8 @@
 // Indexing: cotangent "instance" c in [0, C) belongs to forward frame s = c / B (B
 // cotangents per frame: 6 for the Jacobian of the six polarizability components).
 // Forward arrays are indexed by s, cotangent arrays by c.
+#include <cstdlib>
+
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -215,12 +217,14 @@ template void launch_ssp_bwd<double>(double *, const double *, const double *, i
 
 // =========================================================================== edge block
 // Reverse of _EdgeBlock.forward (_gnn.py:294-351) for one destination edge d per lane group.
+// (Straightforward version: everything from global memory, dQ by global atomics.  Kept as
+// the cross-check of the tiled kernel below; RN_POTGNN_BWD_SIMPLE=1 selects it.)
 //   in : dedge_next [C*E,FP]  (cotangent of the block's output)
 //   out: dedge_prev [C*E,FP]  = residual part (the projection parts are added by GEMMs later)
 //        dpq [C*E,4FP] (first half written here, second half = dQ accumulated atomically)
 //        dnp3 [C*N,6FP] (atomic), dc2pre [C*E,2FP]
 template <int LG, typename T>
-__global__ __launch_bounds__(256) void edge_bwd_kernel(
+__global__ __launch_bounds__(256) void edge_bwd_simple_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
     const T *__restrict__ edge_next, const T *__restrict__ dedge_next, T *__restrict__ dedge_prev,
     T *__restrict__ dpq, T *__restrict__ dnp3, T *__restrict__ dc2pre, int C, int B, Graph g, Dims d,
@@ -392,6 +396,292 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
     atomic_add4(const_cast<T *>(gw.c2_norm_2.g) + 4 * q, G22);
     atomic_add4(const_cast<T *>(gw.c2_norm_2.b) + 4 * q, B22);
   }
+}
+
+
+// ---- tiled EdgeBlock backward ---------------------------------------------------------------
+// Same decomposition as the forward edge_agg_kernel: a workgroup owns one atom tile for the
+// whole launch (topology in LDS once), stages the tile's centred source rows Q' per cotangent
+// instance, and -- new here -- accumulates the source-row cotangents dQ' in LDS (every
+// destination edge entering the tile's atoms adds to them; each source row belongs to
+// exactly one tile, so they leave the CU with plain stores).  One triplet loop: the
+// pre-LayerNorm sums come from the forward tape.
+template <typename T>
+__device__ __forceinline__ void gate_parts(T yf, T yc, T &sg, T &th);
+template <>
+__device__ __forceinline__ void gate_parts<float>(float yf, float yc, float &sg, float &th) {
+  const float kL = 1.4426950408889634f;
+  yc = fminf(fmaxf(yc, -15.0f), 15.0f);
+  sg = fast_rcp(1.0f + fast_exp2(-kL * yf));
+  th = 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2(2.0f * kL * yc));
+}
+template <>
+__device__ __forceinline__ void gate_parts<double>(double yf, double yc, double &sg, double &th) {
+  sg = 1.0 / (1.0 + exp(-yf));
+  th = tanh(yc);
+}
+
+template <int FP, typename T>
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_kernel(
+    const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
+    const T *__restrict__ edge_next, const T *__restrict__ agg_tape, const T *__restrict__ dedge_next,
+    T *__restrict__ dedge_prev, T *__restrict__ dpq, T *__restrict__ dnp3, T *__restrict__ dc2pre,
+    int C, int B, Graph g, Dims d, PassW<T> w, PassW<T> gw, int want_param_grads) {
+  constexpr int LG = FP / 4;
+  constexpr int G = 256 / LG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    unsigned char *p = smem_raw + off;
+    off += (bytes + 15) & ~size_t(15);
+    return p;
+  };
+  T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));
+  T *dq = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));
+  T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));
+  T *nj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));
+  int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));
+  int *dl = reinterpret_cast<int *>(carve((size_t)maxD * 6 * 4));
+  int *d_edge = dl, *d_a = dl + maxD, *d_bl = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
+      *d_cnt = dl + 4 * maxD, *d_skip = dl + 5 * maxD;
+
+  const int tile = blockIdx.x % g.num_tiles;
+  const int cg = blockIdx.x / g.num_tiles, ncg = gridDim.x / g.num_tiles;
+  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  for (int r = threadIdx.x; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
+  for (int i = threadIdx.x; i < dcount; i += 256) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_bl[i] = bd - j0;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+  }
+  __syncthreads();
+
+  const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
+  const int nvalid = min(max(d.Fe - 4 * q, 0), 4);
+  const T inv2n = (T)1 / (T)(2 * d.Fe), invn = (T)1 / (T)d.Fe;
+  const Vec4<T> g1f = load4<T>(w.c3_norm_1.g + 4 * q), b1f = load4<T>(w.c3_norm_1.b + 4 * q);
+  const Vec4<T> g1c = load4<T>(w.c3_norm_1.g + FP + 4 * q), b1c = load4<T>(w.c3_norm_1.b + FP + 4 * q);
+  Vec4<T> G31f{{0, 0, 0, 0}}, B31f = G31f, G31c = G31f, B31c = G31f, G32 = G31f, B32 = G31f;
+  Vec4<T> G21f = G31f, B21f = G31f, G21c = G31f, B21c = G31f, G22 = G31f, B22 = G31f;
+
+  for (int c = cg; c < C; c += ncg) {
+    const int s = c / B;
+    const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    const int64_t cerow0 = (int64_t)c * g.E, cnrow0 = (int64_t)c * g.N;
+    for (int i = threadIdx.x; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+      const int n = i / (2 * FP / 4), cc = (i % (2 * FP / 4)) * 4;
+      store4(nj + (size_t)n * 2 * FP + cc, load4<T>(np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + cc));
+    }
+    for (int r = grp; r < rows; r += G) {  // centred source rows, as in the forward kernel
+      const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
+      const T *np = np3 + (nrow0 + qb[r]) * (6 * FP) + 4 * q;
+      Vec4<T> f = load4<T>(qp), cc = load4<T>(qp + FP);
+      const Vec4<T> nf = load4<T>(np), nc = load4<T>(np + FP);
+      T sum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f.v[k] += nf.v[k];
+        cc.v[k] += nc.v[k];
+        sum += f.v[k] + cc.v[k];
+      }
+      const T mean = lg_sum<LG>(sum) * inv2n;
+      T ss = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f.v[k] = k < nvalid ? f.v[k] - mean : (T)0;
+        cc.v[k] = k < nvalid ? cc.v[k] - mean : (T)0;
+        ss += f.v[k] * f.v[k] + cc.v[k] * cc.v[k];
+      }
+      ss = lg_sum<LG>(ss);
+      store4(qrows + (size_t)r * 2 * FP + 4 * q, f);
+      store4(qrows + (size_t)r * 2 * FP + FP + 4 * q, cc);
+      const Vec4<T> zero{{0, 0, 0, 0}};
+      store4(dq + (size_t)r * 2 * FP + 4 * q, zero);
+      store4(dq + (size_t)r * 2 * FP + FP + 4 * q, zero);
+      if (q == 0) sq[r] = ss;
+    }
+    __syncthreads();
+
+    for (int i = grp; i < dcount; i += G) {
+      const int dst = d_edge[i];
+      const int64_t drow = erow0 + dst, cdrow = cerow0 + dst;
+      const Vec4<T> e1 = load4<T>(edge_next + drow * FP + 4 * q);
+      Vec4<T> dz = load4<T>(dedge_next + cdrow * FP + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz.v[k] *= ((T)1 - e1.v[k] * e1.v[k]);
+      store4(dedge_prev + cdrow * FP + 4 * q, dz);
+
+      // P'_d centred
+      Vec4<T> pf = load4<T>(pq + drow * (4 * FP) + 4 * q), pc = load4<T>(pq + drow * (4 * FP) + FP + 4 * q);
+      {
+        const T *nk = np3 + (nrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
+        const Vec4<T> kf = load4<T>(nk), kc = load4<T>(nk + FP);
+        const Vec4<T> jf = load4<T>(nj + (size_t)d_bl[i] * 2 * FP + 4 * q);
+        const Vec4<T> jc = load4<T>(nj + (size_t)d_bl[i] * 2 * FP + FP + 4 * q);
+        T sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf.v[k] += jf.v[k] + kf.v[k];
+          pc.v[k] += jc.v[k] + kc.v[k];
+          sum += pf.v[k] + pc.v[k];
+        }
+        const T mean = lg_sum<LG>(sum) * inv2n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf.v[k] = k < nvalid ? pf.v[k] - mean : (T)0;
+          pc.v[k] = k < nvalid ? pc.v[k] - mean : (T)0;
+        }
+      }
+      T sp = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sp += pf.v[k] * pf.v[k] + pc.v[k] * pc.v[k];
+      sp = lg_sum<LG>(sp);
+
+      // LayerNorm (c3_norm_2) backward from the taped sums
+      Vec4<T> dagg;
+      {
+        const Vec4<T> g2 = load4<T>(w.c3_norm_2.g + 4 * q);
+        Vec4<T> hat = load4<T>(agg_tape + drow * FP + 4 * q);
+        const T rstd = ln1_hat<LG>(hat, invn, nvalid);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dagg.v[k] = dz.v[k] * g2.v[k];
+          B32.v[k] += dz.v[k];
+          G32.v[k] += dz.v[k] * hat.v[k];
+        }
+        ln1_bwd<LG>(dagg, hat, rstd, invn, nvalid);
+      }
+      Vec4<T> dpf{{0, 0, 0, 0}}, dpc{{0, 0, 0, 0}};
+      const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+      for (int t = 0; t < cnt; ++t) {
+        const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
+        const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
+        const Vec4<T> qf = load4<T>(qr), qc = load4<T>(qr + FP);
+        T dot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dot += pf.v[k] * qf.v[k] + pc.v[k] * qc.v[k];
+        dot = lg_sum<LG>(dot);
+        T var = (sp + sq[r] + (T)2 * dot) * inv2n;
+        var = var > (T)0 ? var : (T)0;
+        const T rstd = (T)1 / sqrt(var + (T)1e-5);
+        Vec4<T> hf, hc, df, dc;
+        T sa = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hf.v[k] = (pf.v[k] + qf.v[k]) * rstd;
+          hc.v[k] = (pc.v[k] + qc.v[k]) * rstd;
+          T sg, th;
+          gate_parts<T>(hf.v[k] * g1f.v[k] + b1f.v[k], hc.v[k] * g1c.v[k] + b1c.v[k], sg, th);
+          const T dyf = dagg.v[k] * th * sg * ((T)1 - sg), dyc = dagg.v[k] * sg * ((T)1 - th * th);
+          B31f.v[k] += dyf;
+          G31f.v[k] += dyf * hf.v[k];
+          B31c.v[k] += dyc;
+          G31c.v[k] += dyc * hc.v[k];
+          df.v[k] = dyf * g1f.v[k];
+          dc.v[k] = dyc * g1c.v[k];
+          sa += df.v[k] + dc.v[k];
+          sb += df.v[k] * hf.v[k] + dc.v[k] * hc.v[k];
+        }
+        sa = lg_sum<LG>(sa) * inv2n;
+        sb = lg_sum<LG>(sb) * inv2n;
+        T *dqr = dq + (size_t)r * 2 * FP + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const T xf = k < nvalid ? rstd * (df.v[k] - sa - hf.v[k] * sb) : (T)0;
+          const T xc = k < nvalid ? rstd * (dc.v[k] - sa - hc.v[k] * sb) : (T)0;
+          dpf.v[k] += xf;
+          dpc.v[k] += xc;
+          atomicAdd(dqr + k, xf);        // LDS: destinations of the same atom share source rows
+          atomicAdd(dqr + FP + k, xc);
+        }
+      }
+      store4(dpq + cdrow * (4 * FP) + 4 * q, dpf);
+      store4(dpq + cdrow * (4 * FP) + FP + 4 * q, dpc);
+      {
+        T *dj = dnp3 + (cnrow0 + j0 + d_bl[i]) * (6 * FP) + 2 * FP + 4 * q;
+        T *dk = dnp3 + (cnrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
+        atomic_add4(dj, dpf);
+        atomic_add4(dj + FP, dpc);
+        atomic_add4(dk, dpf);
+        atomic_add4(dk + FP, dpc);
+      }
+      // c2 = LN(gate(LN(c2pre)))  (_gnn.py:223-228)
+      {
+        Vec4<T> xf = load4<T>(c2pre + drow * (2 * FP) + 4 * q), xc = load4<T>(c2pre + drow * (2 * FP) + FP + 4 * q);
+        const T rstd1 = ln2_hat<LG>(xf, xc, inv2n, nvalid);
+        const Vec4<T> gf = load4<T>(w.c2_norm_1.g + 4 * q), bf = load4<T>(w.c2_norm_1.b + 4 * q);
+        const Vec4<T> gc = load4<T>(w.c2_norm_1.g + FP + 4 * q), bc = load4<T>(w.c2_norm_1.b + FP + 4 * q);
+        Vec4<T> gv, da, db;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          gate_grad(xf.v[k] * gf.v[k] + bf.v[k], xc.v[k] * gc.v[k] + bc.v[k], gv.v[k], da.v[k], db.v[k]);
+        Vec4<T> hat = gv;
+        const T rstd2 = ln1_hat<LG>(hat, invn, nvalid);
+        const Vec4<T> g22 = load4<T>(w.c2_norm_2.g + 4 * q);
+        Vec4<T> dg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dg.v[k] = dz.v[k] * g22.v[k];
+          B22.v[k] += dz.v[k];
+          G22.v[k] += dz.v[k] * hat.v[k];
+        }
+        ln1_bwd<LG>(dg, hat, rstd2, invn, nvalid);
+        Vec4<T> df, dc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const T dyf = dg.v[k] * da.v[k], dyc = dg.v[k] * db.v[k];
+          B21f.v[k] += dyf;
+          G21f.v[k] += dyf * xf.v[k];
+          B21c.v[k] += dyc;
+          G21c.v[k] += dyc * xc.v[k];
+          df.v[k] = dyf * gf.v[k];
+          dc.v[k] = dyc * gc.v[k];
+        }
+        ln2_bwd<LG>(df, dc, xf, xc, rstd1, inv2n, nvalid);
+        store4(dc2pre + cdrow * (2 * FP) + 4 * q, df);
+        store4(dc2pre + cdrow * (2 * FP) + FP + 4 * q, dc);
+      }
+    }
+    __syncthreads();
+    // the tile's source-row cotangents leave the CU once (each row belongs to this tile only)
+    for (int r = grp; r < rows; r += G) {
+      T *o = dpq + (cerow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
+      store4(o, load4<T>(dq + (size_t)r * 2 * FP + 4 * q));
+      store4(o + FP, load4<T>(dq + (size_t)r * 2 * FP + FP + 4 * q));
+    }
+    __syncthreads();
+  }
+  if (want_param_grads) {
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.g) + 4 * q, G31f);
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.b) + 4 * q, B31f);
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.g) + FP + 4 * q, G31c);
+    atomic_add4(const_cast<T *>(gw.c3_norm_1.b) + FP + 4 * q, B31c);
+    atomic_add4(const_cast<T *>(gw.c3_norm_2.g) + 4 * q, G32);
+    atomic_add4(const_cast<T *>(gw.c3_norm_2.b) + 4 * q, B32);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.g) + 4 * q, G21f);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.b) + 4 * q, B21f);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.g) + FP + 4 * q, G21c);
+    atomic_add4(const_cast<T *>(gw.c2_norm_1.b) + FP + 4 * q, B21c);
+    atomic_add4(const_cast<T *>(gw.c2_norm_2.g) + 4 * q, G22);
+    atomic_add4(const_cast<T *>(gw.c2_norm_2.b) + 4 * q, B22);
+  }
+}
+
+static size_t edge_bwd_tile_lds(const Graph &g, int FP, size_t elem) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  return 2 * up((size_t)g.max_tile_out_rows * 2 * FP * elem) + up((size_t)g.max_tile_out_rows * elem) +
+         up((size_t)g.max_tile_nodes * 2 * FP * elem) + up((size_t)g.max_tile_out_rows * 4) +
+         up((size_t)g.max_tile_in_rows * 6 * 4);
 }
 
 // dnp3[c, b_e][Wi block] += dQ'_e  (the node part of the source-row projection)
@@ -590,8 +880,33 @@ template void launch_geom_bwd<double>(const double *, const double *, const doub
     case 32: CALL(32); break;    \
   }
 
+template <int FP, typename T>
+static bool launch_edge_bwd_tile(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
+                                 const T *agg, const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3,
+                                 T *dc2pre, int C, int B, const Graph &g, Dims d, const PassW<T> &w,
+                                 const PassW<T> &gwv, int want, hipStream_t st) {
+  const size_t lds = edge_bwd_tile_lds(g, FP, sizeof(T));
+  if (lds > 160 * 1024 - 512) return false;
+  auto kern = &edge_bwd_tile_kernel<FP, T>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cus = prop.multiProcessorCount;
+  int ncg = per_cu * cus / g.num_tiles;
+  ncg = ncg < 1 ? 1 : (ncg > C ? C : ncg);
+  kern<<<(unsigned)ncg * (unsigned)g.num_tiles, 256, lds, st>>>(pq, np3, c2pre, edge_next, agg, dedge_next,
+                                                                dedge_prev, dpq, dnp3, dc2pre, C, B, g, d,
+                                                                w, gwv, want);
+  return true;
+}
+
 template <typename T>
-void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
+void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_next, const T *agg,
                      const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3, T *dc2pre, int C, int B,
                      const Graph &g, Dims d, const PassW<T> &w, const PassW<T> *gw, hipStream_t st) {
   const int lg = d.FeP / 4;
@@ -600,20 +915,32 @@ void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_ne
   const int64_t threads = (int64_t)C * g.E * lg;
   if (threads == 0) return;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
-#define CALL(LGV)                                                                                  \
-  edge_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(pq, np3, c2pre, edge_next, dedge_next, dedge_prev, \
-                                                  dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want);    \
+  static const bool simple = getenv("RN_POTGNN_BWD_SIMPLE") && atoi(getenv("RN_POTGNN_BWD_SIMPLE")) != 0;
+  bool done = false;
+  if (!simple && agg) {
+    switch (d.FeP) {
+      case 16: done = launch_edge_bwd_tile<16, T>(pq, np3, c2pre, edge_next, agg, dedge_next, dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want, st); break;
+      case 32: done = launch_edge_bwd_tile<32, T>(pq, np3, c2pre, edge_next, agg, dedge_next, dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want, st); break;
+      case 64: done = launch_edge_bwd_tile<64, T>(pq, np3, c2pre, edge_next, agg, dedge_next, dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want, st); break;
+      case 128: done = launch_edge_bwd_tile<128, T>(pq, np3, c2pre, edge_next, agg, dedge_next, dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want, st); break;
+    }
+  }
+#define CALL(LGV)                                                                                    \
+  if (!done)                                                                                         \
+    edge_bwd_simple_kernel<LGV, T><<<blocks, 256, 0, st>>>(pq, np3, c2pre, edge_next, dedge_next,    \
+                                                           dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, \
+                                                           gwv, want);                               \
   q_scatter_kernel<LGV, T><<<blocks, 256, 0, st>>>(dpq, dnp3, C, g)
   RN_LG_SWITCH(d.FeP, CALL)
 #undef CALL
 }
 template void launch_edge_bwd<float>(const float *, const float *, const float *, const float *,
-                                     const float *, float *, float *, float *, float *, int, int,
-                                     const Graph &, Dims, const PassW<float> &, const PassW<float> *,
-                                     hipStream_t);
+                                     const float *, const float *, float *, float *, float *, float *,
+                                     int, int, const Graph &, Dims, const PassW<float> &,
+                                     const PassW<float> *, hipStream_t);
 template void launch_edge_bwd<double>(const double *, const double *, const double *, const double *,
-                                      const double *, double *, double *, double *, double *, int, int,
-                                      const Graph &, Dims, const PassW<double> &,
+                                      const double *, const double *, double *, double *, double *,
+                                      double *, int, int, const Graph &, Dims, const PassW<double> &,
                                       const PassW<double> *, hipStream_t);
 
 template <typename T>
@@ -691,15 +1018,110 @@ __global__ void gemm_tn_kernel(const T *__restrict__ X, int ldx, const T *__rest
     if (dbias && k == 0) atomicAdd(dbias + n, bsum);
   }
 }
+// Tiled version: a workgroup stages 128 rows of X (all K columns) and of a 64-column chunk of
+// dY in LDS and forms the K x 64 partial product with register blocking (thread (tk, tn) owns
+// k = tk + 16 i, n = 4 tn .. 4 tn + 3); workgroups walk row tiles persistently and add their
+// partial sums to the gradient with one atomic per output element.
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void gemm_tn_tiled_kernel(const T *__restrict__ X, int ldx,
+                                                            const T *__restrict__ dY, int ldy, int64_t R,
+                                                            int K, int N, T *__restrict__ dWT, int ldw,
+                                                            T *__restrict__ dbias, int amode,
+                                                            const T *__restrict__ node, Graph g) {
+  constexpr int BR = 128, NC = 64, KI = KMAX / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *xs = reinterpret_cast<T *>(smem_raw);   // [BR][KMAX + 1]
+  T *ys = xs + BR * (KMAX + 1);              // [BR][NC]
+  const int n0 = blockIdx.y * NC;
+  const int tk = threadIdx.x / 16, tn = threadIdx.x % 16;
+  T acc[KI][4];
+#pragma unroll
+  for (int i = 0; i < KI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  T bsum[4] = {0, 0, 0, 0};
+  const int64_t tiles = (R + BR - 1) / BR;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * BR;
+    for (int i = threadIdx.x; i < BR * KMAX; i += 256) {
+      const int r = i / KMAX, k = i % KMAX;
+      const int64_t row = r0 + r;
+      T v = 0;
+      if (row < R && k < K) {
+        if (amode == 0) {
+          v = X[row * ldx + k];
+        } else {
+          const int64_t s = row / g.E;
+          const int e = (int)(row % g.E);
+          v = node[(s * g.N + g.edge_b[e]) * ldx + k] * node[(s * g.N + g.edge_a[e]) * ldx + k];
+        }
+      }
+      xs[r * (KMAX + 1) + k] = v;
+    }
+    for (int i = threadIdx.x; i < BR * NC; i += 256) {
+      const int r = i / NC, n = i % NC;
+      const int64_t row = r0 + r;
+      ys[i] = (row < R && n0 + n < N) ? dY[row * ldy + n0 + n] : (T)0;
+    }
+    __syncthreads();
+    for (int r = 0; r < BR; ++r) {
+      const T y0 = ys[r * NC + 4 * tn], y1 = ys[r * NC + 4 * tn + 1], y2 = ys[r * NC + 4 * tn + 2],
+              y3 = ys[r * NC + 4 * tn + 3];
+#pragma unroll
+      for (int i = 0; i < KI; ++i) {
+        const T x = xs[r * (KMAX + 1) + tk + 16 * i];
+        acc[i][0] += x * y0;
+        acc[i][1] += x * y1;
+        acc[i][2] += x * y2;
+        acc[i][3] += x * y3;
+      }
+      if (tk == 0) {
+        bsum[0] += y0; bsum[1] += y1; bsum[2] += y2; bsum[3] += y3;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = tk + 16 * i;
+    if (k < K)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + 4 * tn + j < N) atomicAdd(dWT + (int64_t)k * ldw + n0 + 4 * tn + j, acc[i][j]);
+  }
+  if (dbias && tk == 0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + 4 * tn + j < N) atomicAdd(dbias + n0 + 4 * tn + j, bsum[j]);
+}
+
 template <typename T>
 void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
                     int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st) {
   if (R == 0) return;
-  const int rows_per_block = 512;
-  dim3 grid((unsigned)((K * N + 255) / 256), (unsigned)((R + rows_per_block - 1) / rows_per_block));
-  if (grid.x > 64) grid.x = 64;
-  gemm_tn_kernel<T><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g,
+  const int64_t tiles = (R + 127) / 128;
+  dim3 grid((unsigned)(tiles < 64 ? tiles : 64), (unsigned)((N + 63) / 64));
+#define RN_TN(KM)                                                                                   \
+  do {                                                                                              \
+    const size_t lds = ((size_t)128 * (KM + 1) + 128 * 64) * sizeof(T);                             \
+    auto kern = &gemm_tn_tiled_kernel<T, KM>;                                                       \
+    if (lds > 48 * 1024)                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+    kern<<<grid, 256, lds, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g);        \
+  } while (0)
+  if (K <= 16) RN_TN(16);
+  else if (K <= 32) RN_TN(32);
+  else if (K <= 64) RN_TN(64);
+  else if (K <= 128) RN_TN(128);
+  else {
+    const int rows_per_block = 512;
+    dim3 g2((unsigned)((K * N + 255) / 256), (unsigned)((R + rows_per_block - 1) / rows_per_block));
+    if (g2.x > 64) g2.x = 64;
+    gemm_tn_kernel<T><<<g2, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g,
                                           rows_per_block);
+  }
+#undef RN_TN
 }
 template void launch_gemm_tn<float>(const float *, int, const float *, int, int64_t, int, int,
                                     float *, int, float *, int, const float *, const Graph &,

@@ -17,6 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
   const float *X;
+  int ldx;     // row stride of X (>= KP)
+  int accum;   // Y += instead of Y =
   int64_t M;
   const float *WT;
   int NOUT;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
       if (AMODE == 1) pre2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < a.M) {
         if (AMODE == 0) {
-          pre[j] = *reinterpret_cast<const float4 *>(a.X + row * KP + c);
+          pre[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + c);
         } else {
           const int64_t s = row / a.E;
           const int e = (int)(row % a.E);
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
             float v = acc[t][r];
             if (EPI == 1) v += sh[t];
             if (EPI == 2) v = ssp_fast(v * sc[t] + sh[t]);
+            if (a.accum) v += a.Y[row * a.NOUT + col];
             a.Y[row * a.NOUT + col] = v;
           }
         }
@@ -186,7 +189,7 @@ void launch_rowgemm<float>(const float *X, int64_t M, int KP, const float *WT, i
                            const float *scale, const float *shift, bool act, int amode,
                            const float *node, const Graph &g, hipStream_t st) {
   if (M == 0) return;
-  GemmArgs a{X, M, WT, NOUT, Y, scale, shift, node, g.edge_a, g.edge_b, g.N, g.E};
+  GemmArgs a{X, KP, 0, M, WT, NOUT, Y, scale, shift, node, g.edge_a, g.edge_b, g.N, g.E};
   const int epi = act ? 2 : (shift ? 1 : 0);
   switch (KP) {
     case 16: launch_mfma_kp<16>(a, amode, epi, st); break;
@@ -194,6 +197,28 @@ void launch_rowgemm<float>(const float *X, int64_t M, int KP, const float *WT, i
     case 64: launch_mfma_kp<64>(a, amode, epi, st); break;
     case 128: launch_mfma_kp<128>(a, amode, epi, st); break;
   }
+}
+
+// Y[M, NOUT] (+)= X[M, 0:N] * Wt[N, NOUT] for any N that is a multiple of 16: the inner
+// dimension is walked in blocks of <= 128 columns (row stride ldx), accumulating into Y.
+// Used for the activation gradients dX = dY * W^T with the pre-transposed weights.
+bool launch_rowgemm_blocks(const float *X, int ldx, int N, int64_t M, const float *Wt, int NOUT,
+                           float *Y, bool accumulate, const Graph &g, hipStream_t st) {
+  if (M == 0) return true;
+  if (NOUT % 32 != 0 || N % 16 != 0) return false;
+  int bk = 128;
+  while (N % bk != 0) bk /= 2;
+  for (int off = 0; off < N; off += bk) {
+    GemmArgs a{X + off, ldx, (accumulate || off > 0) ? 1 : 0, M, Wt + (size_t)off * NOUT, NOUT, Y,
+               nullptr, nullptr, nullptr, g.edge_a, g.edge_b, g.N, g.E};
+    switch (bk) {
+      case 16: launch_mfma_kp<16>(a, 0, 0, st); break;
+      case 32: launch_mfma_kp<32>(a, 0, 0, st); break;
+      case 64: launch_mfma_kp<64>(a, 0, 0, st); break;
+      case 128: launch_mfma_kp<128>(a, 0, 0, st); break;
+    }
+  }
+  return true;
 }
 
 // ---------------------------------------------------------------------------- float64
