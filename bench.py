@@ -31,6 +31,7 @@ HPARAMS = {
     "parity": (5, 14, 4),  # the only documented set (machine-learning.ipynb:187-192)
 }
 EDGE_AGG_KERNEL_ID = 7  # index of "edge_agg" in rn_potgnn_kernel_times / csrc/api.hip
+PROJ_C3_KERNEL_ID = 5   # "proj_edge_c3": the [E,64]x[64,256] projection (HBM-bound)
 LIGHT_CM_PER_FS = 2.99792458e-5
 
 
@@ -137,6 +138,20 @@ def measured_traffic(n, e, fn, fe, frames, passes, steps, launches):
     return per_structure_pass * frames * passes * steps / launches
 
 
+def projection_roofline(times, e, fe, frames, passes, steps):
+    """The HBM-bound kernel of the pipeline, for comparison: the c3 edge projection reads
+    E*Fe and writes E*4Fe floats per structure and pass (its output is an intermediate, so
+    these are actual, not 'algorithmic', bytes)."""
+    ms, launches = times.get("proj_edge_c3", (0.0, 0))
+    if not launches or ms <= 0:
+        return None
+    total = 4 * (e * fe + e * 4 * fe) * frames * passes * steps
+    achieved = total / (ms * 1e-3) / 1e9
+    return {"kernel": "rowgemm_mfma_kernel<64,4,2> (c3 edge projection)", "bound": "hbm",
+            "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "launches": launches, "avg_launch_ms": ms / launches}
+
+
 def cpu_baseline(workload, sample):
     """The oracle's faithful restatement of the reference CPU path, on `sample` frames."""
     from oracle import potgnn_oracle as O
@@ -199,7 +214,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    model.set_profiling(1 if args.profile_all else 100 + EDGE_AGG_KERNEL_ID)
+    model.set_profiling(1 if args.profile_all
+                        else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -265,6 +281,7 @@ def main():
                         "instructions incl. 3 transcendentals per (triplet, feature pair); "
                         "achieved/peak are the HBM figures the metric asks for",
             },
+            "roofline_projection": projection_roofline(times, e, fe, args.frames, passes, args.steps),
             "host_buffers_structures_per_s": host_rate,
         }
         if args.profile_all:

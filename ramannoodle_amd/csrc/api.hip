@@ -460,7 +460,9 @@ struct Timer {
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
   Timer(rn_potgnn *h_, hipStream_t st_, int kid_) : h(h_), st(st_), kid(kid_) {
-    on = h->profiling == 1 || (h->profiling >= 100 && h->profiling - 100 == kid);
+    // 1 = every kernel, 100 + k = kernel k only, 1000 + mask = the kernels whose bit is set
+    on = h->profiling == 1 || (h->profiling >= 100 && h->profiling < 1000 && h->profiling - 100 == kid) ||
+         (h->profiling >= 1000 && (((h->profiling - 1000) >> kid) & 1));
     if (on) {
       HIP_TRY(hipEventCreate(&a));
       HIP_TRY(hipEventCreate(&b));

@@ -350,7 +350,7 @@ __device__ __forceinline__ void ln_rowv(T (&x)[VPL], const T *gam, const T *bet,
 #ifndef RN_AGG_WAVES
 #define RN_AGG_WAVES 3
 #endif
-template <int FP, int VPL, bool PAD, typename T>
+template <int FP, int VPL, bool PAD, typename T, bool TAPE = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_WAVES))) void edge_agg_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
     const T *__restrict__ edge_in, T *__restrict__ edge_out, int S, Graph g, Dims d, PassW<T> w,
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_W
           acc[k] += gate_exp2(yf, yc);
         }
       }
-      if (agg_out) storev<VPL>(agg_out + (erow0 + d_edge[i]) * FP + c0, acc);
+      if (TAPE) storev<VPL>(agg_out + (erow0 + d_edge[i]) * FP + c0, acc);
       ln_rowv<LG, VPL, PAD>(acc, s_c3n2g + c0, s_c3n2b + c0, invn, nvalid);  // c3 (_gnn.py:291)
 
       // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
@@ -624,7 +624,7 @@ static void launch_edge_agg_cfg(const T *pq, const T *np3, const T *c2pre, const
   // Persistent workgroups: one per (tile, frame group).  The grid is sized to exactly the
   // number of workgroups the chip holds at once (a partial second round would leave two
   // thirds of the CUs idle: measured 2.25 instead of 3 waves/SIMD).
-  auto kern = &edge_agg_kernel<FP, VPL, PAD, T>;
+  auto kern = agg_out ? &edge_agg_kernel<FP, VPL, PAD, T, true> : &edge_agg_kernel<FP, VPL, PAD, T, false>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

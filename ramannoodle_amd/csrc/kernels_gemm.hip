@@ -33,7 +33,9 @@ struct GemmArgs {
 // 128-row tiles; wave (wm, wn) computes 32-row sub-tiles wm, wm+WM, .. for its TN column
 // tiles.  k is split between the two lane halves of the 32x32x2 instruction as
 // k = h*KP/2 + step so that every lane reads one contiguous run of its X row from LDS.
-template <int KP, int WN, int TN, int AMODE, int EPI>
+// EXT = true: X has row stride a.ldx and the result may be accumulated into Y (reverse-pass
+// products); EXT = false keeps the inference instantiations free of both.
+template <int KP, int WN, int TN, int AMODE, int EPI, bool EXT = false>
 __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
   constexpr int WM = 4 / WN;
   constexpr int BM = 128;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
       if (AMODE == 1) pre2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < a.M) {
         if (AMODE == 0) {
-          pre[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + c);
+          pre[j] = *reinterpret_cast<const float4 *>(a.X + row * (EXT ? a.ldx : KP) + c);
         } else {
           const int64_t s = row / a.E;
           const int e = (int)(row % a.E);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
             float v = acc[t][r];
             if (EPI == 1) v += sh[t];
             if (EPI == 2) v = ssp_fast(v * sc[t] + sh[t]);
-            if (a.accum) v += a.Y[row * a.NOUT + col];
+            if (EXT && a.accum) v += a.Y[row * a.NOUT + col];
             a.Y[row * a.NOUT + col] = v;
           }
         }
@@ -161,6 +163,20 @@ static void launch_mfma_cfg(const GemmArgs &a, int amode, int epi, dim3 grid, hi
     else RN_GEMM(1, 1);
   }
 #undef RN_GEMM
+}
+
+template <int KP>
+static void launch_mfma_ext(const GemmArgs &a, hipStream_t st) {  // plain product, EXT features
+  int slice = 32;
+  if (a.NOUT % 64 == 0) slice = 64;
+  if (a.NOUT % 128 == 0) slice = 128;
+  const int64_t tiles = (a.M + 127) / 128;
+  dim3 grid((unsigned)(tiles < 2048 ? tiles : 2048), (unsigned)(a.NOUT / slice));
+  switch (slice) {
+    case 32: rowgemm_mfma_kernel<KP, 1, 1, 0, 0, true><<<grid, 256, 0, st>>>(a); break;
+    case 64: rowgemm_mfma_kernel<KP, 2, 1, 0, 0, true><<<grid, 256, 0, st>>>(a); break;
+    case 128: rowgemm_mfma_kernel<KP, 4, 1, 0, 0, true><<<grid, 256, 0, st>>>(a); break;
+  }
 }
 
 template <int KP>
@@ -212,10 +228,10 @@ bool launch_rowgemm_blocks(const float *X, int ldx, int N, int64_t M, const floa
     GemmArgs a{X + off, ldx, (accumulate || off > 0) ? 1 : 0, M, Wt + (size_t)off * NOUT, NOUT, Y,
                nullptr, nullptr, nullptr, g.edge_a, g.edge_b, g.N, g.E};
     switch (bk) {
-      case 16: launch_mfma_kp<16>(a, 0, 0, st); break;
-      case 32: launch_mfma_kp<32>(a, 0, 0, st); break;
-      case 64: launch_mfma_kp<64>(a, 0, 0, st); break;
-      case 128: launch_mfma_kp<128>(a, 0, 0, st); break;
+      case 16: launch_mfma_ext<16>(a, st); break;
+      case 32: launch_mfma_ext<32>(a, st); break;
+      case 64: launch_mfma_ext<64>(a, st); break;
+      case 128: launch_mfma_ext<128>(a, st); break;
     }
   }
   return true;
