@@ -58,6 +58,11 @@ wv, inten = spec.measure(laser_correction=True, laser_wavelength=532)
 out["config4"] = {"modes": 3 * n, "displaced_cells": 6 * n, "seconds": dt,
                   "structures_per_s_f64": 6 * n / dt,
                   "raman_tensor_rms": float(np.sqrt((spec.raman_tensors ** 2).mean()))}
+t = time.perf_counter()
+analytic = model.calc_raman_tensors(ref, disp, method="analytic")
+out["config4"]["analytic_seconds"] = time.perf_counter() - t
+out["config4"]["analytic_vs_fd_rel"] = float(
+    np.abs(analytic - spec.raman_tensors).max() / np.abs(spec.raman_tensors).max())
 # fp32 finite differences for comparison (the reference's default precision): noise level
 plus = model.calc_polarizabilities(ref[None] + disp[:8] * 1e-3)
 minus = model.calc_polarizabilities(ref[None] - disp[:8] * 1e-3)
