@@ -92,9 +92,26 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         self._atom_type_map = graph_utils.atom_type_map(ref_structure.atomic_numbers)
         self._num_atom_types = int((self._atom_type_map >= 0).sum())
 
-        # parameters, created in the reference's module order so that the same
-        # torch.manual_seed gives the same initial weights (_gnn.py:508-539)
+        self._gaussian_filter = (float(gaussian_filter_start), float(gaussian_filter_end))
+        if self._fe < 2:
+            raise ValueError("invalid size_edge_embedding: the Gaussian filter needs >= 2 steps")
+        state = self._fresh_state()
+        offset = state["_edge_embedding.offset"]
+        self._gauss_coefficient = -0.5 / (float(offset[1]) - float(offset[0])) ** 2  # _gnn.py:64
+        # trainable entries become torch Parameters (so torch.optim works on them); buffers
+        # (Gaussian offsets, BatchNorm running statistics) stay plain tensors
+        self._state = OrderedDict(
+            (k, torch.nn.Parameter(v) if self._is_trainable(k) else v) for k, v in state.items())
+        self._handle = None
+        self._profiling = 0
+        self._uploaded_version = None
+        self.training = True  # like a fresh torch Module; calc_polarizabilities switches to eval
+
+    def _fresh_state(self) -> "OrderedDict[str, torch.Tensor]":
+        """Freshly initialised tensors, created in the reference's module order so that the
+        same ``torch.manual_seed`` gives the same initial weights (_gnn.py:508-539)."""
         fn, fe, k = self._fn, self._fe, self._num_atom_types
+        gaussian_filter_start, gaussian_filter_end = self._gaussian_filter
         state: "OrderedDict[str, torch.Tensor]" = OrderedDict()
 
         def add(prefix, module):
@@ -106,9 +123,6 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         add("_node_embedding.4", torch.nn.Linear(fn, fn))
         offset = torch.linspace(gaussian_filter_start, gaussian_filter_end, fe, dtype=torch.float32)
         state["_edge_embedding.offset"] = offset
-        if fe < 2:
-            raise ValueError("invalid size_edge_embedding: the Gaussian filter needs >= 2 steps")
-        self._gauss_coefficient = -0.5 / (float(offset[1]) - float(offset[0])) ** 2  # _gnn.py:64
         for p in range(self._passes):
             add(f"_node_blocks.{p}.c1_linear", torch.nn.Linear(fn + fe, 2 * fn))
             add(f"_node_blocks.{p}.c1_norm", torch.nn.LayerNorm(2 * fn))
@@ -124,14 +138,11 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         add("_to_polarizability_embedding.1", torch.nn.BatchNorm1d(fe))
         add("_to_polarizability_embedding.3", torch.nn.Linear(fe, fe))
         add("_to_polarizability_embedding.5", torch.nn.Linear(fe, 12))
-        # trainable entries become torch Parameters (so torch.optim works on them); buffers
-        # (Gaussian offsets, BatchNorm running statistics) stay plain tensors
-        self._state = OrderedDict(
-            (k, torch.nn.Parameter(v) if self._is_trainable(k) else v) for k, v in state.items())
-        self._handle = None
-        self._profiling = 0
-        self._uploaded_version = None
-        self.training = True  # like a fresh torch Module; calc_polarizabilities switches to eval
+        return state
+
+    def reset_parameters(self) -> None:
+        """Re-initialise every parameter and buffer (``_gnn.py:559-566``)."""
+        self.load_state_dict(self._fresh_state())
 
     # ------------------------------------------------------------------ properties
     @property

@@ -312,3 +312,23 @@ def test_parameters_apply_and_modes():
     model.parameters()[0].grad = torch.ones_like(model.parameters()[0])
     opt.step()
     assert not torch.equal(model.state_dict()["_node_embedding.0.weight"], before["_node_embedding.0.weight"])
+
+
+def test_reset_parameters():
+    """(reference: test/tests/torch/test_gnn.py:116-120)"""
+    model = product_model_from_golden(load_golden("triclinic20"))
+    before = model.state_dict()
+    params = model.parameters()
+    torch.manual_seed(11)
+    model.reset_parameters()
+    after = model.state_dict()
+    assert not torch.equal(before["_node_blocks.0.c1_linear.weight"], after["_node_blocks.0.c1_linear.weight"])
+    assert torch.equal(after["_node_blocks.1.final_norm.weight"], torch.ones(8))
+    assert torch.equal(after["_to_polarizability_embedding.1.running_var"], torch.ones(12))
+    assert all(a is b for a, b in zip(params, model.parameters()))
+    torch.manual_seed(11)
+    from ramannoodle_amd.pmodel import PotGNN
+    g = load_golden("triclinic20")
+    fresh = PotGNN(_ref(), 3.0, 8, 12, 2, 0.0, 4.0, g["mean"], g["std"]).state_dict()
+    for k in after:
+        assert torch.equal(after[k], fresh[k]), k
