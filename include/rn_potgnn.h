@@ -56,6 +56,15 @@ typedef struct rn_potgnn_config {
   int32_t device;               /* HIP device ordinal                                   */
 } rn_potgnn_config;
 
+/*
+ * One-time neighbour search of the reference structure on the device; replaces the pair
+ * test of _radius_graph_pbc (ramannoodle/pmodel/torch/_utils.py:118-137): float32
+ * minimum-image distances, adjacency[a*N + b] = (dist <= cutoff && a != b) as host uint8.
+ * Compacting the flags row-major gives the edge list sorted by (a, b).
+ */
+int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32_t num_atoms,
+                           double cutoff, int device, uint8_t *adjacency);
+
 /* Number of floats rn_potgnn_create expects in `weights` for this configuration. */
 size_t rn_potgnn_weight_count(const rn_potgnn_config *cfg);
 

@@ -1483,6 +1483,34 @@ int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
   return guarded(h, [&]() { train_backward(h, dvec6, grads); });
 }
 
+int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32_t num_atoms,
+                           double cutoff, int device, uint8_t *adjacency) {
+  if (!lattice || !positions || !adjacency || num_atoms <= 0 || !(cutoff > 0)) {
+    set_error(nullptr, "invalid arguments to radius_graph");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error(nullptr, "no usable HIP device (count=%d, requested=%d)", ndev, device);
+    return RN_ERR_NO_DEVICE;
+  }
+  return guarded(nullptr, [&]() {
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)num_atoms;
+    DeviceBuf lat, pos, adj;
+    lat.ensure(9 * sizeof(double));
+    pos.ensure(n * 3 * sizeof(double));
+    adj.ensure(n * n);
+    HIP_TRY(hipMemcpy(lat.p, lattice, 9 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pos.p, positions, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    launch_radius_graph(lat.as<double>(), pos.as<double>(), num_atoms, (float)cutoff,
+                        adj.as<unsigned char>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(adjacency, adj.p, n * n, hipMemcpyDeviceToHost));
+  });
+}
+
 int64_t rn_potgnn_num_triplets(const rn_potgnn *h) { return h ? h->g.T : -1; }
 
 int rn_potgnn_debug_triplets(rn_potgnn *h, int32_t *idx_i, int32_t *idx_j, int32_t *idx_k,

@@ -105,6 +105,9 @@ void launch_readout_reduce(const T *pol, const T *unit4, int S, const Graph &g,
                            const double *mean9, const double *std9, float *vec6,
                            double *alpha, double *alpha_raw, hipStream_t st);
 
+void launch_radius_graph(const double *lattice, const double *pos, int N, float cutoff,
+                         unsigned char *adjacency, hipStream_t st);
+
 void launch_enum_triplets(const Graph &g, int *idx_i, int *idx_j, int *idx_k, int *slot5,
                           int *slot6, hipStream_t st);
 

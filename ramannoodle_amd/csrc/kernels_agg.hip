@@ -734,6 +734,33 @@ template void launch_readout_reduce<double>(const double *, const double *, int,
                                             const double *, const double *, float *, double *,
                                             double *, hipStream_t);
 
+// ============================================================================ radius graph
+// One-time neighbour search of the reference structure (_utils.py:118-137): all N^2
+// minimum-image pair distances in float32 with the reference's operation order,
+// adjacency[a*N + b] = (dist <= cutoff && a != b).  The host compacts the flags
+// (row-major nonzero == edges sorted by (a, b)).
+__global__ void radius_graph_kernel(const double *__restrict__ lattice, const double *__restrict__ pos,
+                                    int N, float cutoff, unsigned char *__restrict__ adjacency) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * N) return;
+  const int a = (int)(idx / N), b = (int)(idx % N);
+  float f[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = wrap_min_image((float)pos[b * 3 + k] - (float)pos[a * 3 + k]);
+  float c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    c[k] = f[0] * (float)lattice[k] + f[1] * (float)lattice[3 + k] + f[2] * (float)lattice[6 + k];
+  const float dist = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  adjacency[idx] = (dist <= cutoff && a != b) ? 1 : 0;
+}
+void launch_radius_graph(const double *lattice, const double *pos, int N, float cutoff,
+                         unsigned char *adjacency, hipStream_t st) {
+  const int64_t total = (int64_t)N * N;
+  if (total == 0) return;
+  radius_graph_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lattice, pos, N, cutoff, adjacency);
+}
+
 // ============================================================================ triplet listing
 // Emits the triplets in exactly the order edge_agg_kernel consumes them (grouped by
 // destination edge, then ascending source edge).  Test/introspection only.

@@ -30,6 +30,26 @@ def radius_graph_pbc(lattice: np.ndarray, positions: np.ndarray, cutoff: float,
     return np.stack([a, b]).astype(np.int64)
 
 
+def radius_graph_pbc_device(lattice: np.ndarray, positions: np.ndarray, cutoff: float,
+                            device: int = 0) -> np.ndarray:
+    """Same edge list from the HIP kernel (``rn_potgnn_radius_graph``): the N^2 pair test
+    runs on the device, the flag compaction on the host."""
+    import ctypes as C
+
+    from ramannoodle_amd import _lib
+
+    lib = _lib.load()
+    lat = np.ascontiguousarray(lattice, dtype=np.float64)
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    n = pos.shape[0]
+    adjacency = np.zeros((n, n), dtype=np.uint8)
+    rc = lib.rn_potgnn_radius_graph(C.c_void_p(lat.ctypes.data), C.c_void_p(pos.ctypes.data), n,
+                                    float(cutoff), int(device), C.c_void_p(adjacency.ctypes.data))
+    _lib.check(rc, None, "rn_potgnn_radius_graph")
+    a, b = np.nonzero(adjacency)
+    return np.stack([a, b]).astype(np.int64)
+
+
 def atom_type_map(atomic_numbers) -> np.ndarray:
     """``int32[119]`` atomic number -> type index, -1 when absent.  Type indices follow
     Python ``set`` iteration order, as the reference does

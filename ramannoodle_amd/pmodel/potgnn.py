@@ -87,7 +87,14 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         self._max_chunk = int(max_chunk_structures)
 
         # frozen graph of the reference structure (_gnn.py:489-499)
-        edges = graph_utils.radius_graph_pbc(ref_structure.lattice, ref_structure.positions, cutoff)
+        # (pair test on the device when there is one; the numpy restatement of the same float32
+        # arithmetic serves GPU-less hosts, e.g. unit tests -- both are pinned by the fixtures)
+        if torch.cuda.is_available():
+            dev = device if device is not None else torch.cuda.current_device()
+            edges = graph_utils.radius_graph_pbc_device(ref_structure.lattice, ref_structure.positions,
+                                                        cutoff, dev)
+        else:
+            edges = graph_utils.radius_graph_pbc(ref_structure.lattice, ref_structure.positions, cutoff)
         self._ref_edge_indexes = np.vstack([np.zeros((1, edges.shape[1]), dtype=np.int64), edges])
         self._atom_type_map = graph_utils.atom_type_map(ref_structure.atomic_numbers)
         self._num_atom_types = int((self._atom_type_map >= 0).sum())
