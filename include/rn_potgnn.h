@@ -179,6 +179,10 @@ int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads);
 
 /* ------------------------------------------------------------------ introspection */
 
+/* Introspection: bit 0 = the fused EdgeBlock kernel is in use (float32, Fn and Fe padded to
+ * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop. */
+int rn_potgnn_config_flags(const rn_potgnn *h);
+
 /* Number of edge triplets T of the frozen graph. */
 int64_t rn_potgnn_num_triplets(const rn_potgnn *h);
 

@@ -41,6 +41,7 @@ class Config(C.Structure):
 _P = C.c_void_p
 SIGNATURES = {
     "rn_potgnn_radius_graph": (C.c_int, [_P, _P, C.c_int32, C.c_double, C.c_int, _P]),
+    "rn_potgnn_config_flags": (C.c_int, [_P]),
     "rn_potgnn_weight_count": (C.c_size_t, [C.POINTER(Config)]),
     "rn_potgnn_create": (C.c_int, [C.POINTER(Config), _P, _P, _P, _P, _P, C.c_size_t, _P, _P,
                                    C.POINTER(_P)]),

@@ -364,6 +364,30 @@ size_t per_structure_elems(const rn_potgnn *h) {
   return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA + E * 4 * FeP;
 }
 
+// Per pass: may the EdgeBlock's triplet loop fold c3_norm_1's scale into its operands and
+// drop the gate's overflow clamp (edge_agg_kernel, FASTG)?  Needs every gamma of a real
+// column away from zero (the loop divides by it) and the gate arguments provably small:
+// a LayerNorm output is at most sqrt(2Fe - 1) in magnitude.
+template <typename T>
+void refresh_pass_flags(rn_potgnn *h) {
+  Precision<T> &P = prec<T>(h);
+  const PackedLayout &L = h->lay;
+  const int Fe = h->d.Fe, FeP = h->d.FeP;
+  const bool off = getenv("RN_POTGNN_NO_FASTG") && atoi(getenv("RN_POTGNN_NO_FASTG")) != 0;
+  for (size_t p = 0; p < L.pass.size() && p < P.pass.size(); ++p) {
+    const float *gam = h->packed.data() + L.pass[p].c3n1_g, *bet = h->packed.data() + L.pass[p].c3n1_b;
+    const double xmax = std::sqrt(2.0 * Fe) * 1.02;
+    bool ok = !off;
+    for (int half = 0; half < 2 && ok; ++half)
+      for (int k = 0; k < Fe && ok; ++k) {
+        const double g = std::fabs((double)gam[half * FeP + k]), b = std::fabs((double)bet[half * FeP + k]);
+        const double arg = (g * xmax + b) * 2.0 * 1.4426950408889634;
+        ok = std::isfinite(g) && std::isfinite(b) && g >= 1e-5 && arg < 60.0;
+      }
+    P.pass[p].c3_fast = ok ? 1 : 0;
+  }
+}
+
 template <typename T>
 void upload_weights(rn_potgnn *h) {  // (re)upload the packed weights and redo the device precompute
   Precision<T> &P = prec<T>(h);
@@ -378,6 +402,7 @@ void upload_weights(rn_potgnn *h) {  // (re)upload the packed weights and redo t
                   w + L.scale0, w + L.shift0, P.lanes[0].stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(P.lanes[0].stream));
+  refresh_pass_flags<T>(h);
 }
 
 template <typename T>
@@ -413,6 +438,7 @@ void ensure_precision(rn_potgnn *h) {
     o.c3_norm_1 = {w + q.c3n1_g, w + q.c3n1_b};
     o.c3_norm_2 = {w + q.c3n2_g, w + q.c3n2_b};
   }
+  refresh_pass_flags<T>(h);
   P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5};
   P.offsets = w + L.offsets;
   P.node_table = w + L.node_table;
@@ -1189,34 +1215,73 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     for (int e = 0; e < E; ++e) h->in_edge[fill[edge_b[e]]++] = e;  // ascending edge id per b
   }
   const Dims d = h->d;
-  // node tiles: consecutive atoms whose outgoing-edge rows fit the LDS budget
-  // (budget counted in float32 rows; the float64 path uses twice the bytes for the same tiles)
-  // 64 KiB tiles for wide embeddings (8 columns per lane: 32 destinations per round, two
-  // workgroups per CU), 36 KiB otherwise (three to four workgroups per CU)
-  const bool vpl8 = getenv("RN_POTGNN_VPL") && atoi(getenv("RN_POTGNN_VPL")) == 8;
-  const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB"))
-                                                     : ((d.FeP >= 64 && vpl8) ? 64 : 36);
-  const size_t budget_rows = std::max<size_t>(1, tile_kb * 1024 / ((size_t)2 * d.FeP * sizeof(float)));
+  // node tiles: consecutive atoms whose outgoing-edge rows fit an LDS budget (counted in
+  // float32 rows; the float64 path uses twice the bytes for the same tiles).  A workgroup
+  // serves its tile's destination edges G at a time (G lane groups), so the budget is chosen
+  // to waste as few lane groups in the last round as possible (18 in-edges per atom and
+  // G = 16: 4 atoms per tile idle 10 % of the groups, 6 atoms 4 %).
+  const size_t row_bytes = (size_t)2 * d.FeP * sizeof(float);
   const size_t cap_rows = (size_t)150 * 1024 / ((size_t)2 * d.FeP * sizeof(double) + 4);
-  int max_rows = 0;
-  h->tile_begin.push_back(0);
-  {
-    int rows = 0;
+  for (int n = 0; n < N; ++n) {
+    const int deg = h->out_ptr[n + 1] - h->out_ptr[n];
+    if ((size_t)deg > cap_rows) {
+      set_error(nullptr, "atom %d has %d outgoing edges; more than %zu per atom is unsupported", n,
+                deg, cap_rows);
+      return RN_ERR_UNSUPPORTED;
+    }
+  }
+  auto build_tiles = [&](size_t budget_rows, std::vector<int> &tb) {
+    tb.assign(1, 0);
+    int rows = 0, max_rows = 0;
     for (int n = 0; n < N; ++n) {
       const int deg = h->out_ptr[n + 1] - h->out_ptr[n];
-      if ((size_t)deg > cap_rows) {
-        set_error(nullptr, "atom %d has %d outgoing edges; more than %zu per atom is unsupported",
-                  n, deg, cap_rows);
-        return RN_ERR_UNSUPPORTED;
-      }
       if (rows > 0 && (size_t)(rows + deg) > budget_rows) {
-        h->tile_begin.push_back(n);
+        tb.push_back(n);
         rows = 0;
       }
       rows += deg;
       max_rows = std::max(max_rows, rows);
     }
-    h->tile_begin.push_back(N);
+    tb.push_back(N);
+    return max_rows;
+  };
+  const bool vpl8 = getenv("RN_POTGNN_VPL") && atoi(getenv("RN_POTGNN_VPL")) == 8;
+  // fused EdgeBlock (kernels_fused.hip): its LDS footprint bounds the tile instead
+  const bool want_fused = getenv("RN_POTGNN_FUSED") && atoi(getenv("RN_POTGNN_FUSED")) != 0;
+  const bool fused_mode = want_fused && d.FnP == 64 && d.FeP == 64;
+  int max_rows = 0;
+  if (getenv("RN_POTGNN_TILE_KB") || vpl8) {
+    const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB")) : 64;
+    max_rows = build_tiles(std::max<size_t>(1, tile_kb * 1024 / row_bytes), h->tile_begin);
+  } else {
+    // relative cost of one frame = (rounds of the slowest tile) x (tiles sharing the chip),
+    // among budgets whose whole LDS footprint stays within 64 KiB (measured: beyond that
+    // only one workgroup per CU runs)
+    const int G = 256 / std::max(1, d.FeP / 4);
+    double best = 0;
+    std::vector<int> tb;
+    for (size_t kb = 8; kb <= 62; kb += 2) {
+      const int mr = build_tiles(std::max<size_t>(1, kb * 1024 / row_bytes), tb);
+      int rounds = 1, max_in = 0, max_nodes = 0;
+      for (size_t t = 0; t + 1 < tb.size(); ++t) {
+        const int din = h->in_ptr[tb[t + 1]] - h->in_ptr[tb[t]];
+        rounds = std::max(rounds, (din + G - 1) / G);
+        max_in = std::max(max_in, din);
+        max_nodes = std::max(max_nodes, tb[t + 1] - tb[t]);
+      }
+      const size_t lds = fused_mode ? edge_fused_lds_bytes(mr, max_in, max_nodes)
+                                    : (size_t)mr * (row_bytes + 4) + (size_t)max_nodes * row_bytes +
+                                          (size_t)12 * d.FeP * 4 + (size_t)mr * 4 + (size_t)max_in * 24 + 96;
+      // unfused: two aggregation workgroups + one projection workgroup (34 KiB) share a CU
+      const size_t lds_cap = fused_mode ? kFusedLdsBudget : (size_t)63 * 1024;
+      if (lds > lds_cap && !h->tile_begin.empty()) break;
+      const double cost = (double)rounds * (double)(tb.size() - 1);
+      if (h->tile_begin.empty() || cost < best * 0.995) {
+        best = cost;
+        h->tile_begin = tb;
+        max_rows = mr;
+      }
+    }
   }
   h->trip_off.assign(E + 1, 0);
   for (int e = 0; e < E; ++e) {
@@ -1297,7 +1362,6 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     hp->chunk = chunk;
     // The single-launch fused EdgeBlock (kernels_fused.hip) is opt-in: on MI355X it is
     // slower than projections + edge_agg (weights pinned in VGPRs cap it at 2 waves/SIMD).
-    const bool want_fused = getenv("RN_POTGNN_FUSED") && atoi(getenv("RN_POTGNN_FUSED")) != 0;
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
     ensure_precision<float>(hp);
   });
@@ -1509,6 +1573,14 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(adjacency, adj.p, n * n, hipMemcpyDeviceToHost));
   });
+}
+
+int rn_potgnn_config_flags(const rn_potgnn *h) {
+  if (!h) return -1;
+  int flags = h->use_fused ? 1 : 0;
+  bool fast = !h->f32.pass.empty();
+  for (const auto &p : h->f32.pass) fast = fast && p.c3_fast;
+  return flags | (fast ? 2 : 0);
 }
 
 int64_t rn_potgnn_num_triplets(const rn_potgnn *h) { return h ? h->g.T : -1; }

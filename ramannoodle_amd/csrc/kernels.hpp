@@ -1,6 +1,8 @@
 // Kernel launch interface between api.hip (host orchestration) and the kernel TUs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstddef>
 #include <cstdint>
 
 namespace rn {
@@ -48,6 +50,7 @@ struct PassW {
   const T *c3_WeT;   // [FeP][4FeP]   (W_4 | W_5) edge parts: dest-edge | source-edge
   Ln<T> c3_norm_1;   // [2FeP]
   Ln<T> c3_norm_2;   // [FeP]
+  int c3_fast;       // host-side decision: c3_norm_1 admits the folded-scale triplet loop
 };
 
 template <typename T>
@@ -156,6 +159,10 @@ void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *l
                      T coef, int C, int B, const Graph &g, Dims d, double *dpos, hipStream_t st);
 
 // Fused EdgeBlock (kernels_fused.hip): projections + triplet aggregation in one launch.
+// Fused EdgeBlock (kernels_fused.hip): float32, FnP == FeP == 64.  Two workgroups per CU
+// need their LDS footprint within this budget.
+constexpr size_t kFusedLdsBudget = 80 * 1024;
+size_t edge_fused_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
 bool edge_fused_supported(const Graph &g, Dims d);
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
                        int S, const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);

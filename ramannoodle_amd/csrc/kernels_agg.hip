@@ -350,7 +350,12 @@ __device__ __forceinline__ void ln_rowv(T (&x)[VPL], const T *gam, const T *bet,
 #ifndef RN_AGG_WAVES
 #define RN_AGG_WAVES 3
 #endif
-template <int FP, int VPL, bool PAD, typename T, bool TAPE = false>
+// `FASTG` (float32, chosen per pass on the host from the c3_norm_1 parameters): the
+// LayerNorm scale is folded into the operands -- LDS holds q*gamma, registers hold p*gamma
+// and p/gamma (so p.q is still one fma per column) -- and the overflow clamp of the gate is
+// dropped because |gamma| sqrt(2Fe) + |beta| bounds its argument; 5 VALU instructions
+// fewer per triplet and column pair.
+template <int FP, int VPL, bool PAD, typename T, bool TAPE = false, bool FASTG = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_WAVES))) void edge_agg_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
     const T *__restrict__ edge_in, T *__restrict__ edge_out, int S, Graph g, Dims d, PassW<T> w,
@@ -366,11 +371,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_W
     off += (bytes + 15) & ~size_t(15);
     return p;
   };
-  T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));  // centred Q' rows
-  T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));               // |q|^2
+  constexpr int RS = 2 * FP;
+  T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * RS * sizeof(T)));  // centred Q' rows
+  T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));           // |q|^2
   T *nj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));      // Wj node[j] + bias
   // per-destination LayerNorm parameters (read once per destination: keep them out of VGPRs)
-  T *lnp = reinterpret_cast<T *>(carve((size_t)8 * FP * sizeof(T)));
+  T *lnp = reinterpret_cast<T *>(carve((size_t)12 * FP * sizeof(T)));
+  T *s_g3 = lnp + 8 * FP, *s_ig3 = lnp + 10 * FP;  // FASTG: scaled gamma of c3_norm_1, 1/gamma
   T *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
     *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP;
   int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));                   // b_e
@@ -380,6 +387,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_W
   for (int c = threadIdx.x; c < 2 * FP; c += 256) {
     s_c2n1g[c] = w.c2_norm_1.g[c];
     s_c2n1b[c] = w.c2_norm_1.b[c];
+    if (FASTG) {
+      const T gam = w.c3_norm_1.g[c] * (c < FP ? GateScale<T>::kF : GateScale<T>::kC);
+      s_g3[c] = gam;
+      s_ig3[c] = ((c % FP) < d.Fe) ? (T)1 / gam : (T)0;
+    }
     if (c < FP) {
       s_c3n2g[c] = w.c3_norm_2.g[c];
       s_c3n2b[c] = w.c3_norm_2.b[c];
@@ -460,8 +472,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_W
         ss += f[k] * f[k] + c[k] * c[k];
       }
       ss = lg_sum<LG>(ss);
-      storev<VPL>(qrows + (size_t)r * 2 * FP + c0, f);
-      storev<VPL>(qrows + (size_t)r * 2 * FP + FP + c0, c);
+      if (FASTG) {
+        T sgf[VPL], sgc[VPL];
+        loadv<VPL>(sgf, s_g3 + c0);
+        loadv<VPL>(sgc, s_g3 + FP + c0);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+          f[k] *= sgf[k];
+          c[k] *= sgc[k];
+        }
+        ss *= inv2n;
+      }
+      storev<VPL>(qrows + (size_t)r * RS + c0, f);
+      storev<VPL>(qrows + (size_t)r * RS + FP + c0, c);
       if (q == 0) sq[r] = ss;
     }
     __syncthreads();
@@ -520,19 +543,61 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_W
       T acc[VPL];
 #pragma unroll
       for (int k = 0; k < VPL; ++k) acc[k] = 0;
+      if constexpr (FASTG) {
+        // pd = p/gamma * (2/2Fe), pg = p*gamma; var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
+        T pdf[VPL], pdc[VPL];
+        {
+          T sgf[VPL], sgc[VPL], igf[VPL], igc[VPL];
+          loadv<VPL>(sgf, s_g3 + c0);
+          loadv<VPL>(sgc, s_g3 + FP + c0);
+          loadv<VPL>(igf, s_ig3 + c0);
+          loadv<VPL>(igc, s_ig3 + FP + c0);
+          const T two_inv = (T)2 * inv2n;
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) {
+            pdf[k] = pf[k] * igf[k] * two_inv;
+            pdc[k] = pc[k] * igc[k] * two_inv;
+            pf[k] *= sgf[k];
+            pc[k] *= sgc[k];
+          }
+        }
+        const T spe = sp * inv2n + (T)1e-5;
+        for (int t = 0; t < cnt; ++t) {
+          const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
+          const T *qr = qrows + (size_t)r * RS + c0;
+          T qf[VPL], qc[VPL];
+          loadv<VPL>(qf, qr);
+          loadv<VPL>(qc, qr + FP);
+          const T sqr = sq[r];
+          T dot = 0;
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) dot += pdf[k] * qf[k] + pdc[k] * qc[k];
+          dot = lg_sum<LG>(dot);
+          T ve = dot + (spe + sqr);
+          ve = ve > (T)1e-5 ? ve : (T)1e-5;
+          const T rstd = fast_rsq(ve);
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) {
+            const T e1 = fast_exp2((pf[k] + qf[k]) * rstd + b3f[k]);
+            const T e2 = fast_exp2((pc[k] + qc[k]) * rstd + b3c[k]);
+            acc[k] += (e2 - (T)1) * fast_rcp(((T)1 + e1) * ((T)1 + e2));
+          }
+        }
+      } else {
       for (int t = 0; t < cnt; ++t) {
         const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
-        const T *qr = qrows + (size_t)r * 2 * FP + c0;
+        const T *qr = qrows + (size_t)r * RS + c0;
         T qf[VPL], qc[VPL];
         loadv<VPL>(qf, qr);
         loadv<VPL>(qc, qr + FP);
+        const T sqr = sq[r];
         T dot = 0;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) dot += pf[k] * qf[k] + pc[k] * qc[k];
 #if RN_EXPERIMENT != 2  // timing-only variant 2: no cross-lane reduction
         dot = lg_sum<LG>(dot);
 #endif
-        T var = (sp + sq[r] + (T)2 * dot) * inv2n;
+        T var = (sp + sqr + (T)2 * dot) * inv2n;
         var = var > (T)0 ? var : (T)0;
         const T rstd = fast_rsq(var + (T)1e-5);
 #pragma unroll
@@ -541,6 +606,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : (VPL == 8 ? 2 : RN_AGG_W
           const T yc = ((pc[k] + qc[k]) * rstd) * g3c[k] + b3c[k];
           acc[k] += gate_exp2(yf, yc);
         }
+      }
       }
       if (TAPE) storev<VPL>(agg_out + (erow0 + d_edge[i]) * FP + c0, acc);
       ln_rowv<LG, VPL, PAD>(acc, s_c3n2g + c0, s_c3n2b + c0, invn, nvalid);  // c3 (_gnn.py:291)
@@ -613,7 +679,7 @@ static int agg_vpl() {
 size_t edge_agg_lds_bytes(const Graph &g, Dims d, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   return up((size_t)g.max_tile_out_rows * 2 * d.FeP * elem) + up((size_t)g.max_tile_out_rows * elem) +
-         up((size_t)g.max_tile_nodes * 2 * d.FeP * elem) + up((size_t)8 * d.FeP * elem) +
+         up((size_t)g.max_tile_nodes * 2 * d.FeP * elem) + up((size_t)12 * d.FeP * elem) +
          up((size_t)g.max_tile_out_rows * 4) + up((size_t)g.max_tile_in_rows * 6 * 4);
 }
 
@@ -624,7 +690,10 @@ static void launch_edge_agg_cfg(const T *pq, const T *np3, const T *c2pre, const
   // Persistent workgroups: one per (tile, frame group).  The grid is sized to exactly the
   // number of workgroups the chip holds at once (a partial second round would leave two
   // thirds of the CUs idle: measured 2.25 instead of 3 waves/SIMD).
-  auto kern = agg_out ? &edge_agg_kernel<FP, VPL, PAD, T, true> : &edge_agg_kernel<FP, VPL, PAD, T, false>;
+  constexpr bool kFloat = sizeof(T) == 4;
+  auto kern = agg_out ? &edge_agg_kernel<FP, VPL, PAD, T, true, false>
+                      : ((kFloat && w.c3_fast) ? &edge_agg_kernel<FP, VPL, PAD, T, false, kFloat>
+                                               : &edge_agg_kernel<FP, VPL, PAD, T, false, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,22 +1,31 @@
-// Fused EdgeBlock for gfx950 (Fn and Fe padded to the same width FP = 64).
+// Fused EdgeBlock for gfx950 (float32, Fn and Fe padded to the same width FP = 64).
 //
-// One persistent workgroup per (frame, atom tile) work item computes, without any
-// intermediate leaving the CU:
-//   Q'_e = W5 edge_e + Wi node[b_e]            for the edges e leaving the tile's atoms
-//   P'_d = W4 edge_d + Wj node[b_d] + Wk node[a_d] + bias   for the edges d entering them
+// One persistent workgroup per (atom tile, frame group) computes, without any projection
+// leaving the CU:
+//   Q'_e = W5 edge_e + Wi node[b_e]                        edges e leaving the tile's atoms
+//   P'_d = W4 edge_d + Wj node[b_d] + Wk node[a_d] + bias  edges d entering them
 //   c2_d = c2_linear(node[b_d] * node[a_d])
-// by exact-fp32 MFMA (v_mfma_f32_16x16x4_f32; the three weight matrices stay in VGPRs as
-// B-fragments for the whole kernel), and then the triplet stage of _EdgeBlock
-// (_gnn.py:270-291): add -> LayerNorm(2Fe) -> sigmoid*tanh -> sum over e, LayerNorm(Fe),
-// plus c2 (_gnn.py:223-228) and the residual tanh (_gnn.py:351).
+// by exact-fp32 MFMA (v_mfma_f32_16x16x4_f32; W4 and the c2 weight stay in VGPRs as
+// B-fragments for the whole kernel, W5 is re-read from L2 once per frame), then the
+// triplet stage of _EdgeBlock (_gnn.py:270-291): add -> LayerNorm(2Fe) -> sigmoid*tanh ->
+// sum over e -> LayerNorm(Fe), plus c2 (_gnn.py:223-228) and the residual tanh
+// (_gnn.py:351).  The node terms (Wi|Wj|Wk) node come from the small per-atom projection
+// `np3` as in the unfused path.
 //
-// Compared with the unfused kernels (kernels_gemm.hip + edge_agg_kernel) this removes the
-// [S*E, 4Fe] and [S*E, 2Fe] projection arrays from HBM (4.9x the algorithmic bytes) and
-// lets the MFMA pipe of one workgroup overlap the VALU pipe of the other on the same CU.
+// Against projections + edge_agg_kernel this removes the [S*E, 4Fe] and [S*E, 2Fe] arrays
+// from HBM (3.5 MB written and read again per structure and pass) and lets the matrix
+// pipe of one workgroup run under the VALU-bound triplet loop of the other on the same CU.
 //
-// LayerNorm of x = P' + Q' uses pre-centred rows: with p = P' - mean(P'), q = Q' - mean(Q')
-//   x - mean(x) = p + q,   sum (x - mean)^2 = |p|^2 + |q|^2 + 2 p.q
-// so each triplet needs ONE 16-lane DPP reduction (p.q) instead of two.
+// Structure of one frame (S1/S2 = workgroup barriers):
+//   stage:  Q' tile by MFMA -> LDS; centre rows, |q|^2                      (2 barriers)
+//   round r (16 destination edges, one per 16-lane group):
+//     MFMA   A operands (edge row, node[b], node[a] rows of the 16 destinations) are read
+//            from LDS tiles that the PREVIOUS round filled by LDS-DMA (global_load_lds,
+//            XOR-swizzled through the per-lane source address); P' and c2 -> LDS     S1
+//     DMA    issue the next round's (or next frame's first round's) operand rows
+//     VALU   triplet loop of the unfused kernel on LDS operands, epilogue, store     S2
+// The tile topology lives in LDS for the whole launch (the graph is the same in every
+// frame), so no load inside the frame loop has a dependent address.
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -35,51 +44,126 @@ struct EdgeFusedArgs {
   PassW<float> w;
 };
 
+namespace {
+constexpr int FP = 64;
+constexpr int LG = 16;            // lanes per row in the VALU phase
+constexpr int NG = 16;            // lane groups per workgroup = destinations per round
+constexpr int KS = 16;            // k values per lane of an MFMA operand (64 / 4 lane quads)
+constexpr int LDQ = 2 * FP + 4;   // LDS row stride of the pre-activation rows (floats)
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int FP>
-__global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs a) {
-  static_assert(FP == 64, "column ownership below assumes 2*FP = 4 waves x 32 columns");
-  constexpr int LG = FP / 4;       // lanes per row in the VALU phase (16)
-  constexpr int KS = FP / 4;       // k per lane quad (16)
-  constexpr int LDQ = 2 * FP + 4;  // LDS row stride (floats)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float *bufQ = reinterpret_cast<float *>(smem_raw);       // [maxRows][LDQ] centred source rows
-  float *bufP = bufQ + (size_t)a.g.max_tile_out_rows * LDQ;  // [16][LDQ]
-  float *bufC = bufP + 16 * LDQ;                           // [16][LDQ]
-  float *sq = bufC + 16 * LDQ;                             // [maxRows] |q|^2
-  int *qb = reinterpret_cast<int *>(sq + a.g.max_tile_out_rows);  // [maxRows] b_e
+struct FusedLds {
+  size_t bufQ, bufP, bufC, atile, sq, nj, lnp, ints, total;
+};
+__host__ __device__ inline FusedLds fused_lds(int maxR, int maxD, int maxN) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  FusedLds L;
+  size_t off = 0;
+  L.bufQ = off; off += up((size_t)maxR * LDQ * 4);
+  L.bufP = off; off += up((size_t)NG * LDQ * 4);
+  L.bufC = off; off += up((size_t)NG * LDQ * 4);
+  L.atile = off; off += 3 * (size_t)NG * FP * 4;
+  L.sq = off; off += up((size_t)maxR * 4);
+  L.nj = off; off += up((size_t)maxN * 2 * FP * 4);
+  L.lnp = off; off += (size_t)12 * FP * 4;
+  L.ints = off; off += up(((size_t)maxR + 6 * (size_t)maxD) * 4);
+  L.total = off;
+  return L;
+}
 
+// 16-byte LDS-DMA: lane l's 16 bytes at `src` land at lds_wave_base + 16 l.
+__device__ __forceinline__ void dma16(const float *src, float *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+}  // namespace
+
+template <bool PAD, bool FASTG>
+__global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const FusedLds L = fused_lds(g.max_tile_out_rows, g.max_tile_in_rows, g.max_tile_nodes);
+  float *bufQ = reinterpret_cast<float *>(smem_raw + L.bufQ);   // [maxR][LDQ] centred source rows
+  float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);   // [16][LDQ] W4 edge_d
+  float *bufC = reinterpret_cast<float *>(smem_raw + L.bufC);   // [16][LDQ] c2 pre-activation
+  float *atile = reinterpret_cast<float *>(smem_raw + L.atile); // 3 x [16][64] swizzled operand rows
+  float *sq = reinterpret_cast<float *>(smem_raw + L.sq);       // [maxR] |q|^2
+  float *nj = reinterpret_cast<float *>(smem_raw + L.nj);       // [maxN][2FP] Wj node[j] + bias
+  float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
+  float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
+        *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP, *s_g3 = lnp + 8 * FP, *s_ig3 = lnp + 10 * FP;
+  int *qb = reinterpret_cast<int *>(smem_raw + L.ints);
+  const int maxD = g.max_tile_in_rows;
+  int *d_edge = qb + g.max_tile_out_rows, *d_a = d_edge + maxD, *d_bl = d_a + maxD, *d_rb = d_bl + maxD,
+      *d_cnt = d_rb + maxD, *d_skip = d_cnt + maxD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, quad = lane >> 4;
   const int colbase = wave * 32;  // this wave's 32 of the 128 pre-activation columns
 
-  // ---- B fragments (weights), resident for the whole kernel
-  float bW4[2][KS], bW5[2][KS], bWc[2][KS];
+  // Workgroups of one frame group share node / np3 rows: keep them on one XCD (its L2).
+  // Dispatch is round-robin over the 8 XCDs, so consecutive logical ids = same XCD.
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.num_tiles;
+  const int sg = logical / g.num_tiles, nsg = gridDim.x / g.num_tiles;
+  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  const int nrounds = (dcount + NG - 1) / NG;
+
+  // ---- once per launch: LayerNorm parameters and the tile topology -> LDS
+  for (int c = tid; c < 2 * FP; c += 256) {
+    s_c2n1g[c] = a.w.c2_norm_1.g[c];
+    s_c2n1b[c] = a.w.c2_norm_1.b[c];
+    const float gam = a.w.c3_norm_1.g[c] * (c < FP ? -kLog2e : 2.0f * kLog2e);
+    s_g3[c] = gam;
+    s_ig3[c] = ((c % FP) < a.d.Fe) ? 1.0f / gam : 0.0f;
+    if (c < FP) {
+      s_c3n2g[c] = a.w.c3_norm_2.g[c];
+      s_c3n2b[c] = a.w.c3_norm_2.b[c];
+      s_c2n2g[c] = a.w.c2_norm_2.g[c];
+      s_c2n2b[c] = a.w.c2_norm_2.b[c];
+    }
+  }
+  for (int r = tid; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
+  for (int i = tid; i < dcount; i += 256) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_bl[i] = bd - j0;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+  }
+
+  // ---- B fragments resident for the whole kernel: lane (n = l15, quad) holds
+  //      W[k = 16 quad + s][colbase + 16 t + n]
+  float bW4[2][KS], bWc[2][KS];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = quad * KS + s, col = colbase + 16 * t + l15;
       bW4[t][s] = a.w.c3_WeT[(size_t)k * (4 * FP) + col];
-      bW5[t][s] = a.w.c3_WeT[(size_t)k * (4 * FP) + 2 * FP + col];
       bWc[t][s] = a.w.c2_WT[(size_t)k * (2 * FP) + col];
     }
   float c2bias[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) c2bias[t] = a.w.c2_bias[colbase + 16 * t + l15];
 
-  // ---- VALU-phase constants: lane q4 of a 16-lane group owns columns 4q4..4q4+3 (+FP)
-  const int grp = tid / LG, q4 = tid % LG;
-  const int nvalid = min(max(a.d.Fe - 4 * q4, 0), 4);
+  // ---- VALU-phase constants: lane q4 of group grp owns columns 4q4..4q4+3 (+FP)
+  const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
+  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
-  float g3f[4], b3f[4], g3c[4], b3c[4];  // c3_norm_1 with the exp2 scale folded in
+  float b3f[4], b3c[4], g3f[4], g3c[4];  // c3_norm_1 with the exp2 scale of the gate folded in
   {
-    const Vec4<float> gf = load4<float>(a.w.c3_norm_1.g + 4 * q4);
-    const Vec4<float> bf = load4<float>(a.w.c3_norm_1.b + 4 * q4);
-    const Vec4<float> gc = load4<float>(a.w.c3_norm_1.g + FP + 4 * q4);
-    const Vec4<float> bc = load4<float>(a.w.c3_norm_1.b + FP + 4 * q4);
+    const Vec4<float> gf = load4<float>(a.w.c3_norm_1.g + c0), bf = load4<float>(a.w.c3_norm_1.b + c0);
+    const Vec4<float> gc = load4<float>(a.w.c3_norm_1.g + FP + c0), bc = load4<float>(a.w.c3_norm_1.b + FP + c0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       g3f[i] = -kLog2e * gf.v[i];
@@ -88,79 +172,115 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       b3c[i] = 2.0f * kLog2e * bc.v[i];
     }
   }
+  __syncthreads();
 
-  const int64_t items = (int64_t)a.S * g.num_tiles;
-  for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
-    const int tile = (int)(item % g.num_tiles);
-    const int s = (int)(item / g.num_tiles);
-    const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
-    const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
-    const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  // LDS-DMA of the operand rows of round `r` of frame `s`: wave w brings rows 4w..4w+3 of
+  // each of the three tiles; slot (row, piece p) receives global piece p ^ row.
+  auto prefetch_round = [&](int s, int r) {
+    const int row = 4 * wave + quad;
+    const int i = min(r * NG + row, dcount - 1);
+    const int piece = (l15 ^ row) & 15;
     const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    float *dst = atile + wave * 256;
+    dma16(a.edge_in + (erow0 + d_edge[i]) * FP + 4 * piece, dst);
+    dma16(a.node + (nrow0 + j0 + d_bl[i]) * FP + 4 * piece, dst + NG * FP);
+    dma16(a.node + (nrow0 + d_a[i]) * FP + 4 * piece, dst + 2 * NG * FP);
+  };
+  if (sg < a.S && dcount > 0) prefetch_round(sg, 0);
 
-    // ================= source rows: Q' = W5 edge_e + Wi node[b_e]  -> LDS
-    for (int mt = 0; mt * 16 < rows; ++mt) {
-      float af[KS];
-      {
-        const int r = mt * 16 + l15;
-        const float *src = a.edge_in + (erow0 + eo0 + min(r, rows - 1)) * FP + quad * KS;
+  for (int s = sg; s < a.S; s += nsg) {
+    const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    // ---- per-atom part of P': Wj node[j] + bias for the tile's atoms
+    for (int i = tid; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+      const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
+      store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + c));
+    }
+    // ================= source rows: W5 edge_e by MFMA -> bufQ (raw)
+    // (batching the operand loads of several 16-row tiles, or fetching the Wi node[b_e] terms
+    //  ahead of the barrier, measured no faster: the extra registers spill)
+    {
+      float bW5[2][KS];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+          bW5[t][k] = a.w.c3_WeT[(size_t)(quad * KS + k) * (4 * FP) + 2 * FP + colbase + 16 * t + l15];
+      for (int mt = 0; mt * 16 < rows; ++mt) {
+        float af[KS];
+        const float *src = a.edge_in + (erow0 + eo0 + min(mt * 16 + l15, rows - 1)) * FP + quad * KS;
 #pragma unroll
         for (int s4 = 0; s4 < KS; s4 += 4) {
           const float4 v = *reinterpret_cast<const float4 *>(src + s4);
           af[s4] = v.x; af[s4 + 1] = v.y; af[s4 + 2] = v.z; af[s4 + 3] = v.w;
         }
-      }
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int k = 0; k < KS; ++k)
+        for (int k = 0; k < KS; ++k)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW5[t][k], acc[t], 0, 0, 0);
+          for (int t = 0; t < 2; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW5[t][k], acc[t], 0, 0, 0);
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = mt * 16 + 4 * quad + rr;
-        if (r < rows) {
-          const int be = g.edge_b[eo0 + r];
-          const float *nrow = a.np3 + (nrow0 + be) * (6 * FP) + colbase + l15;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = mt * 16 + 4 * quad + rr;
+          if (r < rows) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) bufQ[r * LDQ + colbase + 16 * t + l15] = acc[t][rr] + nrow[16 * t];
+            for (int t = 0; t < 2; ++t) bufQ[r * LDQ + colbase + 16 * t + l15] = acc[t][rr];
+          }
         }
       }
     }
-    for (int r = tid; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
     __syncthreads();
-    // centre the source rows and record |q|^2 (padded columns forced to 0)
-    for (int r = grp; r < rows; r += 256 / LG) {
+    // ---- add Wi node[b_e], centre, record |q|^2 (padded columns forced to 0)
+    for (int r = grp; r < rows; r += NG) {
       float *row = bufQ + r * LDQ;
-      Vec4<float> f = load4<float>(row + 4 * q4), c = load4<float>(row + FP + 4 * q4);
-      float sum = (f.v[0] + f.v[1]) + (f.v[2] + f.v[3]) + (c.v[0] + c.v[1]) + (c.v[2] + c.v[3]);
+      const float *np = a.np3 + (nrow0 + qb[r]) * (6 * FP) + c0;
+      Vec4<float> f = load4<float>(row + c0), c = load4<float>(row + FP + c0);
+      const Vec4<float> nf = load4<float>(np), nc = load4<float>(np + FP);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f.v[i] += nf.v[i];
+        c.v[i] += nc.v[i];
+        sum += f.v[i] + c.v[i];
+      }
       const float mean = lg_sum<LG>(sum) * inv2n;
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f.v[i] = (i < nvalid) ? f.v[i] - mean : 0.f;
-        c.v[i] = (i < nvalid) ? c.v[i] - mean : 0.f;
+        f.v[i] = (!PAD || i < nvalid) ? f.v[i] - mean : 0.f;
+        c.v[i] = (!PAD || i < nvalid) ? c.v[i] - mean : 0.f;
         ss += f.v[i] * f.v[i] + c.v[i] * c.v[i];
       }
       ss = lg_sum<LG>(ss);
-      store4(row + 4 * q4, f);
-      store4(row + FP + 4 * q4, c);
+      if (FASTG) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f.v[i] *= g3f[i];
+          c.v[i] *= g3c[i];
+        }
+        ss *= inv2n;
+      }
+      store4(row + c0, f);
+      store4(row + FP + c0, c);
       if (q4 == 0) sq[r] = ss;
     }
     __syncthreads();
 
-    // ================= destination edges, 16 at a time (one per lane group)
-    for (int mt = 0; mt * 16 < dcount; ++mt) {
-      // ---- MFMA: P' and c2 pre-activations for 16 destination edges -> LDS
+    // ================= destination edges, 16 per round (one per lane group)
+    Vec4<float> nkf, nkc;  // Wk node[a_d] of this group's destination, fetched one round ahead
+    if (grp < dcount) {
+      const float *nk = a.np3 + (nrow0 + d_a[grp]) * (6 * FP) + 4 * FP + c0;
+      nkf = load4<float>(nk);
+      nkc = load4<float>(nk + FP);
+    }
+    for (int r = 0; r < nrounds; ++r) {
+      // ---- MFMA: P' and c2 pre-activations of 16 destinations from the DMA'd operand rows
       {
-        const int ia = min(mt * 16 + l15, dcount - 1);  // row this lane feeds as A operand
-        const int dA = g.in_edge[di0 + ia];
         float af[KS];
-        const float *src = a.edge_in + (erow0 + dA) * FP + quad * KS;
 #pragma unroll
-        for (int s4 = 0; s4 < KS; s4 += 4) {
-          const float4 v = *reinterpret_cast<const float4 *>(src + s4);
-          af[s4] = v.x; af[s4 + 1] = v.y; af[s4 + 2] = v.z; af[s4 + 3] = v.w;
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4 *>(atile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
+          af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
         }
         f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -168,14 +288,12 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             accP[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW4[t][k], accP[t], 0, 0, 0);
-        // c2 operand: node[b_d] * node[a_d]
-        const float *nb = a.node + (nrow0 + g.edge_b[dA]) * FP + quad * KS;
-        const float *na = a.node + (nrow0 + g.edge_a[dA]) * FP + quad * KS;
 #pragma unroll
-        for (int s4 = 0; s4 < KS; s4 += 4) {
-          const float4 x = *reinterpret_cast<const float4 *>(nb + s4);
-          const float4 y = *reinterpret_cast<const float4 *>(na + s4);
-          af[s4] = x.x * y.x; af[s4 + 1] = x.y * y.y; af[s4 + 2] = x.z * y.z; af[s4 + 3] = x.w * y.w;
+        for (int j = 0; j < 4; ++j) {
+          const int off = l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4;
+          const float4 x = *reinterpret_cast<const float4 *>(atile + NG * FP + off);
+          const float4 y = *reinterpret_cast<const float4 *>(atile + 2 * NG * FP + off);
+          af[4 * j] = x.x * y.x; af[4 * j + 1] = x.y * y.y; af[4 * j + 2] = x.z * y.z; af[4 * j + 3] = x.w * y.w;
         }
         f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -186,114 +304,171 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int i = 4 * quad + rr;  // row of the 16x16 output tile held in register rr
-          if (mt * 16 + i < dcount) {
-            const int dd = g.in_edge[di0 + mt * 16 + i];
-            const float *nj = a.np3 + (nrow0 + g.edge_b[dd]) * (6 * FP) + 2 * FP + colbase + l15;
-            const float *nk = a.np3 + (nrow0 + g.edge_a[dd]) * (6 * FP) + 4 * FP + colbase + l15;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              bufP[i * LDQ + colbase + 16 * t + l15] = accP[t][rr] + nj[16 * t] + nk[16 * t];
-              bufC[i * LDQ + colbase + 16 * t + l15] = accC[t][rr] + c2bias[t];
+          for (int t = 0; t < 2; ++t) {
+            bufP[i * LDQ + colbase + 16 * t + l15] = accP[t][rr];
+            bufC[i * LDQ + colbase + 16 * t + l15] = accC[t][rr] + c2bias[t];
+          }
+        }
+      }
+      __syncthreads();  // S1: bufP / bufC complete, operand tiles free
+      if (r + 1 < nrounds) prefetch_round(s, r + 1);
+      else if (s + nsg < a.S) prefetch_round(s + nsg, 0);
+
+      // ---- VALU: lane group `grp` owns destination r*16 + grp
+      const int i = r * NG + grp;
+      if (i < dcount) {
+        const int64_t drow = erow0 + d_edge[i];
+        const Vec4<float> old = load4<float>(a.edge_in + drow * FP + c0);
+        float pf[4], pc[4];
+        {
+          const Vec4<float> xf = load4<float>(bufP + grp * LDQ + c0), xc = load4<float>(bufP + grp * LDQ + FP + c0);
+          const Vec4<float> jf = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + c0);
+          const Vec4<float> jc = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + FP + c0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pf[k] = xf.v[k] + nkf.v[k] + jf.v[k];
+            pc[k] = xc.v[k] + nkc.v[k] + jc.v[k];
+          }
+        }
+        if (i + NG < dcount) {  // next round's Wk node[a_d]
+          const float *nk = a.np3 + (nrow0 + d_a[i + NG]) * (6 * FP) + 4 * FP + c0;
+          nkf = load4<float>(nk);
+          nkc = load4<float>(nk + FP);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += pf[k] + pc[k];
+        const float mean = lg_sum<LG>(sum) * inv2n;
+        float sp = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf[k] = (!PAD || k < nvalid) ? pf[k] - mean : 0.f;
+          pc[k] = (!PAD || k < nvalid) ? pc[k] - mean : 0.f;
+          sp += pf[k] * pf[k] + pc[k] * pc[k];
+        }
+        sp = lg_sum<LG>(sp);
+
+        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FASTG) {
+          // pd = p/gamma * (2/2Fe), pg = p*gamma; var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
+          float pdf[4], pdc[4];
+          {
+            const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);
+            const float two_inv = 2.0f * inv2n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              pdf[k] = pf[k] * igf.v[k] * two_inv;
+              pdc[k] = pc[k] * igc.v[k] * two_inv;
+              pf[k] *= g3f[k];
+              pc[k] *= g3c[k];
+            }
+          }
+          const float spe = sp * inv2n + 1e-5f;
+          for (int t = 0; t < cnt; ++t) {
+            const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
+            const float *qr = bufQ + rq * LDQ + c0;
+            const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot += pdf[k] * qf.v[k] + pdc[k] * qc.v[k];
+            dot = lg_sum<LG>(dot);
+            float ve = dot + (spe + sq[rq]);
+            ve = ve > 1e-5f ? ve : 1e-5f;
+            const float rstd = fast_rsq(ve);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float e1 = fast_exp2((pf[k] + qf.v[k]) * rstd + b3f[k]);
+              const float e2 = fast_exp2((pc[k] + qc.v[k]) * rstd + b3c[k]);
+              acc[k] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
+            }
+          }
+        } else {
+          for (int t = 0; t < cnt; ++t) {
+            const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
+            const float *qr = bufQ + rq * LDQ + c0;
+            const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot += pf[k] * qf.v[k] + pc[k] * qc.v[k];
+            dot = lg_sum<LG>(dot);
+            const float var = fmaxf((sp + sq[rq] + 2.0f * dot) * inv2n, 0.0f);
+            const float rstd = fast_rsq(var + 1e-5f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float yf = ((pf[k] + qf.v[k]) * rstd) * g3f[k] + b3f[k];
+              float yc = ((pc[k] + qc.v[k]) * rstd) * g3c[k] + b3c[k];
+              yc = fminf(fmaxf(yc, -43.28f), 43.28f);
+              const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
+              acc[k] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
             }
           }
         }
-      }
-      __syncthreads();
-      // ---- VALU: lane group `grp` owns destination edge mt*16 + grp
-      if (mt * 16 + grp < dcount) {
-        const int dst = g.in_edge[di0 + mt * 16 + grp];
-        const int bd = g.edge_b[dst];
-        const int64_t drow = erow0 + dst;
-        Vec4<float> pf = load4<float>(bufP + grp * LDQ + 4 * q4);
-        Vec4<float> pc = load4<float>(bufP + grp * LDQ + FP + 4 * q4);
-        float sp;
-        {
-          float sum = (pf.v[0] + pf.v[1]) + (pf.v[2] + pf.v[3]) + (pc.v[0] + pc.v[1]) + (pc.v[2] + pc.v[3]);
-          const float mean = lg_sum<LG>(sum) * inv2n;
-          float ss = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            pf.v[i] = (i < nvalid) ? pf.v[i] - mean : 0.f;
-            pc.v[i] = (i < nvalid) ? pc.v[i] - mean : 0.f;
-            ss += pf.v[i] * pf.v[i] + pc.v[i] * pc.v[i];
-          }
-          sp = lg_sum<LG>(ss);
-        }
-        const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
-        const int rev = g.rev_edge[dst];                 // edge (b_d -> a_d) or -1
-        const int rskip = rev >= 0 ? rev - eo0 : re;     // triplets with i == k are excluded
-        const int cnt = (re - rb) - (rev >= 0 ? 1 : 0);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < cnt; ++t) {
-          const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
-          const float *qr = bufQ + r * LDQ + 4 * q4;
-          const Vec4<float> qf = load4<float>(qr);
-          const Vec4<float> qc = load4<float>(qr + FP);
-          float dot = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) dot += pf.v[i] * qf.v[i] + pc.v[i] * qc.v[i];
-          dot = lg_sum<LG>(dot);
-          const float var = fmaxf((sp + sq[r] + 2.0f * dot) * inv2n, 0.0f);
-          const float rstd = fast_rsq(var + 1e-5f);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float yf = ((pf.v[i] + qf.v[i]) * rstd) * g3f[i] + b3f[i];   // -log2e * LN(filter)
-            float yc = ((pc.v[i] + qc.v[i]) * rstd) * g3c[i] + b3c[i];         // 2 log2e * LN(core)
-            yc = fminf(fmaxf(yc, -43.28f), 43.28f);
-            const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
-            acc[i] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
-          }
-        }
-        const LnParams<float> p3n{load4<float>(a.w.c3_norm_2.g + 4 * q4),
-                                  load4<float>(a.w.c3_norm_2.b + 4 * q4)};
-        const Vec4<float> c3 = ln_row<LG, true>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n,
-                                                 invn, nvalid);
-        // c2 (_gnn.py:223-228)
-        const LnParams<float> p2f{load4<float>(a.w.c2_norm_1.g + 4 * q4),
-                                  load4<float>(a.w.c2_norm_1.b + 4 * q4)};
-        const LnParams<float> p2c{load4<float>(a.w.c2_norm_1.g + FP + 4 * q4),
-                                  load4<float>(a.w.c2_norm_1.b + FP + 4 * q4)};
-        const Vec4<float> c2f = load4<float>(bufC + grp * LDQ + 4 * q4);
-        const Vec4<float> c2c = load4<float>(bufC + grp * LDQ + FP + 4 * q4);
-        const Vec4<float> g2 = ln_gate<LG, true>(c2f, c2c, p2f, p2c, inv2n, nvalid);
-        const LnParams<float> p2n{load4<float>(a.w.c2_norm_2.g + 4 * q4),
-                                  load4<float>(a.w.c2_norm_2.b + 4 * q4)};
-        const Vec4<float> c2 = ln_row<LG, true>(g2, p2n, invn, nvalid);
-        const Vec4<float> old = load4<float>(a.edge_in + drow * FP + 4 * q4);
+        const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
+        const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+        // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
+        const LnParams<float> p2f{load4<float>(s_c2n1g + c0), load4<float>(s_c2n1b + c0)};
+        const LnParams<float> p2c{load4<float>(s_c2n1g + FP + c0), load4<float>(s_c2n1b + FP + c0)};
+        const Vec4<float> c2f = load4<float>(bufC + grp * LDQ + c0), c2c = load4<float>(bufC + grp * LDQ + FP + c0);
+        const Vec4<float> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
+        const LnParams<float> p2n{load4<float>(s_c2n2g + c0), load4<float>(s_c2n2b + c0)};
+        const Vec4<float> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
         Vec4<float> out;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out.v[i] = acc_tanh(old.v[i] + c2.v[i] + c3.v[i]);
-        store4(a.edge_out + drow * FP + 4 * q4, out);
+        for (int k = 0; k < 4; ++k) out.v[k] = acc_tanh(old.v[k] + c2.v[k] + c3.v[k]);
+        store4(a.edge_out + drow * FP + c0, out);
       }
-      __syncthreads();  // bufP / bufC are rewritten by the next 16 destinations
+      __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten
     }
   }
 }
 
-size_t edge_fused_lds_bytes(const Graph &g, int FP) {
-  const size_t ldq = 2 * (size_t)FP + 4;
-  return ((size_t)g.max_tile_out_rows * ldq + 2 * 16 * ldq + g.max_tile_out_rows) * sizeof(float) +
-         (size_t)g.max_tile_out_rows * sizeof(int);
+size_t edge_fused_lds_bytes(const Graph &g) {
+  return fused_lds(g.max_tile_out_rows, g.max_tile_in_rows, g.max_tile_nodes).total;
 }
+// LDS footprint of a tile with `rows` out-edges, `in_rows` in-edges and `nodes` atoms.
+size_t edge_fused_lds_bytes(int rows, int in_rows, int nodes) { return fused_lds(rows, in_rows, nodes).total; }
 
 bool edge_fused_supported(const Graph &g, Dims d) {
-  return d.FnP == 64 && d.FeP == 64 && edge_fused_lds_bytes(g, 64) <= 80 * 1024;
+  return d.FnP == 64 && d.FeP == 64 && g.E > 0 && edge_fused_lds_bytes(g) <= kFusedLdsBudget;
+}
+
+template <bool PAD, bool FASTG>
+static void launch_cfg(const EdgeFusedArgs &a, size_t lds, hipStream_t st) {
+  auto kern = &edge_block_fused_kernel<PAD, FASTG>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, 2);
+  int nsg = per_cu * cus / a.g.num_tiles;
+  nsg = nsg < 1 ? 1 : (nsg > a.S ? a.S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)a.g.num_tiles, 256, lds, st>>>(a);
 }
 
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
                        int S, const Graph &g, Dims d, const PassW<float> &w, hipStream_t st) {
-  if (S == 0) return;
+  if (S == 0 || g.E == 0) return;
   EdgeFusedArgs a{edge_in, edge_out, node, np3, S, g, d, w};
-  const size_t lds = edge_fused_lds_bytes(g, 64);
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_block_fused_kernel<64>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  const size_t lds = edge_fused_lds_bytes(g);
+  const bool pad = d.Fe != d.FeP;
+  if (pad) {
+    if (w.c3_fast) launch_cfg<true, true>(a, lds, st);
+    else launch_cfg<true, false>(a, lds, st);
+  } else {
+    if (w.c3_fast) launch_cfg<false, true>(a, lds, st);
+    else launch_cfg<false, false>(a, lds, st);
   }
-  const int64_t items = (int64_t)S * g.num_tiles;
-  const unsigned grid = (unsigned)(items < 512 ? items : 512);  // 2 persistent workgroups per CU
-  edge_block_fused_kernel<64><<<grid, 256, lds, st>>>(a);
 }
 
 }  // namespace rn

@@ -478,6 +478,11 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         _lib.check(rc, handle, "rn_potgnn_debug_stage")
         return buf[: rows.value * cols.value].reshape(rows.value, cols.value).copy()
 
+    def config_flags(self) -> dict:
+        """Which kernel variants the handle selected (``rn_potgnn_config_flags``)."""
+        flags = _lib.load().rn_potgnn_config_flags(self._ensure_handle())
+        return {"fused_edge_block": bool(flags & 1), "folded_gate_scale": bool(flags & 2)}
+
     def set_profiling(self, mode: int) -> None:
         """0 = off, 1 = HIP-event timing of every kernel launch, 100+k = kernel k only."""
         self._profiling = int(mode)

@@ -171,10 +171,15 @@ def test_fused_edge_block_equals_unfused(monkeypatch):
     widths of the aggregation kernel and the interleaved / sequential schedules."""
     from bench import make_workload
     wl = make_workload(num_cells=(2, 2, 2), frames=9, hparams="perf", seed=3)
-    unfused = wl["model"]().calc_polarizabilities(wl["positions"])
+    monkeypatch.setenv("RN_POTGNN_FUSED", "0")
+    m0 = wl["model"]()
+    unfused = m0.calc_polarizabilities(wl["positions"])
+    assert not m0.config_flags()["fused_edge_block"]
     monkeypatch.setenv("RN_POTGNN_FUSED", "1")
-    fused = wl["model"]().calc_polarizabilities(wl["positions"])
-    assert _rel_err(fused, unfused) < 2e-6
+    m1 = wl["model"]()
+    fused = m1.calc_polarizabilities(wl["positions"])
+    assert m1.config_flags()["fused_edge_block"]
+    assert _rel_err(fused, unfused) < 5e-6
     monkeypatch.setenv("RN_POTGNN_FUSED", "0")
     monkeypatch.setenv("RN_POTGNN_VPL", "8")
     wide = wl["model"]().calc_polarizabilities(wl["positions"])
@@ -235,6 +240,37 @@ def test_other_widths_and_graphs_against_oracle(case, cutoff, fn, fe, passes):
         np.testing.assert_array_equal(mine, ref.numpy())
     pos = g["pos_batch"][:3]
     got = model.calc_polarizabilities(pos)
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    std_got = (got - oracle.mean) / oracle.std
+    std_want = (want - oracle.mean) / oracle.std
+    assert _rel_err(std_got, std_want) < REL, (case, fn, fe)
+
+
+@pytest.mark.parametrize(
+    "case, cutoff, fn, fe, passes, frames",
+    [
+        ("triclinic20", 3.0, 40, 50, 2, 3),       # padded columns in both embeddings
+        ("triclinic20", 3.4, 64, 64, 2, 3),       # ragged graph, tiles of unequal size
+        ("triclinic20", 2.2, 64, 33, 1, 2),       # atoms with very few neighbours
+        ("rocksalt64_parity", 3.2, 64, 64, 2, 21),  # several frames per workgroup
+        ("tio2_notebook", 5.0, 64, 64, 1, 2),     # 47 neighbours per atom: one-atom tiles
+    ],
+)
+@pytest.mark.parametrize("fast_gate", [True, False])
+def test_fused_edge_block_against_oracle(monkeypatch, case, cutoff, fn, fe, passes, frames, fast_gate):
+    """The fused EdgeBlock kernel (MFMA projections + LDS-DMA operand rows + triplet stage in one
+    launch) on graphs and widths the bench does not touch, both triplet-loop variants."""
+    from oracle import potgnn_oracle as O
+    monkeypatch.setenv("RN_POTGNN_FUSED", "1")
+    monkeypatch.setenv("RN_POTGNN_NO_FASTG", "0" if fast_gate else "1")
+    g = load_golden(case)
+    model, oracle = _random_model(g, cutoff, fn, fe, passes, seed=fn * 1000 + fe)
+    rng = np.random.default_rng(5)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=frames)] + rng.normal(scale=2e-3, size=(frames,) + base.shape[1:])
+    got = model.calc_polarizabilities(pos)
+    flags = model.config_flags()
+    assert flags["fused_edge_block"] and flags["folded_gate_scale"] == fast_gate
     want = O.calc_polarizabilities(oracle, pos, faithful=False)
     std_got = (got - oracle.mean) / oracle.std
     std_want = (want - oracle.mean) / oracle.std
