@@ -31,7 +31,8 @@ HPARAMS = {
     "parity": (5, 14, 4),  # the only documented set (machine-learning.ipynb:187-192)
 }
 EDGE_AGG_KERNEL_ID = 7  # index of "edge_agg" in rn_potgnn_kernel_times / csrc/api.hip
-PROJ_C3_KERNEL_ID = 5   # "proj_edge_c3": the [E,64]x[64,256] projection (HBM-bound)
+PROJ_C3_KERNEL_ID = 5   # "proj_edge_c3": the [E,64]x[64,256] projection (HBM-bound; unfused pipeline)
+PROJ_C1_KERNEL_ID = 3   # "proj_edge_c1": the [E,64]x[64,128] projection
 LIGHT_CM_PER_FS = 2.99792458e-5
 
 
@@ -128,28 +129,31 @@ def algorithmic_bytes_edge_block(n, e, fn, fe):
     return 4 * (n * fn + 2 * e * fe)
 
 
-def measured_traffic(n, e, fn, fe, frames, passes, steps, launches):
+def measured_traffic(n, e, fn, fe, frames, passes, steps, launches, fused):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01/edge_agg_traffic.json), when they were taken on this workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "edge_agg_traffic.json")
+    (profiles/r01/edge_fused_traffic.json or edge_agg_traffic.json), when they were taken on
+    this workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "edge_fused_traffic.json" if fused else "edge_agg_traffic.json")
     if not (launches and os.path.exists(path) and (n, e, fn, fe) == (128, 2304, 64, 64)):
         return None
     per_structure_pass = json.load(open(path))["hbm_bytes_per_structure_pass"]
     return per_structure_pass * frames * passes * steps / launches
 
 
-def projection_roofline(times, e, fe, frames, passes, steps):
-    """The HBM-bound kernel of the pipeline, for comparison: the c3 edge projection reads
-    E*Fe and writes E*4Fe floats per structure and pass (its output is an intermediate, so
-    these are actual, not 'algorithmic', bytes)."""
-    ms, launches = times.get("proj_edge_c3", (0.0, 0))
-    if not launches or ms <= 0:
-        return None
-    total = 4 * (e * fe + e * 4 * fe) * frames * passes * steps
-    achieved = total / (ms * 1e-3) / 1e9
-    return {"kernel": "rowgemm_mfma_kernel<64,4,2> (c3 edge projection)", "bound": "hbm",
-            "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "launches": launches, "avg_launch_ms": ms / launches}
+def projection_roofline(times, e, fn, fe, frames, passes, steps):
+    """The HBM-bound kernel of the pipeline, for comparison: an edge projection reads E*Fe and
+    writes E*NOUT floats per structure and pass (its output is an intermediate, so these are
+    actual, not 'algorithmic', bytes).  c3 (NOUT = 4Fe) in the unfused pipeline, c1
+    (NOUT = 2Fn) when the fused EdgeBlock has absorbed c3 and c2."""
+    for key, nout, name in (("proj_edge_c3", 4 * fe, "rowgemm_mfma_kernel<64,4,2> (c3 edge projection)"),
+                            ("proj_edge_c1", 2 * fn, "rowgemm_mfma_kernel<64,4,1> (c1 edge projection)")):
+        ms, launches = times.get(key, (0.0, 0))
+        if launches and ms > 0:
+            total = 4 * (e * fe + e * nout) * frames * passes * steps
+            achieved = total / (ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "launches": launches, "avg_launch_ms": ms / launches}
+    return None
 
 
 def cpu_baseline(workload, sample):
@@ -215,7 +219,7 @@ def main():
         step()
     torch.cuda.synchronize()
     model.set_profiling(1 if args.profile_all
-                        else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID))
+                        else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID) + (1 << PROJ_C1_KERNEL_ID))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -241,6 +245,7 @@ def main():
 
     if rank == 0:
         agg_ms, agg_launches = times.get("edge_agg", (0.0, 0))
+        fused = bool(model.config_flags()["fused_edge_block"])
         total_bytes = algorithmic_bytes_edge_block(n, e, fn, fe) * args.frames * passes * args.steps
         achieved = total_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         peak = 8000.0
@@ -267,21 +272,22 @@ def main():
                                else "single GPU",
             },
             "roofline": {
-                "kernel": "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)",
+                "kernel": ("edge_block_fused_kernel (EdgeBlock: MFMA projections + triplet scatter-aggregate)"
+                           if fused else "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "GB/s",
                 "frac": achieved / peak if achieved else None,
-                "traffic": measured_traffic(n, e, fn, fe, args.frames, passes, args.steps, agg_launches),
+                "traffic": measured_traffic(n, e, fn, fe, args.frames, passes, args.steps, agg_launches, fused),
                 "launches": agg_launches,
                 "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
                 "algorithmic_bytes_per_structure_pass": algorithmic_bytes_edge_block(n, e, fn, fe),
-                "note": "edge_agg is VALU/transcendental-bound (DESIGN.md section 5): ~22 VALU "
-                        "instructions incl. 3 transcendentals per (triplet, feature pair); "
-                        "achieved/peak are the HBM figures the metric asks for",
+                "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): ~17 VALU instructions "
+                        "incl. 3 transcendentals per (triplet, feature pair), and fp32 MFMA shares the "
+                        "issue port; achieved/peak are the HBM figures the metric asks for",
             },
-            "roofline_projection": projection_roofline(times, e, fe, args.frames, passes, args.steps),
+            "roofline_projection": projection_roofline(times, e, fn, fe, args.frames, passes, args.steps),
             "host_buffers_structures_per_s": host_rate,
         }
         if args.profile_all:

@@ -3,18 +3,20 @@
 usage: sq_summary.py sq1_counter_collection.csv [sq2_counter_collection.csv]"""
 import csv, collections, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
+passes = collections.defaultdict(set)   # counter -> files it was collected in (averaged over)
 dur = collections.defaultdict(float); calls = collections.Counter()
 seen = set()
 for f in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void rn::', '')[:44]
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+        passes[r['Counter_Name']].add(f)
         key = (f, r['Dispatch_Id'])
         if key not in seen and f == sys.argv[1]:
             seen.add(key); dur[k] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])); calls[k] += 1
 print(f"{'kernel':44s} {'calls':>5s} {'ms':>8s} {'GHz':>5s} {'valu_busy':>9s} {'mfma_busy':>9s} {'wait_any':>8s} {'wait_inst':>9s} {'cyc/valu':>8s} {'waves/simd':>10s}")
 for k in sorted(dur, key=lambda x: -dur[x]):
-    a = acc[k]; t = dur[k] * 1e-9
+    a = {c: v / max(len(passes[c]), 1) for c, v in acc[k].items()}; t = dur[k] * 1e-9
     if t <= 0 or not a.get('SQ_WAVE_CYCLES'): continue
     clk = a['GRBM_GUI_ACTIVE'] / 8 / t            # cycles/s
     simd_cycles = clk * t * 1024                  # total SIMD-cycles available

@@ -384,7 +384,10 @@ void refresh_pass_flags(rn_potgnn *h) {
         const double arg = (g * xmax + b) * 2.0 * 1.4426950408889634;
         ok = std::isfinite(g) && std::isfinite(b) && g >= 1e-5 && arg < 60.0;
       }
-    P.pass[p].c3_fast = ok ? 1 : 0;
+    // bit 0: fused EdgeBlock kernel; bit 1: unfused edge_agg_kernel -- there only with a
+    // single lane: its 170 registers per lane shut the other lane's projection workgroups
+    // out of the CU (150 do not), which costs more than the shorter loop gains
+    P.pass[p].c3_fast = ok ? (h->num_lanes == 1 ? 3 : 1) : 0;
   }
 }
 
@@ -1247,7 +1250,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   };
   const bool vpl8 = getenv("RN_POTGNN_VPL") && atoi(getenv("RN_POTGNN_VPL")) == 8;
   // fused EdgeBlock (kernels_fused.hip): its LDS footprint bounds the tile instead
-  const bool want_fused = getenv("RN_POTGNN_FUSED") && atoi(getenv("RN_POTGNN_FUSED")) != 0;
+  const bool want_fused = getenv("RN_POTGNN_FUSED") ? atoi(getenv("RN_POTGNN_FUSED")) != 0 : true;
   const bool fused_mode = want_fused && d.FnP == 64 && d.FeP == 64;
   int max_rows = 0;
   if (getenv("RN_POTGNN_TILE_KB") || vpl8) {
@@ -1360,8 +1363,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       chunk = std::min(chunk, 2048);
     }
     hp->chunk = chunk;
-    // The single-launch fused EdgeBlock (kernels_fused.hip) is opt-in: on MI355X it is
-    // slower than projections + edge_agg (weights pinned in VGPRs cap it at 2 waves/SIMD).
+    // The fused EdgeBlock (kernels_fused.hip) is the default where it applies (float32,
+    // Fn and Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
     ensure_precision<float>(hp);
   });
@@ -1579,7 +1582,7 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
   int flags = h->use_fused ? 1 : 0;
   bool fast = !h->f32.pass.empty();
-  for (const auto &p : h->f32.pass) fast = fast && p.c3_fast;
+  for (const auto &p : h->f32.pass) fast = fast && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);
 }
 

@@ -51,6 +51,7 @@ struct PassW {
   Ln<T> c3_norm_1;   // [2FeP]
   Ln<T> c3_norm_2;   // [FeP]
   int c3_fast;       // host-side decision: c3_norm_1 admits the folded-scale triplet loop
+                     // (bit 0: in the fused EdgeBlock kernel, bit 1: in edge_agg_kernel)
 };
 
 template <typename T>

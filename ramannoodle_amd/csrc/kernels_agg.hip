@@ -692,7 +692,7 @@ static void launch_edge_agg_cfg(const T *pq, const T *np3, const T *c2pre, const
   // thirds of the CUs idle: measured 2.25 instead of 3 waves/SIMD).
   constexpr bool kFloat = sizeof(T) == 4;
   auto kern = agg_out ? &edge_agg_kernel<FP, VPL, PAD, T, true, false>
-                      : ((kFloat && w.c3_fast) ? &edge_agg_kernel<FP, VPL, PAD, T, false, kFloat>
+                      : ((kFloat && (w.c3_fast & 2)) ? &edge_agg_kernel<FP, VPL, PAD, T, false, kFloat>
                                                : &edge_agg_kernel<FP, VPL, PAD, T, false, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -463,10 +463,10 @@ void launch_edge_fused(const float *edge_in, float *edge_out, const float *node,
   const size_t lds = edge_fused_lds_bytes(g);
   const bool pad = d.Fe != d.FeP;
   if (pad) {
-    if (w.c3_fast) launch_cfg<true, true>(a, lds, st);
+    if (w.c3_fast & 1) launch_cfg<true, true>(a, lds, st);
     else launch_cfg<true, false>(a, lds, st);
   } else {
-    if (w.c3_fast) launch_cfg<false, true>(a, lds, st);
+    if (w.c3_fast & 1) launch_cfg<false, true>(a, lds, st);
     else launch_cfg<false, false>(a, lds, st);
   }
 }

@@ -151,6 +151,118 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------- K = 64 streams
+// Wave-autonomous variant for the three big edge projections of a pass (c1, c3 = P'|Q', c2;
+// K = 64, NOUT a multiple of 128).  The weight slice of a workgroup (128 columns) sits in LDS
+// transposed; every wave streams its own 32-row tiles straight from HBM into A fragments
+// (each lane one contiguous 128-byte run, next tile's run fetched while the current one
+// multiplies) and never meets a barrier after the prologue.  160 VGPRs and 34 KiB of LDS
+// per workgroup, so one such workgroup fits on a CU next to two workgroups of
+// edge_agg_kernel where the register-resident kernel above (196-276 registers per lane)
+// is shut out.  Opt-in (RN_POTGNN_GEMM_STREAM=1): measured on MI355X it is 8-30 % slower
+// than the kernel above in isolation and the better co-residency does not make up for it
+// (profiles/r01/overlap_experiments.txt).
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void rowgemm_stream64_kernel(GemmArgs a, int tiles_per_wave) {
+  constexpr int KP = 64, NS = 128, LDW = KP + 4;
+  __shared__ __attribute__((aligned(16))) float wt[NS * LDW];  // wt[n][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ncol0 = blockIdx.y * NS;
+  for (int i = tid; i < KP * NS; i += 256) {
+    const int k = i / NS, n = i % NS;
+    wt[n * LDW + k] = a.WT[(int64_t)k * a.NOUT + ncol0 + n];
+  }
+  __syncthreads();
+
+  const int64_t num_tiles = (a.M + 31) / 32;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+  // this lane's run of the operand row(s) of tile t: columns 32h .. 32h+31 of row 32t + l31
+  float4 nxt[8], nxt2[AMODE == 1 ? 8 : 1];
+  auto fetch = [&](int64_t tile) {
+    int64_t row = tile * 32 + l31;
+    if (row >= a.M) row = a.M - 1;
+    if (AMODE == 0) {
+      const float *p = a.X + row * KP + 32 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nxt[j] = *reinterpret_cast<const float4 *>(p + 4 * j);
+    } else {
+      const int64_t s = row / a.E;
+      const int e = (int)(row - s * a.E);
+      const float *pb = a.node + (s * a.N + a.edge_b[e]) * KP + 32 * h;
+      const float *pa = a.node + (s * a.N + a.edge_a[e]) * KP + 32 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        nxt[j] = *reinterpret_cast<const float4 *>(pb + 4 * j);
+        nxt2[j] = *reinterpret_cast<const float4 *>(pa + 4 * j);
+      }
+    }
+  };
+  if (first < num_tiles) fetch(first);
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int64_t tile = first + it;
+    if (tile >= num_tiles) break;
+    float afrag[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float4 v = nxt[j];
+      if (AMODE == 1) v = make_float4(v.x * nxt2[j].x, v.y * nxt2[j].y, v.z * nxt2[j].z, v.w * nxt2[j].w);
+      afrag[4 * j] = v.x; afrag[4 * j + 1] = v.y; afrag[4 * j + 2] = v.z; afrag[4 * j + 3] = v.w;
+    }
+    if (it + 1 < tiles_per_wave && tile + 1 < num_tiles) fetch(tile + 1);
+    const int64_t row0 = tile * 32;
+#pragma unroll 1
+    for (int nt = 0; nt < NS / 32; ++nt) {
+      const float *wp = wt + (nt * 32 + l31) * LDW + 32 * h;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 b = *reinterpret_cast<const float4 *>(wp + 4 * j);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * j], b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * j + 1], b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * j + 2], b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * j + 3], b.w, acc, 0, 0, 0);
+      }
+      const int col = ncol0 + nt * 32 + l31;
+      const float sc = (EPI == 2) ? a.scale[col] : 1.0f;
+      const float sh = (EPI >= 1) ? a.shift[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.M) {
+          float v = acc[r];
+          if (EPI == 1) v += sh;
+          if (EPI == 2) v = ssp_fast(v * sc + sh);
+          a.Y[row * a.NOUT + col] = v;
+        }
+      }
+    }
+  }
+}
+
+static bool launch_stream64(const GemmArgs &a, int amode, int epi, hipStream_t st) {
+  static const int enabled = getenv("RN_POTGNN_GEMM_STREAM") ? atoi(getenv("RN_POTGNN_GEMM_STREAM")) : 0;
+  if (!enabled || a.NOUT % 128 != 0 || a.M < 4096) return false;
+  const int64_t tiles = (a.M + 31) / 32;
+  // a few tiles per wave: amortises the weight prologue, keeps the tail short
+  static const int tpw_env = getenv("RN_POTGNN_GEMM_TPW") ? atoi(getenv("RN_POTGNN_GEMM_TPW")) : 4;
+  const int tpw = tpw_env < 1 ? 1 : tpw_env;
+  const dim3 grid((unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), (unsigned)(a.NOUT / 128));
+#define RN_ST(AM, EP) rowgemm_stream64_kernel<AM, EP><<<grid, 256, 0, st>>>(a, tpw)
+  if (amode == 0) {
+    if (epi == 0) RN_ST(0, 0);
+    else if (epi == 1) RN_ST(0, 1);
+    else RN_ST(0, 2);
+  } else {
+    if (epi == 0) RN_ST(1, 0);
+    else RN_ST(1, 1);
+  }
+#undef RN_ST
+  return true;
+}
+
 template <int KP, int WN, int TN>
 static void launch_mfma_cfg(const GemmArgs &a, int amode, int epi, dim3 grid, hipStream_t st) {
 #define RN_GEMM(AM, EP) rowgemm_mfma_kernel<KP, WN, TN, AM, EP><<<grid, 256, 0, st>>>(a)
@@ -210,7 +322,9 @@ void launch_rowgemm<float>(const float *X, int64_t M, int KP, const float *WT, i
   switch (KP) {
     case 16: launch_mfma_kp<16>(a, amode, epi, st); break;
     case 32: launch_mfma_kp<32>(a, amode, epi, st); break;
-    case 64: launch_mfma_kp<64>(a, amode, epi, st); break;
+    case 64:
+      if (!launch_stream64(a, amode, epi, st)) launch_mfma_kp<64>(a, amode, epi, st);
+      break;
     case 128: launch_mfma_kp<128>(a, amode, epi, st); break;
   }
 }
