@@ -44,6 +44,13 @@ struct EdgeFusedArgs {
   PassW<float> w;
 };
 
+#ifndef RN_FUSED_EXPERIMENT
+#define RN_FUSED_EXPERIMENT 0  // timing-only variants (wrong results): 1 no triplet loop, 2 no round MFMA,
+#endif                        // 3 no Q' MFMA, 4 no epilogue transcendental work
+#ifndef RN_FUSED_PAIRWISE
+#define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
+#endif
+
 namespace {
 constexpr int FP = 64;
 constexpr int LG = 16;            // lanes per row in the VALU phase
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < KS; ++k)
+        for (int k = 0; k < (RN_FUSED_EXPERIMENT == 3 ? 1 : KS); ++k)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW5[t][k], acc[t], 0, 0, 0);
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         }
         f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < KS; ++k)
+        for (int k = 0; k < (RN_FUSED_EXPERIMENT == 2 ? 1 : KS); ++k)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             accP[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW4[t][k], accP[t], 0, 0, 0);
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         }
         f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < KS; ++k)
+        for (int k = 0; k < (RN_FUSED_EXPERIMENT == 2 ? 1 : KS); ++k)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bWc[t][k], accC[t], 0, 0, 0);
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         }
         sp = lg_sum<LG>(sp);
 
-        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+        const int rb = d_rb[i], cnt = (RN_FUSED_EXPERIMENT == 1) ? 0 : d_cnt[i], rskip = d_skip[i];
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (FASTG) {
           // pd = p/gamma * (2/2Fe), pg = p*gamma; var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
@@ -366,8 +373,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             }
           }
           const float spe = sp * inv2n + 1e-5f;
-          for (int t = 0; t < cnt; ++t) {
-            const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
+          auto triplet = [&](int rq, float (&sumk)[4]) {
             const float *qr = bufQ + rq * LDQ + c0;
             const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
             float dot = 0.f;
@@ -381,9 +387,26 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             for (int k = 0; k < 4; ++k) {
               const float e1 = fast_exp2((pf[k] + qf.v[k]) * rstd + b3f[k]);
               const float e2 = fast_exp2((pc[k] + qc.v[k]) * rstd + b3c[k]);
-              acc[k] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
+              sumk[k] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
             }
+          };
+#if RN_FUSED_PAIRWISE
+          // two independent triplets per iteration: at two waves per SIMD the second chain
+          // fills the dependency stalls of the first (summation order: even/odd partial sums)
+          float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+          int t = 0;
+          for (; t + 1 < cnt; t += 2) {
+            const int r0 = rb + t + ((rb + t >= rskip) ? 1 : 0);
+            const int r1 = rb + t + 1 + ((rb + t + 1 >= rskip) ? 1 : 0);
+            triplet(r0, acc);
+            triplet(r1, acc2);
           }
+          if (t < cnt) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
+#else
+          for (int t = 0; t < cnt; ++t) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
+#endif
         } else {
           for (int t = 0; t < cnt; ++t) {
             const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         const Vec4<float> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
         Vec4<float> out;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out.v[k] = acc_tanh(old.v[k] + c2.v[k] + c3.v[k]);
+        for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2.v[k] + c3.v[k]);
         store4(a.edge_out + drow * FP + c0, out);
       }
       __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten
