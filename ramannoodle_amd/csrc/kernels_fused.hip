@@ -274,9 +274,16 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     __syncthreads();
 
     // ================= destination edges, 16 per round (one per lane group)
+    // Destination of this lane group in round `round` (-1: none).  A round with at most 8
+    // destinations is split: groups g and g+8 share destination g, half of its triplets each.
+    auto dest_index = [&](int round) {
+      const int rm = dcount - round * NG;
+      const int sl = (rm <= NG / 2) ? (grp & (NG / 2 - 1)) : grp;
+      return sl < rm ? round * NG + sl : -1;
+    };
     Vec4<float> nkf, nkc;  // Wk node[a_d] of this group's destination, fetched one round ahead
-    if (grp < dcount) {
-      const float *nk = a.np3 + (nrow0 + d_a[grp]) * (6 * FP) + 4 * FP + c0;
+    if (const int i0 = dest_index(0); i0 >= 0) {
+      const float *nk = a.np3 + (nrow0 + d_a[i0]) * (6 * FP) + 4 * FP + c0;
       nkf = load4<float>(nk);
       nkc = load4<float>(nk + FP);
     }
@@ -322,14 +329,21 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       if (r + 1 < nrounds) prefetch_round(s, r + 1);
       else if (s + nsg < a.S) prefetch_round(s + nsg, 0);
 
-      // ---- VALU: lane group `grp` owns destination r*16 + grp
-      const int i = r * NG + grp;
-      if (i < dcount) {
-        const int64_t drow = erow0 + d_edge[i];
-        const Vec4<float> old = load4<float>(a.edge_in + drow * FP + c0);
+      // ---- VALU: lane group `grp` owns destination r*16 + slot
+      const int rem = dcount - r * NG;
+      const bool split = rem <= NG / 2;                        // uniform over the workgroup
+      const int slot = split ? (grp & (NG / 2 - 1)) : grp;
+      const int part = split ? (grp >> 3) : 0;                 // which half of the triplets
+      const bool active = slot < rem;
+      const int i = r * NG + slot;
+      const int64_t drow = active ? erow0 + d_edge[i] : 0;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      Vec4<float> old;
+      if (active) {
+        if (part == 0) old = load4<float>(a.edge_in + drow * FP + c0);
         float pf[4], pc[4];
         {
-          const Vec4<float> xf = load4<float>(bufP + grp * LDQ + c0), xc = load4<float>(bufP + grp * LDQ + FP + c0);
+          const Vec4<float> xf = load4<float>(bufP + slot * LDQ + c0), xc = load4<float>(bufP + slot * LDQ + FP + c0);
           const Vec4<float> jf = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + c0);
           const Vec4<float> jc = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + FP + c0);
 #pragma unroll
@@ -338,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             pc[k] = xc.v[k] + nkc.v[k] + jc.v[k];
           }
         }
-        if (i + NG < dcount) {  // next round's Wk node[a_d]
-          const float *nk = a.np3 + (nrow0 + d_a[i + NG]) * (6 * FP) + 4 * FP + c0;
+        if (const int inext = (r + 1 < nrounds) ? dest_index(r + 1) : -1; inext >= 0) {  // next round's Wk node[a_d]
+          const float *nk = a.np3 + (nrow0 + d_a[inext]) * (6 * FP) + 4 * FP + c0;
           nkf = load4<float>(nk);
           nkc = load4<float>(nk + FP);
         }
@@ -357,7 +371,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         sp = lg_sum<LG>(sp);
 
         const int rb = d_rb[i], cnt = (RN_FUSED_EXPERIMENT == 1) ? 0 : d_cnt[i], rskip = d_skip[i];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int half = split ? (cnt + 1) / 2 : cnt;
+        const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's triplets
         if constexpr (FASTG) {
           // pd = p/gamma * (2/2Fe), pg = p*gamma; var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
           float pdf[4], pdc[4];
@@ -394,21 +409,21 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           // two independent triplets per iteration: at two waves per SIMD the second chain
           // fills the dependency stalls of the first (summation order: even/odd partial sums)
           float acc2[4] = {0.f, 0.f, 0.f, 0.f};
-          int t = 0;
-          for (; t + 1 < cnt; t += 2) {
+          int t = t0;
+          for (; t + 1 < t1; t += 2) {
             const int r0 = rb + t + ((rb + t >= rskip) ? 1 : 0);
             const int r1 = rb + t + 1 + ((rb + t + 1 >= rskip) ? 1 : 0);
             triplet(r0, acc);
             triplet(r1, acc2);
           }
-          if (t < cnt) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
+          if (t < t1) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
 #else
-          for (int t = 0; t < cnt; ++t) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
+          for (int t = t0; t < t1; ++t) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
 #endif
         } else {
-          for (int t = 0; t < cnt; ++t) {
+          for (int t = t0; t < t1; ++t) {
             const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
             const float *qr = bufQ + rq * LDQ + c0;
             const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
@@ -428,12 +443,24 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             }
           }
         }
+      }
+      if (split) {  // second halves reach their partner through the unused rows 8..15 of bufP
+        float *xch = bufP + (NG / 2 + slot) * LDQ + c0;
+        if (active && part == 1) store4(xch, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
+        __syncthreads();
+        if (active && part == 0) {
+          const Vec4<float> other = load4<float>(xch);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += other.v[k];
+        }
+      }
+      if (active && part == 0) {
         const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
         const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
         // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
         const LnParams<float> p2f{load4<float>(s_c2n1g + c0), load4<float>(s_c2n1b + c0)};
         const LnParams<float> p2c{load4<float>(s_c2n1g + FP + c0), load4<float>(s_c2n1b + FP + c0)};
-        const Vec4<float> c2f = load4<float>(bufC + grp * LDQ + c0), c2c = load4<float>(bufC + grp * LDQ + FP + c0);
+        const Vec4<float> c2f = load4<float>(bufC + slot * LDQ + c0), c2c = load4<float>(bufC + slot * LDQ + FP + c0);
         const Vec4<float> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
         const LnParams<float> p2n{load4<float>(s_c2n2g + c0), load4<float>(s_c2n2b + c0)};
         const Vec4<float> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);

@@ -5,6 +5,7 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int SHAPE>
 __global__ __launch_bounds__(512) void k(float *out, int iters, int mode) {
@@ -20,6 +21,16 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, int mode) {
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
           c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c2, 0, 0, 0);
           c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
+        }
+        r = c0[0] + c1[1] + c2[2] + c3[3];
+      } else if (SHAPE == 1616) {  // bf16 16x16x16 (matrix core proper)
+        f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+        s16x4 a = {(short)threadIdx.x, 0x3f80, 0x3f00, 0x3e80}, b = {0x3f80, (short)(threadIdx.x * 3), 0x3f00, 0x3f80};
+        for (int i = 0; i < iters; ++i) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c2, 0, 0, 0);
+          c3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c3, 0, 0, 0);
         }
         r = c0[0] + c1[1] + c2[2] + c3[3];
       } else {
@@ -61,7 +72,7 @@ void run(const char *name, float *d, int iters) {
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double mf = (SHAPE == 16 ? 4.0 : 2.0) * iters, vf = 32.0 * iters;
+    const double mf = (SHAPE == 32 ? 2.0 : 4.0) * iters, vf = 32.0 * iters;
     printf("%s mode %d (%s): %.3f ms  -> per MFMA %.1f ns, per VALU fma %.2f ns\n", name, mode,
            mode == 1 ? "MFMA only" : mode == 2 ? "VALU only" : "both", ms, ms * 1e6 / mf, ms * 1e6 / vf);
   }
@@ -70,5 +81,6 @@ int main() {
   float *d; hipMalloc(&d, 4096);
   run<16>("16x16x4f32", d, 20000);
   run<32>("32x32x2f32", d, 20000);
+  run<1616>("16x16x16bf16", d, 20000);
   return 0;
 }
