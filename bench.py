@@ -158,21 +158,33 @@ def projection_roofline(times, e, fn, fe, frames, passes, steps):
 
 
 def cpu_baseline(workload, sample):
-    """The oracle's faithful restatement of the reference CPU path, on `sample` frames."""
+    """The oracle's faithful restatement of the reference CPU path, on `sample` frames; the
+    O(S E) variant of the same arithmetic (no N^2 geometry, no materialised concat, linear
+    readout) and a single-thread run are reported next to it so that the ratio to
+    the GPU is not inflated by the reference's avoidable quadratic terms."""
     from oracle import potgnn_oracle as O
     # a 1-GPU box grants ~16 host cores however many the machine has; more torch threads
     # than that only oversubscribes (measured: 256 threads were 3x slower than 16)
     threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
-    torch.set_num_threads(threads)
     model = workload["oracle"]()
     pos = workload["positions"][:sample]
-    O.calc_polarizabilities(model, pos[:2])  # warm-up
-    t0 = time.perf_counter()
-    O.calc_polarizabilities(model, pos, faithful=True)
-    dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "structures/s", "cores": threads, "kind": "port",
+
+    def rate(frames, faithful, nthreads):
+        torch.set_num_threads(nthreads)
+        O.calc_polarizabilities(model, pos[:2], faithful=faithful)  # warm-up
+        t0 = time.perf_counter()
+        O.calc_polarizabilities(model, pos[:frames], faithful=faithful)
+        dt = time.perf_counter() - t0
+        return frames / dt, dt
+
+    value, dt = rate(sample, True, threads)
+    sane, _ = rate(sample, False, threads)
+    single, _ = rate(max(sample // 5, 2), True, 1)
+    torch.set_num_threads(threads)
+    return {"value": value, "unit": "structures/s", "cores": threads, "kind": "port",
             "sample": f"{sample} frames of the same workload, oracle faithful variant "
-                      f"(100-frame sub-batches, N^2 geometry, O(S^2 E) readout), {dt:.1f} s"}
+                      f"(100-frame sub-batches, N^2 geometry, O(S^2 E) readout), {dt:.1f} s",
+            "linear_variant_structures_per_s": sane, "single_thread_structures_per_s": single}
 
 
 def main():

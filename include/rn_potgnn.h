@@ -177,6 +177,22 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
  */
 int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads);
 
+/*
+ * Data-parallel training (gradient all-reduce plus all-reduced BatchNorm batch
+ * statistics for single-device parity).  With a reducer installed, rn_potgnn_train_forward /
+ * _backward hand it the float64 column sums of the readout BatchNorm (forward: sum z, sum z^2
+ * and the row count; backward: sum dy, sum dy*zhat) and continue with what it leaves in
+ * `values`: the element-wise SUM over all ranks.  Every rank must take the same number of
+ * training steps.  The parameter gradients returned by rn_potgnn_train_backward are those of
+ * this rank's rows; averaging them over ranks (what DistributedDataParallel does) gives the
+ * gradient of the mean loss over the global batch.  fn == NULL removes the reducer.
+ * rn_potgnn_train_row_count: rows the last train_forward's statistics covered (all ranks),
+ * for the unbiased running variance.
+ */
+typedef int (*rn_potgnn_reduce_fn)(double *values, int64_t count, void *ctx);
+int rn_potgnn_set_stat_reducer(rn_potgnn *h, rn_potgnn_reduce_fn fn, void *ctx);
+double rn_potgnn_train_row_count(const rn_potgnn *h);
+
 /* ------------------------------------------------------------------ introspection */
 
 /* Introspection: bit 0 = the fused EdgeBlock kernel is in use (float32, Fn and Fe padded to

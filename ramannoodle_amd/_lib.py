@@ -42,6 +42,8 @@ _P = C.c_void_p
 SIGNATURES = {
     "rn_potgnn_radius_graph": (C.c_int, [_P, _P, C.c_int32, C.c_double, C.c_int, _P]),
     "rn_potgnn_config_flags": (C.c_int, [_P]),
+    "rn_potgnn_set_stat_reducer": (C.c_int, [_P, _P, _P]),
+    "rn_potgnn_train_row_count": (C.c_double, [_P]),
     "rn_potgnn_weight_count": (C.c_size_t, [C.POINTER(Config)]),
     "rn_potgnn_create": (C.c_int, [C.POINTER(Config), _P, _P, _P, _P, _P, C.c_size_t, _P, _P,
                                    C.POINTER(_P)]),

@@ -151,6 +151,9 @@ struct rn_potgnn {
   DeviceBuf io_pos, io_alpha, io_vec6;
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
+  double bn_count = 0;  // rows the pending step's BatchNorm statistics cover (all ranks)
+  rn_potgnn_reduce_fn reducer = nullptr;  // data-parallel training: sums doubles over ranks
+  void *reducer_ctx = nullptr;
   bool last_was_f64 = false;
   // profiling
   int profiling = 0;
@@ -356,6 +359,17 @@ template <>
 Precision<float> &prec<float>(rn_potgnn *h) { return h->f32; }
 template <>
 Precision<double> &prec<double>(rn_potgnn *h) { return h->f64; }
+
+// Sum `n` device doubles over the ranks of a data-parallel training run (no-op without a reducer).
+void reduce_over_ranks(rn_potgnn *h, double *dev, size_t n, hipStream_t st) {
+  if (!h->reducer) return;
+  std::vector<double> host(n);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpy(host.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (h->reducer(host.data(), (int64_t)n, h->reducer_ctx) != 0)
+    throw HipError{hipErrorUnknown, "the statistics reducer (data-parallel training) failed"};
+  HIP_TRY(hipMemcpy(dev, host.data(), n * sizeof(double), hipMemcpyHostToDevice));
+}
 
 size_t per_structure_elems(const rn_potgnn *h) {
   const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges;
@@ -804,8 +818,9 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
   const T *edgeP = P.tape_edge[NP].template as<T>();
   if (rv.train_bn) {
-    launch_bn_train_fwd<T>(P.tape_z1.template as<T>(), fe, HP, d.Fe, P.bn_stats.template as<double>(),
-                           Wd + L.bn_w, Wd + L.bn_b, bufA, b[DH] /*scratch for mean/var*/, st);
+    // (the column sums of train_forward are still in bn_stats, already reduced over ranks)
+    launch_bn_train_apply<T>(P.tape_z1.template as<T>(), fe, HP, d.Fe, P.bn_stats.template as<double>(),
+                             h->bn_count, Wd + L.bn_w, Wd + L.bn_b, bufA, b[DH] /*scratch for mean/var*/, st);
   } else {
     launch_rowgemm<T>(edgeP, fe, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0, nullptr, g, st);
   }
@@ -819,8 +834,11 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   back_gemm(b[DH], ce, HP, L.W3T, L.t_W3, HP, b[DC2], false);                      // d h1
   if (rv.train_bn) {
     launch_ssp_bwd<T>(b[DC2], bufA, nullptr, E, HP, C, B, st);                     // d (BN output)
-    launch_bn_train_bwd<T>(b[DC2], P.tape_z1.template as<T>(), fe, HP, d.Fe,
-                           P.bn_stats.template as<double>(), P.bn_stats.template as<double>() + 2 * HP,
+    double *stats = P.bn_stats.template as<double>(), *sums = stats + 2 * HP, *own = stats + 4 * HP;
+    launch_bn_bwd_sums<T>(b[DC2], P.tape_z1.template as<T>(), fe, HP, d.Fe, stats, h->bn_count, sums, st);
+    HIP_TRY(hipMemcpyAsync(own, sums, sizeof(double) * 2 * HP, hipMemcpyDeviceToDevice, st));
+    reduce_over_ranks(h, sums, (size_t)2 * HP, st);
+    launch_bn_bwd_apply<T>(b[DC2], P.tape_z1.template as<T>(), fe, HP, d.Fe, stats, h->bn_count, sums, own,
                            Wd + L.bn_w, G + L.bn_w, G + L.bn_b, st);               // d z1
     launch_gemm_tn<T>(edgeP, d.FeP, b[DC2], HP, ce, d.FeP, HP, G + L.W0T, HP, G + L.b0p, 0, nullptr, g, st);
   } else {
@@ -970,15 +988,27 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, flo
   const int64_t R = (int64_t)S * g.E;
   T *Wd = P.weights.as<T>();
   P.tape_z1.ensure((size_t)R * HP * sizeof(T));
-  P.bn_stats.ensure(sizeof(double) * 4 * HP);
+  P.bn_stats.ensure(sizeof(double) * 6 * HP);  // forward sums (+ row count during the reduction) | backward sums | own copy
   DeviceBuf &mv = P.mv;
   mv.ensure(sizeof(T) * 2 * HP);
   const T *edgeP = P.tape_edge[h->cfg.num_message_passes].as<T>();
   // z1 = edge W0^T + b0 ; h1 = ssp(BN_batch(z1)) ; then the rest of the readout as in eval
   launch_rowgemm<T>(edgeP, R, d.FeP, P.ro.W0T, HP, P.tape_z1.as<T>(), nullptr, Wd + L.b0p, false, 0,
                     nullptr, g, st);
-  launch_bn_train_fwd<T>(P.tape_z1.as<T>(), R, HP, d.Fe, P.bn_stats.as<double>(), Wd + L.bn_w, Wd + L.bn_b,
-                         c.bufA, mv.as<T>(), st);
+  {
+    // batch statistics over every row of the batch -- of all ranks in a data-parallel run
+    double *stats = P.bn_stats.as<double>();
+    launch_bn_col_sums<T>(P.tape_z1.as<T>(), R, HP, stats, st);
+    h->bn_count = (double)R;
+    if (h->reducer) {
+      const double rows = (double)R;  // slot 2HP is outside the range col_sums clears
+      HIP_TRY(hipMemcpy(stats + 2 * HP, &rows, sizeof(double), hipMemcpyHostToDevice));
+      reduce_over_ranks(h, stats, (size_t)2 * HP + 1, st);  // [sum z | sum z^2 | rows]
+      HIP_TRY(hipMemcpy(&h->bn_count, stats + 2 * HP, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    launch_bn_train_apply<T>(P.tape_z1.as<T>(), R, HP, d.Fe, stats, h->bn_count, Wd + L.bn_w, Wd + L.bn_b,
+                             c.bufA, mv.as<T>(), st);
+  }
   launch_rowgemm<T>(c.bufA, R, HP, P.ro.W3T, HP, c.bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
   launch_rowgemm<T>(c.bufB, R, HP, P.ro.W5T, 32, c.bufA, nullptr, P.ro.b5, false, 0, nullptr, g, st);
   h->io_vec6.ensure((size_t)S * 6 * sizeof(float));
@@ -1537,6 +1567,15 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
   }
   return guarded(h, [&]() { train_forward(h, positions, (int)S, vec6, batch_mean, batch_var); });
 }
+
+int rn_potgnn_set_stat_reducer(rn_potgnn *h, rn_potgnn_reduce_fn fn, void *ctx) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  h->reducer = fn;
+  h->reducer_ctx = ctx;
+  return RN_OK;
+}
+
+double rn_potgnn_train_row_count(const rn_potgnn *h) { return h ? h->bn_count : 0.0; }
 
 int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
   if (!h || !dvec6 || !grads) {

@@ -146,11 +146,17 @@ template <typename T>
 void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
                     int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st);
 template <typename T>
-void launch_bn_train_fwd(const T *z, int64_t R, int W, int F, double *stats, const T *gamma,
-                         const T *beta, T *h, T *mv, hipStream_t st);
+void launch_bn_col_sums(const T *z, int64_t R, int W, double *stats, hipStream_t st);
 template <typename T>
-void launch_bn_train_bwd(T *d, const T *z, int64_t R, int W, int F, const double *stats, double *sums,
-                         const T *gamma, T *dgamma, T *dbeta, hipStream_t st);
+void launch_bn_train_apply(const T *z, int64_t R, int W, int F, const double *stats, double count,
+                           const T *gamma, const T *beta, T *h, T *mv, hipStream_t st);
+template <typename T>
+void launch_bn_bwd_sums(const T *d, const T *z, int64_t R, int W, int F, const double *stats, double count,
+                        double *sums, hipStream_t st);
+template <typename T>
+void launch_bn_bwd_apply(T *d, const T *z, int64_t R, int W, int F, const double *stats, double count,
+                         const double *sums, const double *own_sums, const T *gamma, T *dgamma, T *dbeta,
+                         hipStream_t st);
 template <typename T>
 void launch_node_embed_bwd(const T *dnode0, int S, const Graph &g, Dims d, int K, const T *emb,
                            const T *W2, const T *b2, const T *W4, T *demb, T *dW2, T *db2, T *dW4,

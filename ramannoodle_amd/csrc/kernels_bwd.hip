@@ -1152,16 +1152,16 @@ __global__ void col_sums_kernel(const T *__restrict__ z, int64_t R, int W, doubl
 // batch mean and biased variance (for the running-statistics update) into mv[0:W], mv[W:2W].
 template <typename T>
 __global__ void bn_train_fwd_kernel(const T *__restrict__ z, int64_t R, int W, int F,
-                                    const double *__restrict__ stats, const T *__restrict__ gamma,
-                                    const T *__restrict__ beta, T *__restrict__ h,
-                                    T *__restrict__ mv) {
+                                    const double *__restrict__ stats, double count,
+                                    const T *__restrict__ gamma, const T *__restrict__ beta,
+                                    T *__restrict__ h, T *__restrict__ mv) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * W) return;
   const int c = (int)(idx % W);
   T out = 0;
   if (c < F) {
-    const double mean = stats[c] / (double)R;
-    double var = stats[W + c] / (double)R - mean * mean;
+    const double mean = stats[c] / count;
+    double var = stats[W + c] / count - mean * mean;
     var = var > 0 ? var : 0;
     const T rstd = (T)(1.0 / sqrt(var + 1e-5));
     out = ssp(gamma[c] * ((z[idx] - (T)mean) * rstd) + beta[c]);
@@ -1177,13 +1177,13 @@ __global__ void bn_train_fwd_kernel(const T *__restrict__ z, int64_t R, int W, i
 //   pass 2 (bn_bwd_apply): d <- gamma * rstd * (dy - mean(dy) - zhat * mean(dy zhat))
 template <typename T>
 __global__ void bn_bwd_sums_kernel(const T *__restrict__ dy, const T *__restrict__ z, int64_t R, int W,
-                                   int F, const double *__restrict__ stats, double *__restrict__ sums,
-                                   int rows_per_block) {
+                                   int F, const double *__restrict__ stats, double count,
+                                   double *__restrict__ sums, int rows_per_block) {
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
   for (int c = threadIdx.x; c < F; c += blockDim.x) {
-    const double mean = stats[c] / (double)R;
-    double var = stats[W + c] / (double)R - mean * mean;
+    const double mean = stats[c] / count;
+    double var = stats[W + c] / count - mean * mean;
     var = var > 0 ? var : 0;
     const double rstd = 1.0 / sqrt(var + 1e-5);
     double a = 0, b = 0;
@@ -1198,7 +1198,8 @@ __global__ void bn_bwd_sums_kernel(const T *__restrict__ dy, const T *__restrict
 }
 template <typename T>
 __global__ void bn_bwd_apply_kernel(T *__restrict__ d, const T *__restrict__ z, int64_t R, int W, int F,
-                                    const double *__restrict__ stats, const double *__restrict__ sums,
+                                    const double *__restrict__ stats, double count,
+                                    const double *__restrict__ sums, const double *__restrict__ own_sums,
                                     const T *__restrict__ gamma, T *__restrict__ dgamma,
                                     T *__restrict__ dbeta) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1208,47 +1209,64 @@ __global__ void bn_bwd_apply_kernel(T *__restrict__ d, const T *__restrict__ z, 
     d[idx] = 0;
     return;
   }
-  const double mean = stats[c] / (double)R;
-  double var = stats[W + c] / (double)R - mean * mean;
+  const double mean = stats[c] / count;
+  double var = stats[W + c] / count - mean * mean;
   var = var > 0 ? var : 0;
   const double rstd = 1.0 / sqrt(var + 1e-5);
   const double zhat = ((double)z[idx] - mean) * rstd;
-  const double ma = sums[c] / (double)R, mb = sums[W + c] / (double)R;
+  const double ma = sums[c] / count, mb = sums[W + c] / count;
   d[idx] = (T)((double)gamma[c] * rstd * ((double)d[idx] - ma - zhat * mb));
-  if (idx < W) {
-    dbeta[c] += (T)sums[c];
-    dgamma[c] += (T)sums[W + c];
+  if (idx < W) {  // parameter gradients from this rank's rows only (averaged across ranks later)
+    dbeta[c] += (T)own_sums[c];
+    dgamma[c] += (T)own_sums[W + c];
   }
 }
 
+// The four steps are separate launches because a data-parallel run all-reduces the column
+// sums between (col_sums, apply) and between (bwd_sums, bwd_apply); `count` is the number of
+// rows the statistics cover (all ranks), R the rows of this rank.
 template <typename T>
-void launch_bn_train_fwd(const T *z, int64_t R, int W, int F, double *stats, const T *gamma,
-                         const T *beta, T *h, T *mv, hipStream_t st) {
-  if (R == 0) return;
+void launch_bn_col_sums(const T *z, int64_t R, int W, double *stats, hipStream_t st) {
   (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * W, st);
+  if (R == 0) return;
   const int rpb = 256;
   col_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(z, R, W, stats, rpb);
-  bn_train_fwd_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(z, R, W, F, stats, gamma, beta,
-                                                                          h, mv);
 }
 template <typename T>
-void launch_bn_train_bwd(T *d, const T *z, int64_t R, int W, int F, const double *stats, double *sums,
-                         const T *gamma, T *dgamma, T *dbeta, hipStream_t st) {
+void launch_bn_train_apply(const T *z, int64_t R, int W, int F, const double *stats, double count,
+                           const T *gamma, const T *beta, T *h, T *mv, hipStream_t st) {
   if (R == 0) return;
-  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * W, st);
-  const int rpb = 256;
-  bn_bwd_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(d, z, R, W, F, stats, sums, rpb);
-  bn_bwd_apply_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(d, z, R, W, F, stats, sums,
-                                                                          gamma, dgamma, dbeta);
+  bn_train_fwd_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(z, R, W, F, stats, count, gamma,
+                                                                          beta, h, mv);
 }
-template void launch_bn_train_fwd<float>(const float *, int64_t, int, int, double *, const float *,
-                                         const float *, float *, float *, hipStream_t);
-template void launch_bn_train_fwd<double>(const double *, int64_t, int, int, double *, const double *,
-                                          const double *, double *, double *, hipStream_t);
-template void launch_bn_train_bwd<double>(double *, const double *, int64_t, int, int, const double *,
-                                          double *, const double *, double *, double *, hipStream_t);
-template void launch_bn_train_bwd<float>(float *, const float *, int64_t, int, int, const double *,
-                                         double *, const float *, float *, float *, hipStream_t);
+template <typename T>
+void launch_bn_bwd_sums(const T *d, const T *z, int64_t R, int W, int F, const double *stats, double count,
+                        double *sums, hipStream_t st) {
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * W, st);
+  if (R == 0) return;
+  const int rpb = 256;
+  bn_bwd_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(d, z, R, W, F, stats, count, sums, rpb);
+}
+template <typename T>
+void launch_bn_bwd_apply(T *d, const T *z, int64_t R, int W, int F, const double *stats, double count,
+                         const double *sums, const double *own_sums, const T *gamma, T *dgamma, T *dbeta,
+                         hipStream_t st) {
+  if (R == 0) return;
+  bn_bwd_apply_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(d, z, R, W, F, stats, count, sums,
+                                                                          own_sums, gamma, dgamma, dbeta);
+}
+#define RN_BN_INST(T)                                                                                     \
+  template void launch_bn_col_sums<T>(const T *, int64_t, int, double *, hipStream_t);                    \
+  template void launch_bn_train_apply<T>(const T *, int64_t, int, int, const double *, double, const T *, \
+                                         const T *, T *, T *, hipStream_t);                               \
+  template void launch_bn_bwd_sums<T>(const T *, const T *, int64_t, int, int, const double *, double,    \
+                                      double *, hipStream_t);                                             \
+  template void launch_bn_bwd_apply<T>(T *, const T *, int64_t, int, int, const double *, double,         \
+                                       const double *, const double *, const T *, T *, T *, hipStream_t);
+RN_BN_INST(float)
+RN_BN_INST(double)
+#undef RN_BN_INST
+
 
 // ---- node embedding MLP (Embedding -> ssp -> Linear -> ssp -> Linear, _gnn.py:508-514):
 // gradient of the K x Fn table rows w.r.t. emb, W2, b2, W4, b4.  dnode0 [S*N, FnP] is first

@@ -49,3 +49,31 @@ def calc_polarizabilities_sharded(model, positions_batch: np.ndarray, group=None
     if on_gpu:
         tensor = tensor.cuda()
     return all_gather_frames(tensor, total, group).cpu().numpy()
+
+
+def average_gradients(model, group=None) -> None:
+    """Data-parallel training step, after ``loss.backward()``: replace every parameter
+    gradient by its mean over the ranks (ONE flat all-reduce, <= 1.2 MB for Fn=Fe=64)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in model.parameters() if p.grad is not None]
+    if not params:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    buf = flat.cuda() if dist.get_backend(group) == "nccl" else flat
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    flat = buf.cpu() / dist.get_world_size(group)
+    offset = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[offset:offset + n].reshape(p.grad.shape))
+        offset += n
+
+
+def batch_shard(tensors, group=None):
+    """This rank's contiguous block of every tensor of a mini-batch (first dimension)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, _ = shard_bounds(tensors[0].shape[0], world, rank)
+    return tuple(t[lo:hi] for t in tensors)

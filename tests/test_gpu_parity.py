@@ -4,6 +4,8 @@ reference and against the CPU oracle.  Needs a real MI355X: run with ``-m gpu``.
 Tolerances (float32 path): per-stage intermediates atol 2e-5 on O(1) values; final
 polarizabilities within 1e-5 relative (the north-star bar); indices bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -341,6 +343,34 @@ def test_training_step_gradients_match_reference():
     np.testing.assert_allclose(sd["_to_polarizability_embedding.1.running_var"].numpy(),
                                g["train/running_var"], rtol=1e-5, atol=1e-6)
     assert int(sd["_to_polarizability_embedding.1.num_batches_tracked"]) == 1
+
+
+def test_data_parallel_training_step_matches_reference(tmp_path):
+    """Two ranks (gloo, both on this GPU), half of the fixture batch each: BatchNorm statistics
+    all-reduced inside the device step and gradients averaged over the ranks must reproduce the
+    reference's single-process step on the whole batch."""
+    import socket
+    import subprocess
+    import sys
+    g = load_golden("triclinic20_train")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = tmp_path / "dp.npz"
+    worker = os.path.join(os.path.dirname(__file__), "dp_train_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(out)]) for r in range(2)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0, 0], codes
+    got = np.load(out)
+    np.testing.assert_allclose(got["out"], g["train/out"], rtol=0, atol=1e-5)
+    assert float(got["loss"]) == pytest.approx(float(g["train/loss"]), rel=1e-5)
+    for key in g.files:
+        if key.startswith("train/grad/"):
+            ref = g[key]
+            np.testing.assert_allclose(got["grad/" + key[len("train/grad/"):]], ref, rtol=0,
+                                       atol=3e-4 * np.abs(ref).max() + 1e-6, err_msg=key)
+    np.testing.assert_allclose(got["running_mean"], g["train/running_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["running_var"], g["train/running_var"], rtol=1e-5, atol=1e-6)
 
 
 def test_train_single_epoch_reduces_loss():

@@ -69,3 +69,54 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             for (lo, hi, per), (lo2, _, _) in zip(spans, spans[1:]):
                 assert hi == lo2 and hi - lo <= per
+
+
+class _TorchModel(torch.nn.Module):
+    """Host stand-in with the surface ``train_single_epoch`` uses; BatchNorm-free, so the
+    data-parallel step must equal the single-process step on the whole mini-batch."""
+
+    def __init__(self, group=None):
+        super().__init__()
+        torch.manual_seed(3)
+        self.lin = torch.nn.Linear(6, 6)
+        self.data_parallel_group = group
+
+    def forward(self, lattice, atomic_numbers, position):  # pylint: disable=unused-argument
+        return self.lin(position.reshape(position.shape[0], -1)[:, :6])
+
+
+def _dataset(n):
+    rng = np.random.default_rng(1)
+    pos = torch.tensor(rng.normal(size=(n, 2, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.normal(size=(n, 6)), dtype=torch.float32)
+    lat = torch.eye(3).expand(n, 3, 3)
+    zs = torch.ones(n, 2, dtype=torch.int32)
+    return torch.utils.data.TensorDataset(lat, zs, pos, target)
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ramannoodle_amd.pmodel.train import train_single_epoch
+        model = _TorchModel(group=dist.group.WORLD)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        train_single_epoch(model, _dataset(16), _dataset(4), 8, opt, torch.nn.MSELoss())
+        torch.save(model.state_dict(), os.path.join(out_dir, f"dp{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_epoch_equals_single_process(tmp_path):
+    """``train_single_epoch`` with a process group: same shuffled mini-batches on every rank,
+    contiguous blocks, gradients averaged -> same parameters as one process on full batches."""
+    from ramannoodle_amd.pmodel.train import train_single_epoch
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = _TorchModel()
+    opt = torch.optim.SGD(single.parameters(), lr=0.1)
+    train_single_epoch(single, _dataset(16), _dataset(4), 8, opt, torch.nn.MSELoss())
+    for r in range(2):
+        got = torch.load(tmp_path / f"dp{r}.pt")
+        for k, v in single.state_dict().items():
+            torch.testing.assert_close(got[k], v, rtol=1e-5, atol=1e-6)

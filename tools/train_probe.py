@@ -15,7 +15,12 @@ pos = torch.tensor(wl["positions"], dtype=torch.float32)
 target = torch.randn(batch, 6)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 model.train()
-for it in range(6):
+if os.environ.get("RN_PROBE_NOGC"):
+    import gc
+    gc.disable()
+if os.environ.get("RN_PROBE_THREADS"):
+    torch.set_num_threads(int(os.environ["RN_PROBE_THREADS"]))
+for it in range(int(os.environ.get("RN_PROBE_STEPS", "6"))):
     t0 = time.perf_counter()
     out = model.forward(lat, z, pos)
     t1 = time.perf_counter()
