@@ -23,6 +23,27 @@ __device__ __forceinline__ void atomic_add4(T *p, const Vec4<T> &v) {
   for (int k = 0; k < 4; ++k) atomicAdd(p + k, v.v[k]);
 }
 
+// Parameter-gradient accumulators (LayerNorm gamma / beta) are per lane group; every group of
+// every workgroup adding them straight to the same few hundred global addresses serialises in
+// the memory-side atomic unit (measured: 0.3-0.8 ms per launch at 8 k adders per address,
+// more than the rest of the kernel at training batch sizes).  Sum the G = 256/LG groups of
+// the workgroup in LDS first: one atomic per column and workgroup.  `scratch`: 1024 T.
+// Must be reached by all 256 threads.
+template <int LG, typename T>
+__device__ __forceinline__ void wg_sum_atomic_add(T *scratch, const Vec4<T> &v, T *dst) {
+  constexpr int W = 4 * LG, G = 256 / LG;
+  const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
+  store4(scratch + grp * W + 4 * q, v);
+  __syncthreads();
+  if ((int)threadIdx.x < W) {
+    T s = 0;
+#pragma unroll 4
+    for (int g = 0; g < G; ++g) s += scratch[g * W + threadIdx.x];
+    atomicAdd(dst + threadIdx.x, s);
+  }
+  __syncthreads();
+}
+
 // ---- LayerNorm pieces on the lane-group layout -------------------------------------------
 // forward: normalised values (padded columns -> 0) and 1/sigma of a [filter|core] row
 template <int LG, typename T>
@@ -439,6 +460,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
   };
   T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));
   T *dq = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));
+  if (off < (size_t)1024 * sizeof(T)) off = (size_t)1024 * sizeof(T);  // scratch of wg_sum_atomic_add
   T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));
   T *nj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));
   int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));
@@ -661,25 +683,28 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
     }
     __syncthreads();
   }
-  if (want_param_grads) {
-    atomic_add4(const_cast<T *>(gw.c3_norm_1.g) + 4 * q, G31f);
-    atomic_add4(const_cast<T *>(gw.c3_norm_1.b) + 4 * q, B31f);
-    atomic_add4(const_cast<T *>(gw.c3_norm_1.g) + FP + 4 * q, G31c);
-    atomic_add4(const_cast<T *>(gw.c3_norm_1.b) + FP + 4 * q, B31c);
-    atomic_add4(const_cast<T *>(gw.c3_norm_2.g) + 4 * q, G32);
-    atomic_add4(const_cast<T *>(gw.c3_norm_2.b) + 4 * q, B32);
-    atomic_add4(const_cast<T *>(gw.c2_norm_1.g) + 4 * q, G21f);
-    atomic_add4(const_cast<T *>(gw.c2_norm_1.b) + 4 * q, B21f);
-    atomic_add4(const_cast<T *>(gw.c2_norm_1.g) + FP + 4 * q, G21c);
-    atomic_add4(const_cast<T *>(gw.c2_norm_1.b) + FP + 4 * q, B21c);
-    atomic_add4(const_cast<T *>(gw.c2_norm_2.g) + 4 * q, G22);
-    atomic_add4(const_cast<T *>(gw.c2_norm_2.b) + 4 * q, B22);
+  if (want_param_grads) {  // (uniform) qrows is free after the last frame: reduction scratch
+    __syncthreads();
+    wg_sum_atomic_add<LG>(qrows, G31f, const_cast<T *>(gw.c3_norm_1.g));
+    wg_sum_atomic_add<LG>(qrows, B31f, const_cast<T *>(gw.c3_norm_1.b));
+    wg_sum_atomic_add<LG>(qrows, G31c, const_cast<T *>(gw.c3_norm_1.g) + FP);
+    wg_sum_atomic_add<LG>(qrows, B31c, const_cast<T *>(gw.c3_norm_1.b) + FP);
+    wg_sum_atomic_add<LG>(qrows, G32, const_cast<T *>(gw.c3_norm_2.g));
+    wg_sum_atomic_add<LG>(qrows, B32, const_cast<T *>(gw.c3_norm_2.b));
+    wg_sum_atomic_add<LG>(qrows, G21f, const_cast<T *>(gw.c2_norm_1.g));
+    wg_sum_atomic_add<LG>(qrows, B21f, const_cast<T *>(gw.c2_norm_1.b));
+    wg_sum_atomic_add<LG>(qrows, G21c, const_cast<T *>(gw.c2_norm_1.g) + FP);
+    wg_sum_atomic_add<LG>(qrows, B21c, const_cast<T *>(gw.c2_norm_1.b) + FP);
+    wg_sum_atomic_add<LG>(qrows, G22, const_cast<T *>(gw.c2_norm_2.g));
+    wg_sum_atomic_add<LG>(qrows, B22, const_cast<T *>(gw.c2_norm_2.b));
   }
 }
 
 static size_t edge_bwd_tile_lds(const Graph &g, int FP, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
-  return 2 * up((size_t)g.max_tile_out_rows * 2 * FP * elem) + up((size_t)g.max_tile_out_rows * elem) +
+  // (the two row arrays double as the 1024-element scratch of wg_sum_atomic_add)
+  const size_t row_arrays = std::max(2 * up((size_t)g.max_tile_out_rows * 2 * FP * elem), (size_t)1024 * elem);
+  return row_arrays + up((size_t)g.max_tile_out_rows * elem) +
          up((size_t)g.max_tile_nodes * 2 * FP * elem) + up((size_t)g.max_tile_out_rows * 4) +
          up((size_t)g.max_tile_in_rows * 6 * 4);
 }
@@ -730,10 +755,11 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(
     T *__restrict__ dnpc1, int C, int B, Graph g, Dims d, PassW<T> w, PassW<T> gw,
     int want_param_grads) {
   constexpr int FP = LG * 4;
+  __shared__ __attribute__((aligned(16))) T scratch[1024];
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
   const int q = threadIdx.x % LG;
-  if (gid >= (int64_t)C * g.N) return;
   Vec4<T> G1f{{0, 0, 0, 0}}, B1f = G1f, G1c = G1f, B1c = G1f, G2 = G1f, B2 = G1f;
+  if (gid < (int64_t)C * g.N) {
   const int c = (int)(gid / g.N), b = (int)(gid % g.N);
   const int s = c / B;
   const int64_t frow = (int64_t)s * g.N + b;
@@ -815,13 +841,14 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(
   }
   store4(dnpc1 + gid * (2 * FP) + 4 * q, sf);
   store4(dnpc1 + gid * (2 * FP) + FP + 4 * q, sc);
-  if (want_param_grads) {
-    atomic_add4(const_cast<T *>(gw.c1_norm.g) + 4 * q, G1f);
-    atomic_add4(const_cast<T *>(gw.c1_norm.b) + 4 * q, B1f);
-    atomic_add4(const_cast<T *>(gw.c1_norm.g) + FP + 4 * q, G1c);
-    atomic_add4(const_cast<T *>(gw.c1_norm.b) + FP + 4 * q, B1c);
-    atomic_add4(const_cast<T *>(gw.final_norm.g) + 4 * q, G2);
-    atomic_add4(const_cast<T *>(gw.final_norm.b) + 4 * q, B2);
+  }
+  if (want_param_grads) {  // (uniform) lane groups past the end contribute zeros
+    wg_sum_atomic_add<LG>(scratch, G1f, const_cast<T *>(gw.c1_norm.g));
+    wg_sum_atomic_add<LG>(scratch, B1f, const_cast<T *>(gw.c1_norm.b));
+    wg_sum_atomic_add<LG>(scratch, G1c, const_cast<T *>(gw.c1_norm.g) + FP);
+    wg_sum_atomic_add<LG>(scratch, B1c, const_cast<T *>(gw.c1_norm.b) + FP);
+    wg_sum_atomic_add<LG>(scratch, G2, const_cast<T *>(gw.final_norm.g));
+    wg_sum_atomic_add<LG>(scratch, B2, const_cast<T *>(gw.final_norm.b));
   }
 }
 
