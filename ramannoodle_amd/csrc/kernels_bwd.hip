@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
   if (off < (size_t)1024 * sizeof(T)) off = (size_t)1024 * sizeof(T);  // scratch of wg_sum_atomic_add
   T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));
   T *nj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));
+  T *dnj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));  // d(Wj node[j] + bias), tile atoms
   int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));
   int *dl = reinterpret_cast<int *>(carve((size_t)maxD * 6 * 4));
   int *d_edge = dl, *d_a = dl + maxD, *d_bl = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
     for (int i = threadIdx.x; i < (j1 - j0) * (2 * FP / 4); i += 256) {
       const int n = i / (2 * FP / 4), cc = (i % (2 * FP / 4)) * 4;
       store4(nj + (size_t)n * 2 * FP + cc, load4<T>(np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + cc));
+      store4(dnj + (size_t)n * 2 * FP + cc, Vec4<T>{{0, 0, 0, 0}});
     }
     for (int r = grp; r < rows; r += G) {  // centred source rows, as in the forward kernel
       const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
@@ -585,7 +587,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
       }
       Vec4<T> dpf{{0, 0, 0, 0}}, dpc{{0, 0, 0, 0}};
       const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
-      for (int t = 0; t < cnt; ++t) {
+      // destinations of one atom walk the same source rows: start each lane group at a
+      // different row so that their LDS atomics on dq do not meet at one address
+      const int tstart = cnt > 0 ? (grp * 5) % cnt : 0;
+      for (int tt = 0; tt < cnt; ++tt) {
+        const int t = tt + tstart < cnt ? tt + tstart : tt + tstart - cnt;
         const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
         const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
         const Vec4<T> qf = load4<T>(qr), qc = load4<T>(qr + FP);
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
         dot = lg_sum<LG>(dot);
         T var = (sp + sq[r] + (T)2 * dot) * inv2n;
         var = var > (T)0 ? var : (T)0;
-        const T rstd = (T)1 / sqrt(var + (T)1e-5);
+        const T rstd = fast_rsq(var + (T)1e-5);
         Vec4<T> hf, hc, df, dc;
         T sa = 0, sb = 0;
 #pragma unroll
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
       store4(dpq + cdrow * (4 * FP) + 4 * q, dpf);
       store4(dpq + cdrow * (4 * FP) + FP + 4 * q, dpc);
       {
-        T *dj = dnp3 + (cnrow0 + j0 + d_bl[i]) * (6 * FP) + 2 * FP + 4 * q;
+        T *dj = dnj + (size_t)d_bl[i] * 2 * FP + 4 * q;  // LDS: the atom belongs to this tile only
         T *dk = dnp3 + (cnrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
         atomic_add4(dj, dpf);
         atomic_add4(dj + FP, dpc);
@@ -681,6 +687,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
       store4(o, load4<T>(dq + (size_t)r * 2 * FP + 4 * q));
       store4(o + FP, load4<T>(dq + (size_t)r * 2 * FP + FP + 4 * q));
     }
+    for (int ii = threadIdx.x; ii < (j1 - j0) * (2 * FP / 4); ii += 256) {
+      const int n = ii / (2 * FP / 4), cc = (ii % (2 * FP / 4)) * 4;
+      store4(dnp3 + (cnrow0 + j0 + n) * (6 * FP) + 2 * FP + cc, load4<T>(dnj + (size_t)n * 2 * FP + cc));
+    }
     __syncthreads();
   }
   if (want_param_grads) {  // (uniform) qrows is free after the last frame: reduction scratch
@@ -700,12 +710,328 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
   }
 }
 
+// ---- two-pass variant without LDS atomics ------------------------------------------------
+// In edge_bwd_tile_kernel every (destination d, source row r) pair adds its 2Fe-wide term to
+// dP'_d (registers) AND to dQ'_r (ds_add_f32): 8 LDS float atomics per pair and lane, and the
+// LDS atomic unit, not the VALU (7 % busy), sets the pace (measured 0.9 ms per launch at
+// batch 32).  Here the pair term is evaluated twice instead -- once by the lane group that
+// owns d (sums over r: dP'), once by the lane group that owns r (sums over d: dQ') -- so both
+// sums stay in registers and leave with plain stores.  Needs the centred P' rows and the
+// per-destination LayerNorm cotangents of the tile in LDS (one workgroup per CU at Fe = 64).
+template <int FP, typename T>
+__global__ __launch_bounds__(256) void edge_bwd_tile2_kernel(
+    const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
+    const T *__restrict__ edge_next, const T *__restrict__ agg_tape, const T *__restrict__ dedge_next,
+    T *__restrict__ dedge_prev, T *__restrict__ dpq, T *__restrict__ dnp3, T *__restrict__ dc2pre,
+    int C, int B, Graph g, Dims d, PassW<T> w, PassW<T> gw, int want_param_grads) {
+  constexpr int LG = FP / 4;
+  constexpr int G = 256 / LG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    unsigned char *p = smem_raw + off;
+    off += (bytes + 15) & ~size_t(15);
+    return p;
+  };
+  T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));   // centred Q' rows
+  T *prows = reinterpret_cast<T *>(carve((size_t)maxD * 2 * FP * sizeof(T)));   // centred P' rows
+  if (off < (size_t)1024 * sizeof(T)) off = (size_t)1024 * sizeof(T);            // scratch of wg_sum_atomic_add
+  T *dagg_s = reinterpret_cast<T *>(carve((size_t)maxD * FP * sizeof(T)));       // d(sum over triplets), per destination
+  T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));
+  T *sp_s = reinterpret_cast<T *>(carve((size_t)maxD * sizeof(T)));
+  T *nj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));
+  T *dnj = reinterpret_cast<T *>(carve((size_t)maxN * 2 * FP * sizeof(T)));
+  int *qb = reinterpret_cast<int *>(carve((size_t)maxR * 4));
+  int *qn = reinterpret_cast<int *>(carve((size_t)maxR * 4));                    // tile-local atom a_r of a source row
+  int *dl = reinterpret_cast<int *>(carve((size_t)maxD * 6 * 4));
+  int *d_edge = dl, *d_a = dl + maxD, *d_bl = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
+      *d_cnt = dl + 4 * maxD, *d_skip = dl + 5 * maxD;
+
+  const int tile = blockIdx.x % g.num_tiles;
+  const int cg = blockIdx.x / g.num_tiles, ncg = gridDim.x / g.num_tiles;
+  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    qb[r] = g.edge_b[eo0 + r];
+    qn[r] = g.edge_a[eo0 + r] - j0;
+  }
+  for (int i = threadIdx.x; i < dcount; i += 256) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_bl[i] = bd - j0;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+  }
+  __syncthreads();
+
+  const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
+  const int nvalid = min(max(d.Fe - 4 * q, 0), 4);
+  const T inv2n = (T)1 / (T)(2 * d.Fe), invn = (T)1 / (T)d.Fe;
+  const Vec4<T> g1f = load4<T>(w.c3_norm_1.g + 4 * q), b1f = load4<T>(w.c3_norm_1.b + 4 * q);
+  const Vec4<T> g1c = load4<T>(w.c3_norm_1.g + FP + 4 * q), b1c = load4<T>(w.c3_norm_1.b + FP + 4 * q);
+  Vec4<T> G31f{{0, 0, 0, 0}}, B31f = G31f, G31c = G31f, B31c = G31f, G32 = G31f, B32 = G31f;
+  Vec4<T> G21f = G31f, B21f = G31f, G21c = G31f, B21c = G31f, G22 = G31f, B22 = G31f;
+
+  // the term of pair (d, r): x = d(P'_d + Q'_r) through LayerNorm(c3_norm_1) and the gate;
+  // `stats` = also accumulate the LayerNorm parameter gradients (first pass only)
+  auto pair_term = [&](const Vec4<T> &pf, const Vec4<T> &pc, T sp, const Vec4<T> &qf, const Vec4<T> &qc, T sqr,
+                       const Vec4<T> &dagg, bool stats, Vec4<T> &xf, Vec4<T> &xc) {
+    T dot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dot += pf.v[k] * qf.v[k] + pc.v[k] * qc.v[k];
+    dot = lg_sum<LG>(dot);
+    T var = (sp + sqr + (T)2 * dot) * inv2n;
+    var = var > (T)0 ? var : (T)0;
+    const T rstd = fast_rsq(var + (T)1e-5);
+    Vec4<T> hf, hc, df, dc;
+    T sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hf.v[k] = (pf.v[k] + qf.v[k]) * rstd;
+      hc.v[k] = (pc.v[k] + qc.v[k]) * rstd;
+      T sg, th;
+      gate_parts<T>(hf.v[k] * g1f.v[k] + b1f.v[k], hc.v[k] * g1c.v[k] + b1c.v[k], sg, th);
+      const T dyf = dagg.v[k] * th * sg * ((T)1 - sg), dyc = dagg.v[k] * sg * ((T)1 - th * th);
+      if (stats) {
+        B31f.v[k] += dyf;
+        G31f.v[k] += dyf * hf.v[k];
+        B31c.v[k] += dyc;
+        G31c.v[k] += dyc * hc.v[k];
+      }
+      df.v[k] = dyf * g1f.v[k];
+      dc.v[k] = dyc * g1c.v[k];
+      sa += df.v[k] + dc.v[k];
+      sb += df.v[k] * hf.v[k] + dc.v[k] * hc.v[k];
+    }
+    sa = lg_sum<LG>(sa) * inv2n;
+    sb = lg_sum<LG>(sb) * inv2n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xf.v[k] = k < nvalid ? rstd * (df.v[k] - sa - hf.v[k] * sb) : (T)0;
+      xc.v[k] = k < nvalid ? rstd * (dc.v[k] - sa - hc.v[k] * sb) : (T)0;
+    }
+  };
+
+  for (int c = cg; c < C; c += ncg) {
+    const int s = c / B;
+    const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    const int64_t cerow0 = (int64_t)c * g.E, cnrow0 = (int64_t)c * g.N;
+    for (int i = threadIdx.x; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+      const int n = i / (2 * FP / 4), cc = (i % (2 * FP / 4)) * 4;
+      store4(nj + (size_t)n * 2 * FP + cc, load4<T>(np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + cc));
+      store4(dnj + (size_t)n * 2 * FP + cc, Vec4<T>{{0, 0, 0, 0}});
+    }
+    for (int r = grp; r < rows; r += G) {  // centred source rows, as in the forward kernel
+      const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
+      const T *np = np3 + (nrow0 + qb[r]) * (6 * FP) + 4 * q;
+      Vec4<T> f = load4<T>(qp), cc = load4<T>(qp + FP);
+      const Vec4<T> nf = load4<T>(np), nc = load4<T>(np + FP);
+      T sum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f.v[k] += nf.v[k];
+        cc.v[k] += nc.v[k];
+        sum += f.v[k] + cc.v[k];
+      }
+      const T mean = lg_sum<LG>(sum) * inv2n;
+      T ss = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f.v[k] = k < nvalid ? f.v[k] - mean : (T)0;
+        cc.v[k] = k < nvalid ? cc.v[k] - mean : (T)0;
+        ss += f.v[k] * f.v[k] + cc.v[k] * cc.v[k];
+      }
+      ss = lg_sum<LG>(ss);
+      store4(qrows + (size_t)r * 2 * FP + 4 * q, f);
+      store4(qrows + (size_t)r * 2 * FP + FP + 4 * q, cc);
+      if (q == 0) sq[r] = ss;
+    }
+    __syncthreads();  // nj complete
+
+    // ---- per destination: residual-tanh and LayerNorm(c3_norm_2) backward, centred P' -> LDS; c2 branch
+    for (int i = grp; i < dcount; i += G) {
+      const int dst = d_edge[i];
+      const int64_t drow = erow0 + dst, cdrow = cerow0 + dst;
+      const Vec4<T> e1 = load4<T>(edge_next + drow * FP + 4 * q);
+      Vec4<T> dz = load4<T>(dedge_next + cdrow * FP + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz.v[k] *= ((T)1 - e1.v[k] * e1.v[k]);
+      store4(dedge_prev + cdrow * FP + 4 * q, dz);
+      Vec4<T> pf = load4<T>(pq + drow * (4 * FP) + 4 * q), pc = load4<T>(pq + drow * (4 * FP) + FP + 4 * q);
+      {
+        const T *nk = np3 + (nrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
+        const Vec4<T> kf = load4<T>(nk), kc = load4<T>(nk + FP);
+        const Vec4<T> jf = load4<T>(nj + (size_t)d_bl[i] * 2 * FP + 4 * q);
+        const Vec4<T> jc = load4<T>(nj + (size_t)d_bl[i] * 2 * FP + FP + 4 * q);
+        T sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf.v[k] += jf.v[k] + kf.v[k];
+          pc.v[k] += jc.v[k] + kc.v[k];
+          sum += pf.v[k] + pc.v[k];
+        }
+        const T mean = lg_sum<LG>(sum) * inv2n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf.v[k] = k < nvalid ? pf.v[k] - mean : (T)0;
+          pc.v[k] = k < nvalid ? pc.v[k] - mean : (T)0;
+        }
+      }
+      T sp = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sp += pf.v[k] * pf.v[k] + pc.v[k] * pc.v[k];
+      sp = lg_sum<LG>(sp);
+      store4(prows + (size_t)i * 2 * FP + 4 * q, pf);
+      store4(prows + (size_t)i * 2 * FP + FP + 4 * q, pc);
+      if (q == 0) sp_s[i] = sp;
+      {
+        Vec4<T> dagg;
+        const Vec4<T> g2 = load4<T>(w.c3_norm_2.g + 4 * q);
+        Vec4<T> hat = load4<T>(agg_tape + drow * FP + 4 * q);
+        const T rstd = ln1_hat<LG>(hat, invn, nvalid);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dagg.v[k] = dz.v[k] * g2.v[k];
+          B32.v[k] += dz.v[k];
+          G32.v[k] += dz.v[k] * hat.v[k];
+        }
+        ln1_bwd<LG>(dagg, hat, rstd, invn, nvalid);
+        store4(dagg_s + (size_t)i * FP + 4 * q, dagg);
+      }
+      // c2 = LN(gate(LN(c2pre)))  (_gnn.py:223-228)
+      {
+        Vec4<T> xf = load4<T>(c2pre + drow * (2 * FP) + 4 * q), xc = load4<T>(c2pre + drow * (2 * FP) + FP + 4 * q);
+        const T rstd1 = ln2_hat<LG>(xf, xc, inv2n, nvalid);
+        const Vec4<T> gf = load4<T>(w.c2_norm_1.g + 4 * q), bf = load4<T>(w.c2_norm_1.b + 4 * q);
+        const Vec4<T> gc = load4<T>(w.c2_norm_1.g + FP + 4 * q), bc = load4<T>(w.c2_norm_1.b + FP + 4 * q);
+        Vec4<T> gv, da, db;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          gate_grad(xf.v[k] * gf.v[k] + bf.v[k], xc.v[k] * gc.v[k] + bc.v[k], gv.v[k], da.v[k], db.v[k]);
+        Vec4<T> hat = gv;
+        const T rstd2 = ln1_hat<LG>(hat, invn, nvalid);
+        const Vec4<T> g22 = load4<T>(w.c2_norm_2.g + 4 * q);
+        Vec4<T> dg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dg.v[k] = dz.v[k] * g22.v[k];
+          B22.v[k] += dz.v[k];
+          G22.v[k] += dz.v[k] * hat.v[k];
+        }
+        ln1_bwd<LG>(dg, hat, rstd2, invn, nvalid);
+        Vec4<T> df, dc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const T dyf = dg.v[k] * da.v[k], dyc = dg.v[k] * db.v[k];
+          B21f.v[k] += dyf;
+          G21f.v[k] += dyf * xf.v[k];
+          B21c.v[k] += dyc;
+          G21c.v[k] += dyc * xc.v[k];
+          df.v[k] = dyf * gf.v[k];
+          dc.v[k] = dyc * gc.v[k];
+        }
+        ln2_bwd<LG>(df, dc, xf, xc, rstd1, inv2n, nvalid);
+        store4(dc2pre + cdrow * (2 * FP) + 4 * q, df);
+        store4(dc2pre + cdrow * (2 * FP) + FP + 4 * q, dc);
+      }
+    }
+    __syncthreads();  // qrows, prows, dagg complete
+
+    // ---- pass over destinations: dP'_d = sum over source rows
+    for (int i = grp; i < dcount; i += G) {
+      const Vec4<T> pf = load4<T>(prows + (size_t)i * 2 * FP + 4 * q), pc = load4<T>(prows + (size_t)i * 2 * FP + FP + 4 * q);
+      const Vec4<T> dagg = load4<T>(dagg_s + (size_t)i * FP + 4 * q);
+      const T sp = sp_s[i];
+      Vec4<T> dpf{{0, 0, 0, 0}}, dpc{{0, 0, 0, 0}};
+      const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+      for (int t = 0; t < cnt; ++t) {
+        const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
+        const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
+        Vec4<T> xf, xc;
+        pair_term(pf, pc, sp, load4<T>(qr), load4<T>(qr + FP), sq[r], dagg, true, xf, xc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dpf.v[k] += xf.v[k];
+          dpc.v[k] += xc.v[k];
+        }
+      }
+      const int64_t cdrow = cerow0 + d_edge[i];
+      store4(dpq + cdrow * (4 * FP) + 4 * q, dpf);
+      store4(dpq + cdrow * (4 * FP) + FP + 4 * q, dpc);
+      T *dj = dnj + (size_t)d_bl[i] * 2 * FP + 4 * q;  // LDS: the atom belongs to this tile only
+      T *dk = dnp3 + (cnrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
+      atomic_add4(dj, dpf);
+      atomic_add4(dj + FP, dpc);
+      atomic_add4(dk, dpf);
+      atomic_add4(dk + FP, dpc);
+    }
+    // ---- pass over source rows: dQ'_r = sum over the destinations entering the row's atom
+    for (int r = grp; r < rows; r += G) {
+      const Vec4<T> qf = load4<T>(qrows + (size_t)r * 2 * FP + 4 * q), qc = load4<T>(qrows + (size_t)r * 2 * FP + FP + 4 * q);
+      const T sqr = sq[r];
+      const int n = qn[r];
+      const int i0 = g.in_ptr[j0 + n] - di0, i1 = g.in_ptr[j0 + n + 1] - di0;
+      Vec4<T> dqf{{0, 0, 0, 0}}, dqc{{0, 0, 0, 0}};
+      for (int i = i0; i < i1; ++i) {
+        if (d_skip[i] == r) continue;  // r is the reverse of destination i: that triplet does not exist
+        Vec4<T> xf, xc;
+        pair_term(load4<T>(prows + (size_t)i * 2 * FP + 4 * q), load4<T>(prows + (size_t)i * 2 * FP + FP + 4 * q),
+                  sp_s[i], qf, qc, sqr, load4<T>(dagg_s + (size_t)i * FP + 4 * q), false, xf, xc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dqf.v[k] += xf.v[k];
+          dqc.v[k] += xc.v[k];
+        }
+      }
+      T *o = dpq + (cerow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
+      store4(o, dqf);
+      store4(o + FP, dqc);
+    }
+    __syncthreads();  // dnj complete
+    for (int ii = threadIdx.x; ii < (j1 - j0) * (2 * FP / 4); ii += 256) {
+      const int n = ii / (2 * FP / 4), cc = (ii % (2 * FP / 4)) * 4;
+      store4(dnp3 + (cnrow0 + j0 + n) * (6 * FP) + 2 * FP + cc, load4<T>(dnj + (size_t)n * 2 * FP + cc));
+    }
+    __syncthreads();
+  }
+  if (want_param_grads) {  // (uniform) qrows is free after the last frame: reduction scratch
+    wg_sum_atomic_add<LG>(qrows, G31f, const_cast<T *>(gw.c3_norm_1.g));
+    wg_sum_atomic_add<LG>(qrows, B31f, const_cast<T *>(gw.c3_norm_1.b));
+    wg_sum_atomic_add<LG>(qrows, G31c, const_cast<T *>(gw.c3_norm_1.g) + FP);
+    wg_sum_atomic_add<LG>(qrows, B31c, const_cast<T *>(gw.c3_norm_1.b) + FP);
+    wg_sum_atomic_add<LG>(qrows, G32, const_cast<T *>(gw.c3_norm_2.g));
+    wg_sum_atomic_add<LG>(qrows, B32, const_cast<T *>(gw.c3_norm_2.b));
+    wg_sum_atomic_add<LG>(qrows, G21f, const_cast<T *>(gw.c2_norm_1.g));
+    wg_sum_atomic_add<LG>(qrows, B21f, const_cast<T *>(gw.c2_norm_1.b));
+    wg_sum_atomic_add<LG>(qrows, G21c, const_cast<T *>(gw.c2_norm_1.g) + FP);
+    wg_sum_atomic_add<LG>(qrows, B21c, const_cast<T *>(gw.c2_norm_1.b) + FP);
+    wg_sum_atomic_add<LG>(qrows, G22, const_cast<T *>(gw.c2_norm_2.g));
+    wg_sum_atomic_add<LG>(qrows, B22, const_cast<T *>(gw.c2_norm_2.b));
+  }
+}
+
+static size_t edge_bwd_tile2_lds(const Graph &g, int FP, size_t elem) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  const size_t row_arrays = std::max(up((size_t)g.max_tile_out_rows * 2 * FP * elem) +
+                                         up((size_t)g.max_tile_in_rows * 2 * FP * elem), (size_t)1024 * elem);
+  return row_arrays + up((size_t)g.max_tile_in_rows * FP * elem) + up((size_t)g.max_tile_out_rows * elem) +
+         up((size_t)g.max_tile_in_rows * elem) + 2 * up((size_t)g.max_tile_nodes * 2 * FP * elem) +
+         2 * up((size_t)g.max_tile_out_rows * 4) + up((size_t)g.max_tile_in_rows * 6 * 4);
+}
+
 static size_t edge_bwd_tile_lds(const Graph &g, int FP, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   // (the two row arrays double as the 1024-element scratch of wg_sum_atomic_add)
   const size_t row_arrays = std::max(2 * up((size_t)g.max_tile_out_rows * 2 * FP * elem), (size_t)1024 * elem);
   return row_arrays + up((size_t)g.max_tile_out_rows * elem) +
-         up((size_t)g.max_tile_nodes * 2 * FP * elem) + up((size_t)g.max_tile_out_rows * 4) +
+         2 * up((size_t)g.max_tile_nodes * 2 * FP * elem) + up((size_t)g.max_tile_out_rows * 4) +
          up((size_t)g.max_tile_in_rows * 6 * 4);
 }
 
@@ -912,9 +1238,12 @@ static bool launch_edge_bwd_tile(const T *pq, const T *np3, const T *c2pre, cons
                                  const T *agg, const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3,
                                  T *dc2pre, int C, int B, const Graph &g, Dims d, const PassW<T> &w,
                                  const PassW<T> &gwv, int want, hipStream_t st) {
-  const size_t lds = edge_bwd_tile_lds(g, FP, sizeof(T));
+  static const bool no_two_pass = getenv("RN_POTGNN_BWD_ATOMIC") && atoi(getenv("RN_POTGNN_BWD_ATOMIC")) != 0;
+  const size_t lds2 = edge_bwd_tile2_lds(g, FP, sizeof(T));
+  const bool two_pass = !no_two_pass && lds2 <= 160 * 1024 - 512;
+  const size_t lds = two_pass ? lds2 : edge_bwd_tile_lds(g, FP, sizeof(T));
   if (lds > 160 * 1024 - 512) return false;
-  auto kern = &edge_bwd_tile_kernel<FP, T>;
+  auto kern = two_pass ? &edge_bwd_tile2_kernel<FP, T> : &edge_bwd_tile_kernel<FP, T>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1122,10 +1451,113 @@ __global__ __launch_bounds__(256) void gemm_tn_tiled_kernel(const T *__restrict_
       if (n0 + 4 * tn + j < N) atomicAdd(dbias + n0 + 4 * tn + j, bsum[j]);
 }
 
+// Weight gradients on the matrix pipe (float32): dW^T[k][n] += sum_r X[r][k] dY[r][n] is a
+// [K x R] x [R x N] product with a huge reduction length, so v_mfma_f32_32x32x2_f32 takes TWO
+// rows per instruction: lane (m, h) supplies X[2s+h][k0+m] and dY[2s+h][n0+m] -- both plain
+// coalesced dword loads, no transposition, no LDS.  A workgroup owns a block of rows; wave w
+// owns 32 output columns and keeps all K/32 accumulator tiles; partial sums leave with one
+// atomic per element and workgroup.  (The VALU kernel above spent 164 us per call on this.)
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <int KT, int AMODE>
+__global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restrict__ X, int ldx,
+                                                           const float *__restrict__ dY, int ldy, int64_t R,
+                                                           int K, int N, float *__restrict__ dWT, int ldw,
+                                                           float *__restrict__ dbias,
+                                                           const float *__restrict__ node, Graph g,
+                                                           int rows_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ntile = blockIdx.y * 4 + wave;
+  if (ntile * 32 >= N) return;  // (no barriers in this kernel)
+  const int ncol = ntile * 32 + l31;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  f32x16_t acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  constexpr int U = 4;  // row pairs in flight
+  for (int64_t rb = r0; rb < r1; rb += 2 * U) {
+    float a[U][KT], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = rb + 2 * u + h;
+      const bool ok = row < r1;
+      b[u] = ok ? dY[row * ldy + ncol] : 0.f;
+      if (AMODE == 0) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const int k = 32 * t + l31;
+          a[u][t] = (ok && k < K) ? X[row * ldx + k] : 0.f;
+        }
+      } else {
+        int64_t nb = 0, na = 0;
+        if (ok) {
+          const int64_t s = row / g.E;
+          const int e = (int)(row - s * g.E);
+          nb = (s * g.N + g.edge_b[e]) * ldx;
+          na = (s * g.N + g.edge_a[e]) * ldx;
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const int k = 32 * t + l31;
+          a[u][t] = (ok && k < K) ? node[nb + k] * node[na + k] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bsum += b[u];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (k < K) atomicAdd(dWT + (int64_t)k * ldw + ncol, acc[t][i]);
+    }
+  if (dbias) atomicAdd(dbias + ncol, bsum);  // both lane halves hold half of the rows
+}
+
+static bool launch_gemm_tn_mfma(const float *X, int ldx, const float *dY, int ldy, int64_t R, int K, int N,
+                                float *dWT, int ldw, float *dbias, int amode, const float *node,
+                                const Graph &g, hipStream_t st) {
+  static const bool off = getenv("RN_POTGNN_BWD_VALU_GEMM") && atoi(getenv("RN_POTGNN_BWD_VALU_GEMM")) != 0;
+  if (off || K > 128 || N % 32 != 0) return false;
+  // ~512 workgroups or >= 64 rows each: enough parallelism, few atomics per output element
+  int rows_per_block = (int)((R + 511) / 512);
+  rows_per_block = std::max(64, (rows_per_block + 7) / 8 * 8);
+  const dim3 grid((unsigned)((R + rows_per_block - 1) / rows_per_block), (unsigned)((N + 127) / 128));
+  const int kt = (K + 31) / 32;
+#define RN_TNM(KTV)                                                                                           \
+  do {                                                                                                        \
+    if (amode == 0) gemm_tn_mfma_kernel<KTV, 0><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw,     \
+                                                                      dbias, node, g, rows_per_block);        \
+    else gemm_tn_mfma_kernel<KTV, 1><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, node,   \
+                                                           g, rows_per_block);                                \
+  } while (0)
+  switch (kt) {
+    case 1: RN_TNM(1); break;
+    case 2: RN_TNM(2); break;
+    case 3: RN_TNM(3); break;
+    default: RN_TNM(4); break;
+  }
+#undef RN_TNM
+  return true;
+}
+
 template <typename T>
 void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
                     int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st) {
   if (R == 0) return;
+  if constexpr (sizeof(T) == 4) {
+    if (launch_gemm_tn_mfma(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g, st)) return;
+  }
   const int64_t tiles = (R + 127) / 128;
   dim3 grid((unsigned)(tiles < 64 ? tiles : 64), (unsigned)((N + 63) / 64));
 #define RN_TN(KM)                                                                                   \
