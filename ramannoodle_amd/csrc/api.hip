@@ -118,7 +118,7 @@ struct Precision {
   // forward tape + cotangent workspace of the reverse pass (Jacobian d alpha / d r)
   std::vector<DeviceBuf> tape_node, tape_edge, tape_agg;
   DeviceBuf bw[17];
-  DeviceBuf tape_z1, bn_stats, grad, seeds, mv;  // training: pre-BatchNorm activations, batch sums, gradient blob
+  DeviceBuf tape_z1, bn_stats, grad, seeds, mv, type_sums;  // training: pre-BatchNorm activations, batch sums, gradient blob
   bool tape_on = false;
 };
 
@@ -899,9 +899,12 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     }
     cur ^= 1;
   }
-  if (G)
+  if (G) {
+    P.type_sums.ensure((size_t)h->cfg.num_atom_types * d.Fn * sizeof(T));
     launch_node_embed_bwd<T>(b[DN0 + cur], S, g, d, h->cfg.num_atom_types, Wd + L.emb, Wd + L.W2, Wd + L.b2,
-                             Wd + L.W4, G + L.emb, G + L.W2, G + L.b2, G + L.W4, G + L.b4, st);
+                             Wd + L.W4, G + L.emb, G + L.W2, G + L.b2, G + L.W4, G + L.b4,
+                             P.type_sums.template as<T>(), st);
+  }
   if (rv.d_dpos)
     launch_geom_bwd<T>(b[DE0 + cur], b[DUNIT], unit4, P.lattice.template as<T>(), P.offsets,
                        (T)h->cfg.gauss_coefficient, C, B, g, d, rv.d_dpos, st);

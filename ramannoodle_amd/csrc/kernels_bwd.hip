@@ -27,11 +27,11 @@ __device__ __forceinline__ void atomic_add4(T *p, const Vec4<T> &v) {
 // every workgroup adding them straight to the same few hundred global addresses serialises in
 // the memory-side atomic unit (measured: 0.3-0.8 ms per launch at 8 k adders per address,
 // more than the rest of the kernel at training batch sizes).  Sum the G = 256/LG groups of
-// the workgroup in LDS first: one atomic per column and workgroup.  `scratch`: 1024 T.
-// Must be reached by all 256 threads.
-template <int LG, typename T>
+// the workgroup in LDS first: one atomic per column and workgroup.  `scratch`: 4 NT elements.
+// Must be reached by all NT threads of the workgroup.
+template <int LG, typename T, int NT = 256>
 __device__ __forceinline__ void wg_sum_atomic_add(T *scratch, const Vec4<T> &v, T *dst) {
-  constexpr int W = 4 * LG, G = 256 / LG;
+  constexpr int W = 4 * LG, G = NT / LG;
   const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
   store4(scratch + grp * W + 4 * q, v);
   __syncthreads();
@@ -718,14 +718,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
 // owns d (sums over r: dP'), once by the lane group that owns r (sums over d: dQ') -- so both
 // sums stay in registers and leave with plain stores.  Needs the centred P' rows and the
 // per-destination LayerNorm cotangents of the tile in LDS (one workgroup per CU at Fe = 64).
-template <int FP, typename T>
-__global__ __launch_bounds__(256) void edge_bwd_tile2_kernel(
+template <int FP, typename T, int NT>
+__global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
     const T *__restrict__ edge_next, const T *__restrict__ agg_tape, const T *__restrict__ dedge_next,
     T *__restrict__ dedge_prev, T *__restrict__ dpq, T *__restrict__ dnp3, T *__restrict__ dc2pre,
     int C, int B, Graph g, Dims d, PassW<T> w, PassW<T> gw, int want_param_grads) {
   constexpr int LG = FP / 4;
-  constexpr int G = 256 / LG;
+  constexpr int G = NT / LG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
   size_t off = 0;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void edge_bwd_tile2_kernel(
   };
   T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));   // centred Q' rows
   T *prows = reinterpret_cast<T *>(carve((size_t)maxD * 2 * FP * sizeof(T)));   // centred P' rows
-  if (off < (size_t)1024 * sizeof(T)) off = (size_t)1024 * sizeof(T);            // scratch of wg_sum_atomic_add
+  if (off < (size_t)4 * NT * sizeof(T)) off = (size_t)4 * NT * sizeof(T);            // scratch of wg_sum_atomic_add
   T *dagg_s = reinterpret_cast<T *>(carve((size_t)maxD * FP * sizeof(T)));       // d(sum over triplets), per destination
   T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));
   T *sp_s = reinterpret_cast<T *>(carve((size_t)maxD * sizeof(T)));
@@ -753,11 +753,11 @@ __global__ __launch_bounds__(256) void edge_bwd_tile2_kernel(
   const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
   const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
+  for (int r = threadIdx.x; r < rows; r += NT) {
     qb[r] = g.edge_b[eo0 + r];
     qn[r] = g.edge_a[eo0 + r] - j0;
   }
-  for (int i = threadIdx.x; i < dcount; i += 256) {
+  for (int i = threadIdx.x; i < dcount; i += NT) {
     const int dst = g.in_edge[di0 + i];
     const int ad = g.edge_a[dst], bd = g.edge_b[dst];
     const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void edge_bwd_tile2_kernel(
     const int s = c / B;
     const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
     const int64_t cerow0 = (int64_t)c * g.E, cnrow0 = (int64_t)c * g.N;
-    for (int i = threadIdx.x; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+    for (int i = threadIdx.x; i < (j1 - j0) * (2 * FP / 4); i += NT) {
       const int n = i / (2 * FP / 4), cc = (i % (2 * FP / 4)) * 4;
       store4(nj + (size_t)n * 2 * FP + cc, load4<T>(np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + cc));
       store4(dnj + (size_t)n * 2 * FP + cc, Vec4<T>{{0, 0, 0, 0}});
@@ -995,32 +995,32 @@ __global__ __launch_bounds__(256) void edge_bwd_tile2_kernel(
       store4(o + FP, dqc);
     }
     __syncthreads();  // dnj complete
-    for (int ii = threadIdx.x; ii < (j1 - j0) * (2 * FP / 4); ii += 256) {
+    for (int ii = threadIdx.x; ii < (j1 - j0) * (2 * FP / 4); ii += NT) {
       const int n = ii / (2 * FP / 4), cc = (ii % (2 * FP / 4)) * 4;
       store4(dnp3 + (cnrow0 + j0 + n) * (6 * FP) + 2 * FP + cc, load4<T>(dnj + (size_t)n * 2 * FP + cc));
     }
     __syncthreads();
   }
   if (want_param_grads) {  // (uniform) qrows is free after the last frame: reduction scratch
-    wg_sum_atomic_add<LG>(qrows, G31f, const_cast<T *>(gw.c3_norm_1.g));
-    wg_sum_atomic_add<LG>(qrows, B31f, const_cast<T *>(gw.c3_norm_1.b));
-    wg_sum_atomic_add<LG>(qrows, G31c, const_cast<T *>(gw.c3_norm_1.g) + FP);
-    wg_sum_atomic_add<LG>(qrows, B31c, const_cast<T *>(gw.c3_norm_1.b) + FP);
-    wg_sum_atomic_add<LG>(qrows, G32, const_cast<T *>(gw.c3_norm_2.g));
-    wg_sum_atomic_add<LG>(qrows, B32, const_cast<T *>(gw.c3_norm_2.b));
-    wg_sum_atomic_add<LG>(qrows, G21f, const_cast<T *>(gw.c2_norm_1.g));
-    wg_sum_atomic_add<LG>(qrows, B21f, const_cast<T *>(gw.c2_norm_1.b));
-    wg_sum_atomic_add<LG>(qrows, G21c, const_cast<T *>(gw.c2_norm_1.g) + FP);
-    wg_sum_atomic_add<LG>(qrows, B21c, const_cast<T *>(gw.c2_norm_1.b) + FP);
-    wg_sum_atomic_add<LG>(qrows, G22, const_cast<T *>(gw.c2_norm_2.g));
-    wg_sum_atomic_add<LG>(qrows, B22, const_cast<T *>(gw.c2_norm_2.b));
+    wg_sum_atomic_add<LG, T, NT>(qrows, G31f, const_cast<T *>(gw.c3_norm_1.g));
+    wg_sum_atomic_add<LG, T, NT>(qrows, B31f, const_cast<T *>(gw.c3_norm_1.b));
+    wg_sum_atomic_add<LG, T, NT>(qrows, G31c, const_cast<T *>(gw.c3_norm_1.g) + FP);
+    wg_sum_atomic_add<LG, T, NT>(qrows, B31c, const_cast<T *>(gw.c3_norm_1.b) + FP);
+    wg_sum_atomic_add<LG, T, NT>(qrows, G32, const_cast<T *>(gw.c3_norm_2.g));
+    wg_sum_atomic_add<LG, T, NT>(qrows, B32, const_cast<T *>(gw.c3_norm_2.b));
+    wg_sum_atomic_add<LG, T, NT>(qrows, G21f, const_cast<T *>(gw.c2_norm_1.g));
+    wg_sum_atomic_add<LG, T, NT>(qrows, B21f, const_cast<T *>(gw.c2_norm_1.b));
+    wg_sum_atomic_add<LG, T, NT>(qrows, G21c, const_cast<T *>(gw.c2_norm_1.g) + FP);
+    wg_sum_atomic_add<LG, T, NT>(qrows, B21c, const_cast<T *>(gw.c2_norm_1.b) + FP);
+    wg_sum_atomic_add<LG, T, NT>(qrows, G22, const_cast<T *>(gw.c2_norm_2.g));
+    wg_sum_atomic_add<LG, T, NT>(qrows, B22, const_cast<T *>(gw.c2_norm_2.b));
   }
 }
 
 static size_t edge_bwd_tile2_lds(const Graph &g, int FP, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   const size_t row_arrays = std::max(up((size_t)g.max_tile_out_rows * 2 * FP * elem) +
-                                         up((size_t)g.max_tile_in_rows * 2 * FP * elem), (size_t)1024 * elem);
+                                         up((size_t)g.max_tile_in_rows * 2 * FP * elem), (size_t)2048 * elem);
   return row_arrays + up((size_t)g.max_tile_in_rows * FP * elem) + up((size_t)g.max_tile_out_rows * elem) +
          up((size_t)g.max_tile_in_rows * elem) + 2 * up((size_t)g.max_tile_nodes * 2 * FP * elem) +
          2 * up((size_t)g.max_tile_out_rows * 4) + up((size_t)g.max_tile_in_rows * 6 * 4);
@@ -1035,41 +1035,58 @@ static size_t edge_bwd_tile_lds(const Graph &g, int FP, size_t elem) {
          up((size_t)g.max_tile_in_rows * 6 * 4);
 }
 
-// dnp3[c, b_e][Wi block] += dQ'_e  (the node part of the source-row projection)
+// dnp3[c, n][Wi block] = sum over the edges e entering atom n of dQ'_e  (the node part of the
+// source-row projection).  Gather over the in-edge list, one lane group per (instance, atom):
+// a single writer per row, no atomics (the scatter form spent 150 us per call on them).
 template <int LG, typename T>
-__global__ void q_scatter_kernel(const T *__restrict__ dpq, T *__restrict__ dnp3, int C, Graph g) {
+__global__ void q_gather_kernel(const T *__restrict__ dpq, T *__restrict__ dnp3, int C, Graph g) {
   constexpr int FP = LG * 4;
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
   const int q = threadIdx.x % LG;
-  if (gid >= (int64_t)C * g.E) return;
-  const int c = (int)(gid / g.E), e = (int)(gid % g.E);
-  const T *src = dpq + gid * (4 * FP) + 2 * FP + 4 * q;
-  T *dst = dnp3 + ((int64_t)c * g.N + g.edge_b[e]) * (6 * FP) + 4 * q;
-  atomic_add4(dst, load4<T>(src));
-  atomic_add4(dst + FP, load4<T>(src + FP));
+  if (gid >= (int64_t)C * g.N) return;
+  const int c = (int)(gid / g.N), n = (int)(gid % g.N);
+  Vec4<T> sf{{0, 0, 0, 0}}, sc{{0, 0, 0, 0}};
+  for (int i = g.in_ptr[n]; i < g.in_ptr[n + 1]; ++i) {
+    const T *src = dpq + ((int64_t)c * g.E + g.in_edge[i]) * (4 * FP) + 2 * FP + 4 * q;
+    const Vec4<T> f = load4<T>(src), cc = load4<T>(src + FP);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sf.v[k] += f.v[k];
+      sc.v[k] += cc.v[k];
+    }
+  }
+  T *dst = dnp3 + gid * (6 * FP) + 4 * q;
+  store4(dst, sf);
+  store4(dst + FP, sc);
 }
 
-// d(node[b]*node[a]) -> dnode[b], dnode[a]   (operand of c2_linear)
+// d(node[b]*node[a]) -> dnode   (operand of c2_linear): atom n collects dprod_e * node[a_e] from
+// the edges entering it and dprod_e * node[b_e] from the edges leaving it (contiguous range);
+// one lane group per (instance, atom), single writer, no atomics.
 template <int LG, typename T>
 __global__ void prod_bwd_kernel(const T *__restrict__ dprod, const T *__restrict__ node,
                                 T *__restrict__ dnode, int C, int B, Graph g) {
   constexpr int FP = LG * 4;
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
   const int q = threadIdx.x % LG;
-  if (gid >= (int64_t)C * g.E) return;
-  const int c = (int)(gid / g.E), e = (int)(gid % g.E);
-  const int64_t nrow0 = (int64_t)(c / B) * g.N, cnrow0 = (int64_t)c * g.N;
-  const int a = g.edge_a[e], b = g.edge_b[e];
-  const Vec4<T> dp = load4<T>(dprod + gid * FP + 4 * q);
-  const Vec4<T> nb = load4<T>(node + (nrow0 + b) * FP + 4 * q), na = load4<T>(node + (nrow0 + a) * FP + 4 * q);
-  Vec4<T> tb, ta;
+  if (gid >= (int64_t)C * g.N) return;
+  const int c = (int)(gid / g.N), n = (int)(gid % g.N);
+  const int64_t nrow0 = (int64_t)(c / B) * g.N, cerow0 = (int64_t)c * g.E;
+  Vec4<T> acc = load4<T>(dnode + gid * FP + 4 * q);
+  for (int i = g.in_ptr[n]; i < g.in_ptr[n + 1]; ++i) {
+    const int e = g.in_edge[i];
+    const Vec4<T> dp = load4<T>(dprod + (cerow0 + e) * FP + 4 * q);
+    const Vec4<T> na = load4<T>(node + (nrow0 + g.edge_a[e]) * FP + 4 * q);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    tb.v[k] = dp.v[k] * na.v[k];
-    ta.v[k] = dp.v[k] * nb.v[k];
+    for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * na.v[k];
   }
-  atomic_add4(dnode + (cnrow0 + b) * FP + 4 * q, tb);
-  atomic_add4(dnode + (cnrow0 + a) * FP + 4 * q, ta);
+  for (int e = g.out_ptr[n]; e < g.out_ptr[n + 1]; ++e) {
+    const Vec4<T> dp = load4<T>(dprod + (cerow0 + e) * FP + 4 * q);
+    const Vec4<T> nb = load4<T>(node + (nrow0 + g.edge_b[e]) * FP + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * nb.v[k];
+  }
+  store4(dnode + gid * FP + 4 * q, acc);
 }
 
 // =========================================================================== node block
@@ -1243,21 +1260,27 @@ static bool launch_edge_bwd_tile(const T *pq, const T *np3, const T *c2pre, cons
   const bool two_pass = !no_two_pass && lds2 <= 160 * 1024 - 512;
   const size_t lds = two_pass ? lds2 : edge_bwd_tile_lds(g, FP, sizeof(T));
   if (lds > 160 * 1024 - 512) return false;
-  auto kern = two_pass ? &edge_bwd_tile2_kernel<FP, T> : &edge_bwd_tile_kernel<FP, T>;
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // the two-pass kernel holds one tile per CU: 512 threads (two waves per SIMD) share it
+  constexpr int NT2 = 512;
+  const void *kern = two_pass ? reinterpret_cast<const void *>(&edge_bwd_tile2_kernel<FP, T, NT2>)
+                              : reinterpret_cast<const void *>(&edge_bwd_tile_kernel<FP, T>);
+  const int threads = two_pass ? NT2 : 256;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int per_cu = 0, dev = 0, cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1)
     per_cu = 1;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
     cus = prop.multiProcessorCount;
   int ncg = per_cu * cus / g.num_tiles;
   ncg = ncg < 1 ? 1 : (ncg > C ? C : ncg);
-  kern<<<(unsigned)ncg * (unsigned)g.num_tiles, 256, lds, st>>>(pq, np3, c2pre, edge_next, agg, dedge_next,
-                                                                dedge_prev, dpq, dnp3, dc2pre, C, B, g, d,
-                                                                w, gwv, want);
+  const unsigned grid = (unsigned)ncg * (unsigned)g.num_tiles;
+  if (two_pass)
+    edge_bwd_tile2_kernel<FP, T, NT2><<<grid, NT2, lds, st>>>(pq, np3, c2pre, edge_next, agg, dedge_next,
+                                                              dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want);
+  else
+    edge_bwd_tile_kernel<FP, T><<<grid, 256, lds, st>>>(pq, np3, c2pre, edge_next, agg, dedge_next, dedge_prev,
+                                                        dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want);
   return true;
 }
 
@@ -1286,7 +1309,7 @@ void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_ne
     edge_bwd_simple_kernel<LGV, T><<<blocks, 256, 0, st>>>(pq, np3, c2pre, edge_next, dedge_next,    \
                                                            dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, \
                                                            gwv, want);                               \
-  q_scatter_kernel<LGV, T><<<blocks, 256, 0, st>>>(dpq, dnp3, C, g)
+  q_gather_kernel<LGV, T><<<(unsigned)(((int64_t)C * g.N * lg + 255) / 256), 256, 0, st>>>(dpq, dnp3, C, g)
   RN_LG_SWITCH(d.FeP, CALL)
 #undef CALL
 }
@@ -1303,7 +1326,7 @@ template <typename T>
 void launch_prod_bwd(const T *dprod, const T *node, T *dnode, int C, int B, const Graph &g, Dims d,
                      hipStream_t st) {
   const int lg = d.FnP / 4;
-  const int64_t threads = (int64_t)C * g.E * lg;
+  const int64_t threads = (int64_t)C * g.N * lg;
   if (threads == 0) return;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define CALL(LGV) prod_bwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(dprod, node, dnode, C, B, g)
@@ -1730,8 +1753,29 @@ RN_BN_INST(double)
 // ---- node embedding MLP (Embedding -> ssp -> Linear -> ssp -> Linear, _gnn.py:508-514):
 // gradient of the K x Fn table rows w.r.t. emb, W2, b2, W4, b4.  dnode0 [S*N, FnP] is first
 // summed per atom type.  One workgroup; K and Fn are tiny.
+// sums[k][o] += sum over the rows r (atoms of all frames) of type k of dnode0[r][o]: a block
+// walks `rows_per_block` rows, thread o owns column o (private per-type partial sums in LDS),
+// then one atomic per (type, column) and block.
 template <typename T>
-__global__ void node_embed_bwd_kernel(const T *__restrict__ dnode0, int S, Graph g, Dims d, int K,
+__global__ void type_col_sums_kernel(const T *__restrict__ dnode0, int64_t R, int N, int FnP, int Fn, int K,
+                                     const int *__restrict__ atom_type, T *__restrict__ sums,
+                                     int rows_per_block) {
+  extern __shared__ unsigned char smem_raw[];
+  T *acc = reinterpret_cast<T *>(smem_raw);  // [K][Fn]
+  const int o = threadIdx.x;
+  if (o >= Fn) return;
+  for (int k = 0; k < K; ++k) acc[k * Fn + o] = 0;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  for (int64_t r = r0; r < r1; ++r) {
+    const int k = atom_type[r % N];
+    if (k >= 0 && k < K) acc[k * Fn + o] += dnode0[r * FnP + o];
+  }
+  for (int k = 0; k < K; ++k) atomicAdd(sums + k * Fn + o, acc[k * Fn + o]);
+}
+
+template <typename T>
+__global__ void node_embed_bwd_kernel(const T *__restrict__ type_sums, int S, Graph g, Dims d, int K,
                                       const T *__restrict__ emb, const T *__restrict__ W2,
                                       const T *__restrict__ b2, const T *__restrict__ W4,
                                       T *__restrict__ demb, T *__restrict__ dW2, T *__restrict__ db2,
@@ -1743,11 +1787,7 @@ __global__ void node_embed_bwd_kernel(const T *__restrict__ dnode0, int S, Graph
   T *z2 = a1 + K * Fn;                      // pre-activation of the first Linear
   T *dz2 = z2 + K * Fn;
   for (int i = threadIdx.x; i < K * Fn; i += blockDim.x) {
-    const int k = i / Fn, o = i % Fn;
-    T s = 0;
-    for (int64_t r = 0; r < (int64_t)S * g.N; ++r)
-      if (g.atom_type[r % g.N] == k) s += dnode0[r * d.FnP + o];
-    dt[i] = s;
+    dt[i] = type_sums[i];  // d table: cotangent of the initial embedding summed per atom type
     a1[i] = ssp(emb[i]);
   }
   __syncthreads();
@@ -1798,17 +1838,23 @@ __global__ void node_embed_bwd_kernel(const T *__restrict__ dnode0, int S, Graph
 template <typename T>
 void launch_node_embed_bwd(const T *dnode0, int S, const Graph &g, Dims d, int K, const T *emb,
                            const T *W2, const T *b2, const T *W4, T *demb, T *dW2, T *db2, T *dW4,
-                           T *db4, hipStream_t st) {
+                           T *db4, T *sums /* scratch [K * Fn] */, hipStream_t st) {
   const size_t lds = (size_t)4 * K * d.Fn * sizeof(T);
-  node_embed_bwd_kernel<T><<<1, 256, lds, st>>>(dnode0, S, g, d, K, emb, W2, b2, W4, demb, dW2, db2, dW4,
+  const size_t need = (size_t)K * d.Fn * sizeof(T);
+  (void)hipMemsetAsync(sums, 0, need, st);
+  const int64_t R = (int64_t)S * g.N;
+  const int rpb = 64, threads = (d.Fn + 63) / 64 * 64;
+  type_col_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), threads, need, st>>>(
+      dnode0, R, g.N, d.FnP, d.Fn, K, g.atom_type, sums, rpb);
+  node_embed_bwd_kernel<T><<<1, 256, lds, st>>>(sums, S, g, d, K, emb, W2, b2, W4, demb, dW2, db2, dW4,
                                                 db4);
 }
 template void launch_node_embed_bwd<float>(const float *, int, const Graph &, Dims, int, const float *,
                                            const float *, const float *, const float *, float *,
-                                           float *, float *, float *, float *, hipStream_t);
+                                           float *, float *, float *, float *, float *, hipStream_t);
 template void launch_node_embed_bwd<double>(const double *, int, const Graph &, Dims, int,
                                             const double *, const double *, const double *,
                                             const double *, double *, double *, double *, double *,
-                                            double *, hipStream_t);
+                                            double *, double *, hipStream_t);
 
 }  // namespace rn
