@@ -1501,6 +1501,7 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
+  const int64_t s0 = (AMODE == 1 && g.E > 0) ? r0 / g.E : 0, e0 = (AMODE == 1) ? r0 - s0 * g.E : 0;
   constexpr int U = 4;  // row pairs in flight
   for (int64_t rb = r0; rb < r1; rb += 2 * U) {
     float a[U][KT], b[U];
@@ -1517,9 +1518,14 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
         }
       } else {
         int64_t nb = 0, na = 0;
-        if (ok) {
-          const int64_t s = row / g.E;
-          const int e = (int)(row - s * g.E);
+        if (ok) {  // (frame, edge) of the row without a 64-bit division per row
+          int64_t s = s0;
+          int64_t e64 = e0 + (row - r0);
+          while (e64 >= g.E) {
+            e64 -= g.E;
+            ++s;
+          }
+          const int e = (int)e64;
           nb = (s * g.N + g.edge_b[e]) * ldx;
           na = (s * g.N + g.edge_a[e]) * ldx;
         }
