@@ -139,6 +139,7 @@ struct rn_potgnn {
   // graph
   std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge;
   bool use_fused = false;
+  bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   Graph g{};
   DeviceBuf g_ints;
   double lattice[9], mean[9], stdv[9];
@@ -612,14 +613,24 @@ struct ChunkRun {
       launch_rowgemm<T>(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, nullptr, w.c1_bias, false,
                         0, nullptr, g, st());
     }
-    {
-      Timer t(h, st(), K_PROJ_EDGE_C1);
-      launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0,
-                        nullptr, g, st());
+    bool node_fused = false;
+    if constexpr (sizeof(T) == 4) {
+      if (fused() && h->use_node_fused) {  // c1 edge projection + aggregation in one launch
+        Timer t(h, st(), K_NODE_AGG);
+        launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, st());
+        node_fused = true;
+      }
     }
-    {
-      Timer t(h, st(), K_NODE_AGG);
-      launch_node_agg<T>(npc1, bufA, node[cur], node[nxt], S, g, d, w, st());
+    if (!node_fused) {
+      {
+        Timer t(h, st(), K_PROJ_EDGE_C1);
+        launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0,
+                          nullptr, g, st());
+      }
+      {
+        Timer t(h, st(), K_NODE_AGG);
+        launch_node_agg<T>(npc1, bufA, node[cur], node[nxt], S, g, d, w, st());
+      }
     }
     {  // EdgeBlock uses the UPDATED node embedding (_gnn.py:649-650)
       Timer t(h, st(), K_PROJ_NODE);
@@ -1399,6 +1410,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // The fused EdgeBlock (kernels_fused.hip) is the default where it applies (float32,
     // Fn and Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
+    const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
+    hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
     ensure_precision<float>(hp);
   });
   if (rc != RN_OK) return rc;

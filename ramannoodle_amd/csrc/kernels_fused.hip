@@ -474,6 +474,192 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   }
 }
 
+// ============================================================================ NodeBlock
+// _NodeBlock.forward (_gnn.py:122-151) in one launch: for the edges e entering the tile's
+// atoms,  c1 = W_e edge_e (MFMA, operand rows by LDS-DMA one round ahead) + (W_n node[b_e] + bias)
+// (the small per-atom projection npc1), LayerNorm(2Fn) -> sigmoid*tanh, summed per atom in
+// in-edge order, LayerNorm(Fn), residual tanh.  Replaces the c1 edge projection (0.59 MB in,
+// 1.18 MB out per structure and pass) plus node_agg_kernel (which read it back).
+struct NodeFusedArgs {
+  const float *edge;     // [S*E, FP]
+  const float *node_in;  // [S*N, FP]
+  const float *npc1;     // [S*N, 2FP] = W_n node + bias
+  float *node_out;       // [S*N, FP]
+  int S;
+  Graph g;
+  Dims d;
+  PassW<float> w;
+};
+
+namespace {
+constexpr int LDG = FP + 4;  // row stride of the gated rows in LDS
+struct NodeFusedLds {
+  size_t bufP, atile, gated, nj, lnp, ints, total;
+};
+__host__ __device__ inline NodeFusedLds node_fused_lds(int maxD, int maxN) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  NodeFusedLds L;
+  size_t off = 0;
+  L.bufP = off; off += up((size_t)NG * LDQ * 4);
+  L.atile = off; off += (size_t)NG * FP * 4;
+  L.gated = off; off += up((size_t)maxD * LDG * 4);
+  L.nj = off; off += up((size_t)maxN * 2 * FP * 4);
+  L.lnp = off; off += (size_t)6 * FP * 4;
+  L.ints = off; off += up((size_t)2 * maxD * 4);
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+template <bool PAD>
+__global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Graph &g = a.g;
+  const NodeFusedLds L = node_fused_lds(g.max_tile_in_rows, g.max_tile_nodes);
+  float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);    // [16][LDQ] W_e edge_e of a round
+  float *atile = reinterpret_cast<float *>(smem_raw + L.atile);  // [16][64] swizzled operand rows
+  float *gated = reinterpret_cast<float *>(smem_raw + L.gated);  // [maxD][LDG] gate outputs of the tile
+  float *nj = reinterpret_cast<float *>(smem_raw + L.nj);        // [maxN][2FP] W_n node + bias
+  float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
+  float *s_c1g = lnp, *s_c1b = lnp + 2 * FP, *s_fg = lnp + 4 * FP, *s_fb = lnp + 5 * FP;
+  int *d_edge = reinterpret_cast<int *>(smem_raw + L.ints), *d_bl = d_edge + g.max_tile_in_rows;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int colbase = wave * 32;
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.num_tiles;
+  const int sg = logical / g.num_tiles, nsg = gridDim.x / g.num_tiles;
+  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  const int nrounds = (dcount + NG - 1) / NG;
+
+  for (int c = tid; c < 2 * FP; c += 256) {
+    s_c1g[c] = a.w.c1_norm.g[c];
+    s_c1b[c] = a.w.c1_norm.b[c];
+    if (c < FP) {
+      s_fg[c] = a.w.final_norm.g[c];
+      s_fb[c] = a.w.final_norm.b[c];
+    }
+  }
+  for (int i = tid; i < dcount; i += 256) {
+    const int e = g.in_edge[di0 + i];
+    d_edge[i] = e;
+    d_bl[i] = g.edge_b[e] - j0;
+  }
+  float bW[2][KS];  // B fragments of the edge part of c1_linear, resident
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) bW[t][k] = a.w.c1_WeT[(size_t)(quad * KS + k) * (2 * FP) + colbase + 16 * t + l15];
+
+  const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
+  const int nvalid = min(max(a.d.Fn - c0, 0), 4);
+  const float inv2n = 1.0f / (float)(2 * a.d.Fn), invn = 1.0f / (float)a.d.Fn;
+  __syncthreads();
+
+  auto prefetch_round = [&](int s, int r) {
+    const int row = 4 * wave + quad;
+    const int i = min(r * NG + row, dcount - 1);
+    const int piece = (l15 ^ row) & 15;
+    dma16(a.edge + ((int64_t)s * g.E + d_edge[i]) * FP + 4 * piece, atile + wave * 256);
+  };
+  if (sg < a.S && dcount > 0) prefetch_round(sg, 0);
+
+  for (int s = sg; s < a.S; s += nsg) {
+    const int64_t nrow0 = (int64_t)s * g.N;
+    for (int i = tid; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+      const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
+      store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.npc1 + (nrow0 + j0 + n) * (2 * FP) + c));
+    }
+    __syncthreads();  // the DMA'd operand rows of round 0 (every wave's share) have landed
+    for (int r = 0; r < nrounds; ++r) {
+      {
+        float af[KS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4 *>(atile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
+          af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW[t][k], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bufP[(4 * quad + rr) * LDQ + colbase + 16 * t + l15] = acc[t][rr];
+      }
+      __syncthreads();  // S1: bufP complete, operand tile free
+      if (r + 1 < nrounds) prefetch_round(s, r + 1);
+      else if (s + nsg < a.S) prefetch_round(s + nsg, 0);
+      const int i = r * NG + grp;
+      if (i < dcount) {
+        const float *njr = nj + (size_t)d_bl[i] * 2 * FP + c0;
+        Vec4<float> xf = load4<float>(bufP + grp * LDQ + c0), xc = load4<float>(bufP + grp * LDQ + FP + c0);
+        const Vec4<float> af = load4<float>(njr), ac = load4<float>(njr + FP);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xf.v[k] += af.v[k];
+          xc.v[k] += ac.v[k];
+        }
+        const LnParams<float> pf{load4<float>(s_c1g + c0), load4<float>(s_c1b + c0)};
+        const LnParams<float> pc{load4<float>(s_c1g + FP + c0), load4<float>(s_c1b + FP + c0)};
+        store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
+      }
+      __syncthreads();  // S2: bufP may be rewritten, next round's operand rows landed; after the last round: gated complete
+    }
+    // ---- per atom: sum over its in-edges (ascending, as the reference's scatter), LayerNorm, residual
+    for (int n = grp; n < j1 - j0; n += NG) {
+      const int i0 = g.in_ptr[j0 + n] - di0, i1 = g.in_ptr[j0 + n + 1] - di0;
+      Vec4<float> acc{{0.f, 0.f, 0.f, 0.f}};
+      for (int i = i0; i < i1; ++i) {
+        const Vec4<float> v = load4<float>(gated + (size_t)i * LDG + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc.v[k] += v.v[k];
+      }
+      const LnParams<float> pn{load4<float>(s_fg + c0), load4<float>(s_fb + c0)};
+      const Vec4<float> ln = ln_row<LG, PAD>(acc, pn, invn, nvalid);
+      const Vec4<float> old = load4<float>(a.node_in + (nrow0 + j0 + n) * FP + c0);
+      Vec4<float> out;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + ln.v[k]);
+      store4(a.node_out + (nrow0 + j0 + n) * FP + c0, out);
+    }
+  }
+}
+
+size_t node_fused_lds_bytes(const Graph &g) { return node_fused_lds(g.max_tile_in_rows, g.max_tile_nodes).total; }
+
+void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
+                       const Graph &g, Dims d, const PassW<float> &w, hipStream_t st) {
+  if (S == 0 || g.N == 0) return;
+  NodeFusedArgs a{edge, node_in, npc1, node_out, S, g, d, w};
+  const size_t lds = node_fused_lds_bytes(g);
+  const bool pad = d.Fn != d.FnP;
+  auto kern = pad ? &node_block_fused_kernel<true> : &node_block_fused_kernel<false>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, 4);
+  int nsg = per_cu * cus / g.num_tiles;
+  nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)g.num_tiles, 256, lds, st>>>(a);
+}
+
 size_t edge_fused_lds_bytes(const Graph &g) {
   return fused_lds(g.max_tile_out_rows, g.max_tile_in_rows, g.max_tile_nodes).total;
 }
