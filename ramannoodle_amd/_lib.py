@@ -37,7 +37,7 @@ class Config(C.Structure):
     ]
 
 
-# symbol -> (restype, argtypes); must list every function declared in rn_potgnn.h
+# symbol -> (restype, argtypes); must list every function declared in include/*.h
 _P = C.c_void_p
 SIGNATURES = {
     "rn_potgnn_radius_graph": (C.c_int, [_P, _P, C.c_int32, C.c_double, C.c_int, _P]),
@@ -66,6 +66,13 @@ SIGNATURES = {
                                          C.POINTER(C.c_int64), C.c_int]),
     "rn_potgnn_last_error": (C.c_char_p, [_P]),
     "rn_potgnn_version": (C.c_char_p, []),
+    # include/rn_ingest.h (host-only trajectory reader)
+    "rn_xdatcar_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "rn_xdatcar_close": (None, [_P]),
+    "rn_xdatcar_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32)]),
+    "rn_xdatcar_species": (C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_int32)]),
+    "rn_xdatcar_read": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int]),
+    "rn_xdatcar_last_error": (C.c_char_p, [_P]),
 }
 
 _lib = None

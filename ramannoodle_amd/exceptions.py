@@ -14,6 +14,11 @@ class UserError(Exception):
     """The user has done something they shouldn't (``ramannoodle/exceptions.py:33``)."""
 
 
+class InvalidFileException(Exception):
+    """File cannot be read, likely due to an invalid or unexpected format
+    (``ramannoodle/exceptions.py:12``)."""
+
+
 class DeviceError(RuntimeError):
     """The HIP library is missing or a device call failed."""
 
