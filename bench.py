@@ -208,11 +208,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # (test hook: RN_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, so that the N > 1
+    #  code path can be exercised on a 1-GPU box; RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("RN_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     cells = tuple(int(c) for c in args.cells.split(","))
     wl = make_workload(cells, args.frames, args.hparams, seed=22 + rank, t0=rank * args.frames)

@@ -409,3 +409,29 @@ def test_device_radius_graph_bit_exact(golden):
     edges = G.radius_graph_pbc_device(g["lattice"], g["positions"], cutoff)
     np.testing.assert_array_equal(edges, g["ref_edge_indexes"][1:])
     np.testing.assert_array_equal(edges, G.radius_graph_pbc(g["lattice"], g["positions"], cutoff))
+
+
+def test_bench_two_ranks_contract(tmp_path):
+    """The N > 1 launch the driver uses (torch.distributed.run, one rank per GPU) on this 1-GPU
+    box: both ranks share cuda:0 over gloo (RN_BENCH_SHARE_GPU).  Rank 0 prints exactly one JSON
+    line with the whole-job rate; the all-gathered result is exercised by the step itself."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RN_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "96", "--no-cpu"]
+    done = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout
+    result = json.loads(lines[0])
+    assert result["n_gpus"] == 2 and result["steps"] == 2 and result["scaling"] == "weak"
+    assert result["value"] == pytest.approx(2 * 96 * 2 / (result["ms_per_step"] * 2e-3), rel=1e-6)
+    assert result["roofline"]["launches"] > 0 and result["unit"] == "structures/s"
