@@ -140,6 +140,7 @@ struct rn_potgnn {
   std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge;
   bool use_fused = false;
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
+  bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   Graph g{};
   DeviceBuf g_ints;
   double lattice[9], mean[9], stdv[9];
@@ -676,11 +677,20 @@ struct ChunkRun {
     {
       Timer t(h, st(), K_READOUT_MLP);
       const int HP = std::max(d.FeP, 32);
-      launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
-                        nullptr, g, st());
-      launch_rowgemm<T>(bufA, ME, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st());
-      launch_rowgemm<T>(bufB, ME, HP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g,
-                        st());
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (fused() && h->use_readout_fused) {  // the three layers in one launch
+          launch_readout_fused(edge[cur], ME, P.ro, bufA, st());
+          done = true;
+        }
+      }
+      if (!done) {
+        launch_rowgemm<T>(edge[cur], ME, d.FeP, P.ro.W0T, HP, bufA, P.ro.scale0, P.ro.shift0, true, 0,
+                          nullptr, g, st());
+        launch_rowgemm<T>(bufA, ME, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st());
+        launch_rowgemm<T>(bufB, ME, HP, P.ro.W5T, 32, bufA, nullptr, P.ro.b5, false, 0, nullptr, g,
+                          st());
+      }
     }
     {
       Timer t(h, st(), K_READOUT_REDUCE);
@@ -1412,6 +1422,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
     const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
     hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
+    const bool want_ro = getenv("RN_POTGNN_READOUT_FUSED") ? atoi(getenv("RN_POTGNN_READOUT_FUSED")) != 0 : true;
+    hp->use_readout_fused = hp->use_fused && want_ro;
     ensure_precision<float>(hp);
   });
   if (rc != RN_OK) return rc;

@@ -660,6 +660,126 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
   kern<<<(unsigned)nsg * (unsigned)g.num_tiles, 256, lds, st>>>(a);
 }
 
+// ============================================================================ readout MLP
+// _to_polarizability_embedding (_gnn.py:532-539) in one launch: Linear -> BatchNorm(eval, folded)
+// -> ssp -> Linear -> ssp -> Linear(12) per edge row.  The three weight matrices sit in LDS
+// transposed; every wave walks its own 16-row tiles: A fragments of the first product straight
+// from HBM, the hidden rows pass from the C layout of one product to the A layout of the next
+// through a wave-private LDS slab (a wave's LDS operations complete in order: no barrier).
+// Replaces three projection launches that wrote and re-read two [S*E, 64] intermediates.
+struct ReadoutFusedArgs {
+  const float *edge;  // [M, FP]
+  float *pol;         // [M, 32]: columns 0..15 written (12 real)
+  int64_t M;
+  ReadoutW<float> w;
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs a, int tiles_per_wave) {
+  constexpr int LDW = FP + 4;
+  __shared__ __attribute__((aligned(16))) float w0t[FP * LDW], w3t[FP * LDW], w5t[16 * LDW];
+  __shared__ __attribute__((aligned(16))) float slab_all[4 * 16 * LDW];
+  __shared__ float s_scale0[FP], s_shift0[FP], s_b3[FP], s_b5[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  for (int i = tid; i < FP * FP; i += 256) {
+    const int k = i / FP, n = i % FP;  // W?T is [K][N] row-major
+    w0t[n * LDW + k] = a.w.W0T[i];
+    w3t[n * LDW + k] = a.w.W3T[i];
+  }
+  for (int i = tid; i < FP * 16; i += 256) {
+    const int k = i / 16, n = i % 16;
+    w5t[n * LDW + k] = a.w.W5T[k * 32 + n];
+  }
+  if (tid < FP) {
+    s_scale0[tid] = a.w.scale0[tid];
+    s_shift0[tid] = a.w.shift0[tid];
+    s_b3[tid] = a.w.b3[tid];
+    if (tid < 16) s_b5[tid] = a.w.b5[tid];
+  }
+  __syncthreads();
+  float *slab = slab_all + wave * 16 * LDW;
+  const int64_t num_tiles = (a.M + 15) / 16;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+
+  // one 16 x 64 times 64 x (16 NT) product: A in registers (k = 16 quad + s), B rows from LDS
+  auto product = [&](const float (&af)[KS], const float *wt, int nt, f32x4 &acc) {
+    const float *wp = wt + (nt * 16 + l15) * LDW + quad * KS;
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 b = *reinterpret_cast<const float4 *>(wp + 4 * j);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j], b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 1], b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 2], b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 3], b.w, acc, 0, 0, 0);
+    }
+  };
+  auto load_slab = [&](float (&af)[KS]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4 *>(slab + l15 * LDW + quad * KS + 4 * j);
+      af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
+    }
+  };
+
+  float nxt[KS];
+  auto fetch = [&](int64_t tile) {
+    int64_t row = tile * 16 + l15;
+    if (row >= a.M) row = a.M - 1;
+    const float *p = a.edge + row * FP + quad * KS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+      nxt[4 * j] = v.x; nxt[4 * j + 1] = v.y; nxt[4 * j + 2] = v.z; nxt[4 * j + 3] = v.w;
+    }
+  };
+  if (first < num_tiles) fetch(first);
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int64_t tile = first + it;
+    if (tile >= num_tiles) break;
+    float af[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) af[k] = nxt[k];
+    if (it + 1 < tiles_per_wave && tile + 1 < num_tiles) fetch(tile + 1);
+    f32x4 acc;
+    // h1 = ssp(BN(edge W0^T))
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      product(af, w0t, nt, acc);
+      const int col = nt * 16 + l15;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        slab[(4 * quad + rr) * LDW + col] = ssp_fast(acc[rr] * s_scale0[col] + s_shift0[col]);
+    }
+    load_slab(af);
+    // h2 = ssp(h1 W3^T + b3)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      product(af, w3t, nt, acc);
+      const int col = nt * 16 + l15;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) slab[(4 * quad + rr) * LDW + col] = ssp_fast(acc[rr] + s_b3[col]);
+    }
+    load_slab(af);
+    // pol = h2 W5^T + b5
+    product(af, w5t, 0, acc);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t row = tile * 16 + 4 * quad + rr;
+      if (row < a.M) a.pol[row * 32 + l15] = acc[rr] + s_b5[l15];
+    }
+  }
+}
+
+void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, hipStream_t st) {
+  if (M == 0) return;
+  ReadoutFusedArgs a{edge, pol, M, w};
+  const int64_t tiles = (M + 15) / 16;
+  const int tpw = 8;
+  readout_fused_kernel<0><<<(unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), 256, 0, st>>>(a, tpw);
+}
+
 size_t edge_fused_lds_bytes(const Graph &g) {
   return fused_lds(g.max_tile_out_rows, g.max_tile_in_rows, g.max_tile_nodes).total;
 }
