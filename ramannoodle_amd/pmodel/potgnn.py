@@ -487,6 +487,11 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         return out
 
     # ------------------------------------------------------------------ introspection
+    @property
+    def num_triplets(self) -> int:
+        """Number of edge triplets (k->j, j->i, i != k) of the frozen graph."""
+        return int(_lib.load().rn_potgnn_num_triplets(self._ensure_handle()))
+
     def triplets(self):
         """Edge triplets as the device enumerates them, re-sorted into the reference's
         order: ``(i, j, idx_i, idx_j, idx_k, slot5, slot6)`` int64 arrays with the meaning of

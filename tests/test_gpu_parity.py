@@ -167,6 +167,31 @@ def test_full_size_properties():
     assert _rel_err(a[:2], orc) < REL
 
 
+def test_config3_full_size_properties():
+    """BASELINE config 3 at full size (256 atoms, E = 4608, T = 78336, 10 000 MD frames, perf widths):
+    what must hold without an oracle -- frames are independent (any permutation of the batch
+    permutes the result bit-exactly, whatever chunk and lane a frame lands in), pieces of the
+    trajectory give the same bits as the whole, outputs are symmetric and finite, and shifting
+    atoms by lattice vectors changes nothing beyond float32 round-off."""
+    from bench import make_workload
+    wl = make_workload(num_cells=(4, 4, 2), frames=10_000, hparams="perf", seed=33)
+    model = wl["model"]()
+    pos = wl["positions"]
+    assert pos.shape == (10_000, 256, 3) and model.num_edges == 4608 and model.num_triplets == 78336
+    a = model.calc_polarizabilities(pos)
+    assert a.shape == (10_000, 3, 3) and np.isfinite(a).all()
+    np.testing.assert_array_equal(a, np.swapaxes(a, 1, 2))
+    perm = np.random.default_rng(7).permutation(len(pos))
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos[perm]), a[perm])
+    pieces = np.concatenate([model.calc_polarizabilities(pos[lo:hi])
+                             for lo, hi in ((0, 1), (1, 778), (778, 4099), (4099, 10_000))])
+    np.testing.assert_array_equal(pieces, a)
+    shift = np.random.default_rng(1).integers(-2, 3, size=(1,) + pos.shape[1:]).astype(np.float64)
+    assert _rel_err(model.calc_polarizabilities(pos[:500] + shift), a[:500]) < REL
+    # the trajectory is not degenerate: frames differ by far more than the tolerance
+    assert np.abs(a - a.mean(axis=0)).max() > 1e2 * REL * np.abs(a).max()
+
+
 def test_fused_edge_block_equals_unfused(monkeypatch):
     """The opt-in fused EdgeBlock kernel (MFMA projections + triplet stage in one launch) and
     the default kernel chain are two implementations of the same math; so are the two lane
