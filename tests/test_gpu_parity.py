@@ -192,6 +192,35 @@ def test_config3_full_size_properties():
     assert np.abs(a - a.mean(axis=0)).max() > 1e2 * REL * np.abs(a).max()
 
 
+def test_config4_full_size_properties():
+    """BASELINE config 4 at full size (256 atoms, 768 modes, +-delta = 1536 displaced cells): the
+    float64 finite-difference Raman tensors and the analytic reverse-mode ones are two
+    independent routes to the same derivative (agreement O(delta^2)); the analytic map is
+    linear in the displacement; the spectrum built from them is finite and non-trivial."""
+    from bench import make_workload
+    from ramannoodle_amd.dynamics import Phonons
+    wl = make_workload(num_cells=(4, 4, 2), frames=2, hparams="perf", seed=33)
+    model = wl["model"]()
+    rng = np.random.default_rng(44)
+    n = model.num_atoms
+    qmat, _ = np.linalg.qr(rng.normal(size=(3 * n, 3 * n)))
+    mass = np.where(np.arange(n) % 2 == 0, 24.305, 15.999)
+    disp = (qmat.T.reshape(3 * n, n, 3) / np.sqrt(mass)[None, :, None]) / np.diag(wl["lattice"])[None, None, :]
+    ref = wl["positions"][0]  # a thermally displaced frame (the ideal sites are inversion centres)
+    spectrum = Phonons(ref, np.linspace(50.0, 900.0, 3 * n), disp).get_raman_spectrum(model)
+    fd = spectrum.raman_tensors
+    assert fd.shape == (768, 3, 3) and np.isfinite(fd).all()
+    analytic = model.calc_raman_tensors(ref, disp, method="analytic")
+    scale = np.abs(fd).max()
+    assert scale > 0 and np.abs(analytic - fd).max() < 1e-6 * scale
+    mix = rng.normal(size=(5, 768))
+    combined = model.calc_raman_tensors(ref, np.einsum("km,mnc->knc", mix, disp), method="analytic")
+    np.testing.assert_allclose(combined, np.einsum("km,mij->kij", mix, analytic), rtol=0,
+                               atol=1e-9 * np.abs(combined).max())
+    wavenumbers, intensities = spectrum.measure(laser_correction=True, laser_wavelength=532)
+    assert wavenumbers.shape == (768,) and np.isfinite(intensities).all() and intensities.max() > 0
+
+
 def test_fused_edge_block_equals_unfused(monkeypatch):
     """The opt-in fused EdgeBlock kernel (MFMA projections + triplet stage in one launch) and
     the default kernel chain are two implementations of the same math; so are the two lane
