@@ -11,7 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ramannoodle_amd.parallel import all_gather_frames, calc_polarizabilities_sharded, shard_bounds
+from ramannoodle_amd.parallel import (all_gather_frames, calc_polarizabilities_sharded,
+                                      calc_raman_tensors_sharded, shard_bounds)
 
 
 class _Model:
@@ -23,6 +24,11 @@ class _Model:
         self.calls.append(positions_batch.shape[0])
         v = positions_batch.reshape(positions_batch.shape[0], self.w.shape[0]) @ self.w
         return v[:, [[0, 3, 4], [3, 1, 5], [4, 5, 2]]]
+
+    def calc_raman_tensors(self, ref_positions, displacements, delta=1e-3):
+        plus = self.calc_polarizabilities(ref_positions[None] + delta * displacements)
+        minus = self.calc_polarizabilities(ref_positions[None] - delta * displacements)
+        return (plus - minus) / delta
 
 
 def _free_port():
@@ -47,6 +53,10 @@ def _worker(rank, world, port, total, out_dir):
         local = torch.arange(lo, hi, dtype=torch.float64).view(-1, 1, 1).expand(-1, 3, 3).contiguous()
         got = all_gather_frames(local, total)
         assert torch.equal(got[:, 0, 0], torch.arange(total, dtype=torch.float64))
+        # phonon modes shard the same way
+        disp = np.random.default_rng(3).normal(size=(total, n, 3))
+        tensors = calc_raman_tensors_sharded(_Model(n), pos[0], disp, delta=1e-2)
+        np.save(os.path.join(out_dir, f"t{rank}.npy"), tensors)
     finally:
         dist.destroy_process_group()
 
@@ -58,8 +68,11 @@ def test_sharded_evaluation_two_ranks(tmp_path, total):
     n = 7
     pos = np.random.default_rng(9).uniform(size=(total, n, 3))
     expect = _Model(n).calc_polarizabilities(pos)
+    disp = np.random.default_rng(3).normal(size=(total, n, 3))
+    expect_tensors = _Model(n).calc_raman_tensors(pos[0], disp, delta=1e-2)
     for r in range(2):
         np.testing.assert_array_equal(np.load(tmp_path / f"r{r}.npy"), expect)
+        np.testing.assert_allclose(np.load(tmp_path / f"t{r}.npy"), expect_tensors, rtol=1e-12, atol=1e-12)
 
 
 def test_shard_bounds_cover_everything():
