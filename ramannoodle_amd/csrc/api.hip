@@ -1405,21 +1405,25 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     HIP_TRY(hipMemcpy(hp->d_mean_std.p, ms, sizeof(ms), hipMemcpyHostToDevice));
 
     pack_weights(hp, weights);
-    // chunk size: measured on MI355X (profiles/r01_chunk_sweep.txt) throughput rises
-    // monotonically with the chunk (fewer, larger launches; 8 -> 500 frames: 21k -> 48k
-    // structures/s) and the Infinity Cache does not reward small chunks, so size the
-    // per-lane workspace to ~1.5 GiB of the 288 GB HBM.
+    // The fused kernels (kernels_fused.hip) are the default where they apply (float32, Fn and
+    // Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
+    hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
+    // Chunk size and lanes.  Throughput rises monotonically with the frames per launch
+    // (profiles/r01_chunk_sweep.txt, profiles/r01/overlap_experiments.txt section 7) and the
+    // Infinity Cache does not reward small chunks.  The fused kernels take a whole CU each, so a
+    // second lane has nothing to overlap with: ONE lane with an 8 GiB workspace (of 288 GB HBM)
+    // beats two lanes of 1.5 GiB (63.7 k vs 62.1 k structures/s at 4000 frames).  The unfused
+    // pipeline keeps two alternating lanes of 1.5 GiB.
+    if (!getenv("RN_POTGNN_LANES")) hp->num_lanes = hp->use_fused ? 1 : 2;
     int chunk = cfg->max_chunk_structures;
     if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
     if (chunk <= 0) {
       const size_t per = per_structure_elems(hp) * sizeof(float);
-      chunk = (int)std::max<size_t>(1, ((size_t)1536 << 20) / std::max<size_t>(per, 1));
-      chunk = std::min(chunk, 2048);
+      const size_t budget = hp->use_fused ? ((size_t)8192 << 20) : ((size_t)1536 << 20);
+      chunk = (int)std::max<size_t>(1, budget / std::max<size_t>(per, 1));
+      chunk = std::min(chunk, 4096);
     }
     hp->chunk = chunk;
-    // The fused EdgeBlock (kernels_fused.hip) is the default where it applies (float32,
-    // Fn and Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
-    hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
     const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
     hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
     const bool want_ro = getenv("RN_POTGNN_READOUT_FUSED") ? atoi(getenv("RN_POTGNN_READOUT_FUSED")) != 0 : true;
