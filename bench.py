@@ -34,6 +34,7 @@ EDGE_AGG_KERNEL_ID = 7  # index of "edge_agg" in rn_potgnn_kernel_times / csrc/a
 PROJ_C3_KERNEL_ID = 5   # "proj_edge_c3": the [E,64]x[64,256] projection (HBM-bound; unfused pipeline)
 PROJ_C1_KERNEL_ID = 3   # "proj_edge_c1": the [E,64]x[64,128] projection (timed with --profile-all only:
                         # event pairs around it cost the two-lane schedule ~3 % of throughput)
+NODE_AGG_KERNEL_ID = 4  # "node_agg": the NodeBlock scatter-aggregate (fused: incl. its c1 projection)
 LIGHT_CM_PER_FS = 2.99792458e-5
 
 
@@ -141,6 +142,25 @@ def measured_traffic(n, e, fn, fe, frames, passes, steps, launches, fused):
     return per_structure_pass * frames * passes * steps / launches
 
 
+def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused):
+    """The other scatter-aggregate of a pass: B_NB = 4 (E Fe + 2 N Fn) algorithmic bytes per
+    structure and pass over the HIP-event time of the NodeBlock kernel."""
+    ms, launches = times.get("node_agg", (0.0, 0))
+    if not launches or ms <= 0:
+        return None
+    per = 4 * (e * fe + 2 * n * fn)
+    achieved = per * frames * passes * steps / (ms * 1e-3) / 1e9
+    traffic = None
+    path = os.path.join(ROOT, "profiles", "r01", "node_fused_traffic.json")
+    if fused and os.path.exists(path) and (n, e, fn, fe) == (128, 2304, 64, 64):
+        traffic = json.load(open(path))["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
+    return {"kernel": "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
+            else "node_agg_kernel (NodeBlock scatter-aggregate; its c1 projection is a separate launch)",
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": traffic, "launches": launches, "avg_launch_ms": ms / launches,
+            "algorithmic_bytes_per_structure_pass": per}
+
+
 def projection_roofline(times, e, fn, fe, frames, passes, steps):
     """The HBM-bound kernel of the pipeline, for comparison: an edge projection reads E*Fe and
     writes E*NOUT floats per structure and pass (its output is an intermediate, so these are
@@ -240,7 +260,7 @@ def main():
         step()
     torch.cuda.synchronize()
     model.set_profiling(1 if args.profile_all
-                        else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID))
+                        else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID) + (1 << NODE_AGG_KERNEL_ID))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -308,6 +328,8 @@ def main():
                         "incl. 3 transcendentals per (triplet, feature pair), and fp32 MFMA shares the "
                         "issue port; achieved/peak are the HBM figures the metric asks for",
             },
+            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, args.frames, passes, args.steps,
+                                                     fused),
             "roofline_projection": projection_roofline(times, e, fn, fe, args.frames, passes, args.steps),
             "host_buffers_structures_per_s": host_rate,
         }
@@ -315,6 +337,9 @@ def main():
             result["kernel_ms"] = {k: round(v[0], 3) for k, v in times.items()}
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, args.frames))
+        for key in ("roofline_nodeblock", "roofline_projection"):
+            if result.get(key) is None:
+                result.pop(key, None)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
