@@ -195,6 +195,19 @@ double rn_potgnn_train_row_count(const rn_potgnn *h);
 
 /* ------------------------------------------------------------------ introspection */
 
+/*
+ * On-device reduction of a polarizability time series to the unpolarised MD Raman spectrum
+ * before the laser / Bose-Einstein corrections: replaces the diff, the seven
+ * autocorrelations and the seven FFTs of MDRamanSpectrum.measure (ramannoodle/spectrum/_raman.py:
+ * 282-297 via calc_signal_spectrum, spectrum/utils.py:76-124) by one batched forward FFT, one
+ * weighted power spectrum, one inverse FFT and one length-(S-1) FFT in float64 (hipFFT, loaded
+ * on first use: RN_ERR_UNSUPPORTED if it cannot be).  alpha: host float64[S][3][3];
+ * intensities: host float64[num_bins] with num_bins = ceil((S-1)/2) - 1, the non-negative
+ * frequencies of fftfreq(S-1) without the zero bin (45 a^2 + 7 g^2, same scale as the reference).
+ */
+int rn_md_raman_intensities(const double *alpha, int64_t S, int device, double *intensities,
+                            int64_t num_bins);
+
 /* Introspection: bit 0 = the fused EdgeBlock kernel is in use (float32, Fn and Fe padded to
  * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop. */
 int rn_potgnn_config_flags(const rn_potgnn *h);

@@ -66,6 +66,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int64), C.c_int]),
     "rn_potgnn_last_error": (C.c_char_p, [_P]),
     "rn_potgnn_version": (C.c_char_p, []),
+    "rn_md_raman_intensities": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64]),
     # include/rn_ingest.h (host-only trajectory reader)
     "rn_xdatcar_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "rn_xdatcar_close": (None, [_P]),

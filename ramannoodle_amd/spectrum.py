@@ -100,6 +100,24 @@ def convolve_spectrum(wavenumbers, intensities, function: str = "gaussian", widt
     return out_wavenumbers, (kernel * np.asarray(intensities)[:, None]).sum(axis=0)
 
 
+def _md_intensities_on_device(polarizability_ts: NDArray[np.float64], timestep: float, device: int):
+    """(wavenumbers, uncorrected intensities) of ``MDRamanSpectrum.measure`` from the device path."""
+    import ctypes as C
+
+    from ramannoodle_amd import _lib
+    alpha = np.ascontiguousarray(polarizability_ts, dtype=np.float64)
+    n = alpha.shape[0] - 1
+    if n < 2:
+        raise ValueError("the device reduction needs at least three time steps")
+    bins = (n + 1) // 2 - 1
+    intensities = np.empty(bins, dtype=np.float64)
+    rc = _lib.load().rn_md_raman_intensities(C.c_void_p(alpha.ctypes.data), alpha.shape[0], device,
+                                             C.c_void_p(intensities.ctypes.data), bins)
+    _lib.check(rc, None, "rn_md_raman_intensities")
+    wavenumbers = scipy.fftpack.fftfreq(n, timestep) * _PER_FS_TO_CM1
+    return wavenumbers[1:bins + 1], intensities
+
+
 class PhononRamanSpectrum(RamanSpectrum):
     """First-order spectrum from phonon wavenumbers ``(M,)`` and Raman tensors ``(M,3,3)``
     (``spectrum/_raman.py:72-194``)."""
@@ -151,11 +169,22 @@ class MDRamanSpectrum(RamanSpectrum):
     def timestep(self) -> float:
         return self._timestep
 
+    def _measure_on_device(self, device: int):
+        return _md_intensities_on_device(self._polarizability_ts, self._timestep, device)
+
     def measure(self, orientation="polycrystalline", laser_correction=False,
-                laser_wavelength=522, bose_einstein_correction=False, temperature=300):
+                laser_wavelength=522, bose_einstein_correction=False, temperature=300, device=None):
+        """``device`` (an int, not in the reference's signature): reduce the time series on that
+        GPU (``rn_md_raman_intensities``: one batched FFT, one power spectrum, two more FFTs)
+        instead of on the host; pays off for very long series (S >> 1e5) or many models."""
         _require_polycrystalline(orientation)
-        ad = np.diff(self._polarizability_ts, axis=0)  # d(alpha)/dt up to a constant
         dt = self._timestep
+        if device is not None:
+            wavenumbers, intensities = self._measure_on_device(int(device))
+            intensities = _apply_corrections(wavenumbers, intensities, laser_correction,
+                                             laser_wavelength, bose_einstein_correction, temperature)
+            return wavenumbers, intensities
+        ad = np.diff(self._polarizability_ts, axis=0)  # d(alpha)/dt up to a constant
 
         def spec(sig):
             return calc_signal_spectrum(sig, dt)[1]
