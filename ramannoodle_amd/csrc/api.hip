@@ -3,10 +3,11 @@
 // A handle owns: the frozen graph (CSR both ways, node tiles, triplet offsets), the
 // weights re-laid-out for the kernels (transposed, [filter|core] halves padded to a
 // power-of-two width, concatenated Linear layers split into per-operand blocks), and
-// per-"lane" device workspaces.  An evaluation walks the frames in chunks (a few hundred
-// frames: large launches amortise launch gaps and tails), alternating chunks between two
-// HIP streams so that the MFMA-bound projections of one chunk overlap the VALU-bound
-// aggregation of the other.
+// per-"lane" device workspaces (a lane = a HIP stream).  An evaluation walks the frames in
+// chunks (hundreds to thousands of frames: large launches amortise launch gaps and tails).
+// The fused pipeline (kernels_fused.hip) uses one lane; the unfused one alternates chunks
+// between two lanes so that the HBM-bound projections of one chunk overlap the VALU-bound
+// aggregation of the other (run_pair).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
