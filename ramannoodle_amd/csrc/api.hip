@@ -1420,7 +1420,10 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
     if (chunk <= 0) {
       const size_t per = per_structure_elems(hp) * sizeof(float);
-      const size_t budget = hp->use_fused ? ((size_t)8192 << 20) : ((size_t)1536 << 20);
+      size_t budget = hp->use_fused ? ((size_t)8192 << 20) : ((size_t)1536 << 20);
+      size_t free_b = 0, total_b = 0;  // on a shared GPU: at most 1/8 of what is free right now
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+        budget = std::min(budget, std::max<size_t>(free_b / 8 / (size_t)hp->num_lanes, (size_t)64 << 20));
       chunk = (int)std::max<size_t>(1, budget / std::max<size_t>(per, 1));
       chunk = std::min(chunk, 4096);
     }
