@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark: structures/s of GNN polarizability evaluation on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 3|2]
 
-A "step" is one pass of the hot path -- ``PotGNN.calc_polarizabilities`` on one batch of
-synthetic MD frames already resident in HBM -- plus, for N > 1, the single all-gather of
-per-frame polarizabilities.  Workload = BASELINE.json configs[1]: 128-atom rocksalt cell
-(cutoff 3.2 A: E = 2304 directed edges, T = 39168 triplets), 1000 frames per GPU, perf
-widths Fn = Fe = 64, P = 4.  Weak scaling: every rank evaluates its
-own 1000 frames.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path -- ``PotGNN.calc_polarizabilities`` on synthetic MD
+frames already resident in HBM -- plus, for N > 1, the single all-gather of the per-frame
+polarizabilities (RCCL).  Rank 0 prints ONE JSON line.
+
+``--config 3`` (default, BASELINE.json configs[2], the north star's workload): 256-atom
+rocksalt cell (cutoff 3.2 A: E = 4608 directed edges, T = 78336 triplets), ONE 10 000-frame
+MD trajectory, perf widths Fn = Fe = 64, P = 4.  The frames are sharded over the N ranks in
+contiguous blocks (1250 per GPU at N = 8): strong scaling, total work fixed.
+``--config 2`` (configs[1]): 128-atom cell, 1000 frames PER GPU (weak scaling).
+
+Launch: with ``--gpus N > 1`` and no ``WORLD_SIZE`` in the environment this process starts
+the N ranks itself (plain child processes, started before anything here touches the GPU)
+and exits with their status; under ``torch.distributed.run`` (``WORLD_SIZE`` set) it is one
+rank, and ``--gpus`` must equal ``WORLD_SIZE``.
 """
 from __future__ import annotations
 
@@ -126,20 +134,36 @@ def make_workload(num_cells=(4, 2, 2), frames=1000, hparams="perf", seed=22, t0=
 
 
 # ----------------------------------------------------------------------------- roofline
+CONFIGS = {
+    # BASELINE.json configs[2] / configs[1]: cells, frames, seed, scaling
+    3: dict(cells=(4, 4, 2), frames=10_000, seed=33, scaling="strong"),
+    2: dict(cells=(4, 2, 2), frames=1_000, seed=22, scaling="weak"),
+}
+PROFILE_ROUNDS = ("r02", "r01")  # newest first: where committed PMC summaries are looked up
+
+
 def algorithmic_bytes_edge_block(n, e, fn, fe):
     """B_EB per structure and pass: 4 (N Fn + 2 E Fe)."""
     return 4 * (n * fn + 2 * e * fe)
 
 
-def measured_traffic(n, e, fn, fe, frames, passes, steps, launches, fused):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01/edge_fused_traffic.json or edge_agg_traffic.json), when they were taken on
-    this workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "edge_fused_traffic.json" if fused else "edge_agg_traffic.json")
-    if not (launches and os.path.exists(path) and (n, e, fn, fe) == (128, 2304, 64, 64)):
-        return None
-    per_structure_pass = json.load(open(path))["hbm_bytes_per_structure_pass"]
-    return per_structure_pass * frames * passes * steps / launches
+def edge_block_mfma_flops(e, fn, fe):
+    """fp32 MFMA FLOPs of the fused EdgeBlock per structure and pass: the three edge-row
+    products W5 edge, W4 edge ([E,Fe] x [Fe,2Fe]) and c2 ([E,Fn] x [Fn,2Fe])."""
+    return 2 * e * (2 * fe * 2 * fe + fn * 2 * fe)
+
+
+def committed_profile(name, n, e, fn, fe):
+    """A PMC summary committed under profiles/rNN/ (taken with rocprofv3 --pmc on this very
+    workload: the file records its own N, E, Fn, Fe), newest round first; None if absent."""
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            shape = rec.get("workload_shape", [128, 2304, 64, 64])  # r01 files: config 2
+            if list(shape) == [n, e, fn, fe]:
+                return rec
+    return None
 
 
 def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused):
@@ -151,9 +175,9 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused):
     per = 4 * (e * fe + 2 * n * fn)
     achieved = per * frames * passes * steps / (ms * 1e-3) / 1e9
     traffic = None
-    path = os.path.join(ROOT, "profiles", "r01", "node_fused_traffic.json")
-    if fused and os.path.exists(path) and (n, e, fn, fe) == (128, 2304, 64, 64):
-        traffic = json.load(open(path))["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
+    rec = committed_profile("node_fused_traffic.json", n, e, fn, fe) if fused else None
+    if rec:
+        traffic = rec["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
     return {"kernel": "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
             else "node_agg_kernel (NodeBlock scatter-aggregate; its c1 projection is a separate launch)",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -162,10 +186,9 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused):
 
 
 def projection_roofline(times, e, fn, fe, frames, passes, steps):
-    """The HBM-bound kernel of the pipeline, for comparison: an edge projection reads E*Fe and
-    writes E*NOUT floats per structure and pass (its output is an intermediate, so these are
-    actual, not 'algorithmic', bytes).  c3 (NOUT = 4Fe) in the unfused pipeline, c1
-    (NOUT = 2Fn) when the fused EdgeBlock has absorbed c3 and c2."""
+    """The HBM-bound kernel of the unfused pipeline, for comparison: an edge projection reads
+    E*Fe and writes E*NOUT floats per structure and pass (its output is an intermediate, so
+    these are actual, not 'algorithmic', bytes)."""
     for key, nout, name in (("proj_edge_c3", 4 * fe, "rowgemm_mfma_kernel<64,4,2> (c3 edge projection)"),
                             ("proj_edge_c1", 2 * fn, "rowgemm_mfma_kernel<64,4,1> (c1 edge projection)")):
         ms, launches = times.get(key, (0.0, 0))
@@ -177,11 +200,13 @@ def projection_roofline(times, e, fn, fe, frames, passes, steps):
     return None
 
 
-def cpu_baseline(workload, sample):
-    """The oracle's faithful restatement of the reference CPU path, on `sample` frames; the
-    O(S E) variant of the same arithmetic (no N^2 geometry, no materialised concat, linear
-    readout) and a single-thread run are reported next to it so that the ratio to
-    the GPU is not inflated by the reference's avoidable quadratic terms."""
+def cpu_baseline(workload, sample, reps=3):
+    """the oracle's faithful restatement of the reference CPU path
+    (100-frame sub-batches, N^2 geometry, materialised concat, O(S^2 E) readout) on `sample`
+    frames of the same workload, 1 warm-up + `reps` timed repetitions (value = median; min
+    next to it).  The O(S E) variant of the same arithmetic and a single-thread run are
+    reported beside it so that the GPU/CPU ratio is not inflated by the reference's avoidable
+    quadratic terms."""
     from oracle import potgnn_oracle as O
     # a 1-GPU box grants ~16 host cores however many the machine has; more torch threads
     # than that only oversubscribes (measured: 256 threads were 3x slower than 16)
@@ -189,22 +214,65 @@ def cpu_baseline(workload, sample):
     model = workload["oracle"]()
     pos = workload["positions"][:sample]
 
-    def rate(frames, faithful, nthreads):
+    def timed(frames, faithful, nthreads, repeat):
         torch.set_num_threads(nthreads)
-        O.calc_polarizabilities(model, pos[:2], faithful=faithful)  # warm-up
-        t0 = time.perf_counter()
-        O.calc_polarizabilities(model, pos[:frames], faithful=faithful)
-        dt = time.perf_counter() - t0
-        return frames / dt, dt
+        O.calc_polarizabilities(model, pos[:min(frames, 4)], faithful=faithful)  # warm-up
+        out = []
+        for _ in range(repeat):
+            t0 = time.perf_counter()
+            O.calc_polarizabilities(model, pos[:frames], faithful=faithful)
+            out.append(time.perf_counter() - t0)
+        return out
 
-    value, dt = rate(sample, True, threads)
-    sane, _ = rate(sample, False, threads)
-    single, _ = rate(max(sample // 5, 2), True, 1)
+    faithful = timed(sample, True, threads, reps)
+    sane = timed(sample, False, threads, 1)
+    few = max(sample // 10, 2)
+    single = timed(few, True, 1, 1)
     torch.set_num_threads(threads)
-    return {"value": value, "unit": "structures/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} frames of the same workload, oracle faithful variant "
-                      f"(100-frame sub-batches, N^2 geometry, O(S^2 E) readout), {dt:.1f} s",
-            "linear_variant_structures_per_s": sane, "single_thread_structures_per_s": single}
+    median = sorted(faithful)[len(faithful) // 2]
+    return {"value": sample / median, "unit": "structures/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} frames of the same workload (one reference sub-batch), oracle faithful "
+                      f"variant (N^2 geometry, materialised concat, O(S^2 E) readout), 1 warm-up + "
+                      f"{reps} repetitions of {median:.1f} s (median)",
+            "repetitions_s": [round(t, 3) for t in faithful],
+            "best_structures_per_s": sample / min(faithful),
+            "linear_variant_structures_per_s": sample / sane[0],
+            "single_thread_structures_per_s": few / single[0]}
+
+
+# ----------------------------------------------------------------------------- launch
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.
+    Nothing in this (parent) process has touched the GPU: counting devices does not
+    initialise HIP, and the children are fresh interpreters."""
+    import socket
+    import subprocess
+    share = os.environ.get("RN_BENCH_SHARE_GPU", "0") == "1"
+    have = torch.cuda.device_count()
+    if not share and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):  # a rank died: the others would wait for ever
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    return max((abs(c) for c in codes), default=0)
 
 
 def main():
@@ -212,20 +280,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
-    ap.add_argument("--cells", type=str, default="4,2,2")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
+                    help="BASELINE.json workload: 3 = 256 atoms, 10k frames sharded over the GPUs "
+                         "(default); 2 = 128 atoms, 1000 frames per GPU")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="override: total frames (config 3) / frames per GPU (config 2)")
+    ap.add_argument("--cells", type=str, default="")
     ap.add_argument("--hparams", choices=list(HPARAMS), default="perf")
     ap.add_argument("--cpu-sample", type=int, default=100,
                     help="frames for the CPU baseline (100 = one reference sub-batch)")
+    ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP-event timing of every kernel (perturbs the timed region)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # (test hook: RN_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, so that the N > 1
@@ -242,17 +321,29 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    cells = tuple(int(c) for c in args.cells.split(","))
-    wl = make_workload(cells, args.frames, args.hparams, seed=22 + rank, t0=rank * args.frames)
+    from ramannoodle_amd.parallel import shard_bounds
+    cfg = CONFIGS[args.config]
+    cells = tuple(int(c) for c in args.cells.split(",")) if args.cells else cfg["cells"]
+    strong = cfg["scaling"] == "strong"
+    if strong:  # ONE trajectory of `total` frames; this rank owns the contiguous block [lo, hi)
+        total = args.frames or cfg["frames"]
+        lo, hi, per = shard_bounds(total, world, rank)
+    else:       # every rank has its own `frames` frames (consecutive stretches of one trajectory)
+        per = args.frames or cfg["frames"]
+        total, lo, hi = per * world, rank * per, (rank + 1) * per
+    mine = hi - lo
+    wl = make_workload(cells, mine, args.hparams, seed=cfg["seed"], t0=lo)
     model = wl["model"](device=local, max_chunk_structures=args.chunk)
     n, e = model.num_atoms, model.num_edges
     fn, fe, passes = wl["hparams"]
     pos = torch.tensor(wl["positions"], device="cuda")
-    out = torch.empty((args.frames, 3, 3), dtype=torch.float64, device="cuda")
-    gathered = torch.empty((world * args.frames, 3, 3), dtype=torch.float64, device="cuda")
+    # the rank's block of the all-gather input (padded to `per` frames when the split is ragged)
+    out = torch.zeros((per, 3, 3), dtype=torch.float64, device="cuda")
+    gathered = torch.empty((world * per, 3, 3), dtype=torch.float64, device="cuda")
 
     def step():
-        model.calc_polarizabilities_device(pos, out)
+        if mine:
+            model.calc_polarizabilities_device(pos, out[:mine])
         if world > 1:
             dist.all_gather_into_tensor(gathered, out)
 
@@ -279,69 +370,89 @@ def main():
     times = model.kernel_times()
     model.set_profiling(0)
     # informational: the host-buffer entry point (adds PCIe H2D/D2H); never the headline value
-    host_pos = wl["positions"]
-    t1 = time.perf_counter()
-    model.calc_polarizabilities(host_pos)
-    host_rate = args.frames / (time.perf_counter() - t1)
+    host_rate = None
+    if rank == 0 and mine:
+        sample = wl["positions"][:min(mine, 2000)]
+        t1 = time.perf_counter()
+        model.calc_polarizabilities(sample)
+        host_rate = len(sample) / (time.perf_counter() - t1)
 
     if rank == 0:
         agg_ms, agg_launches = times.get("edge_agg", (0.0, 0))
         fused = bool(model.config_flags()["fused_edge_block"])
-        total_bytes = algorithmic_bytes_edge_block(n, e, fn, fe) * args.frames * passes * args.steps
+        per_pass = algorithmic_bytes_edge_block(n, e, fn, fe)
+        total_bytes = per_pass * mine * passes * args.steps
         achieved = total_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         peak = 8000.0
+        traffic_rec = committed_profile("edge_fused_traffic.json" if fused else "edge_agg_traffic.json", n, e, fn, fe)
+        issue_rec = committed_profile("edge_fused_issue.json", n, e, fn, fe) if fused else None
+        frames_per_launch = mine * passes * args.steps / agg_launches if agg_launches else None
+        roofline = {
+            "kernel": ("edge_block_fused_kernel (EdgeBlock: MFMA projections + triplet scatter-aggregate)"
+                       if fused else "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)"),
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": peak,
+            "unit": "GB/s",
+            "frac": achieved / peak if achieved else None,
+            "traffic": (traffic_rec["hbm_bytes_per_structure_pass"] * frames_per_launch
+                        if traffic_rec and frames_per_launch else None),
+            "launches": agg_launches,
+            "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
+            "algorithmic_bytes_per_structure_pass": per_pass,
+            # why frac is small: the kernel is bound by SIMD instruction issue, not by HBM.
+            # issue_frac = (VALU-busy + fp32-MFMA-busy) share of SIMD cycles from the committed SQ
+            # counter pass of this kernel on this workload; mfma_frac = its fp32 MFMA FLOP/s, measured
+            # live, over the 157.3 TFLOP/s fp32 peak.
+            "issue_frac": issue_rec["valu_plus_mfma_busy"] if issue_rec else None,
+            "mfma_frac": (edge_block_mfma_flops(e, fn, fe) * mine * passes * args.steps / (agg_ms * 1e-3) / 157.3e12
+                          if fused and agg_ms > 0 else None),
+            "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): ~17 VALU instructions "
+                    "incl. 3 transcendentals per (triplet, feature pair), and fp32 MFMA shares the "
+                    "issue port; achieved/peak/frac are the HBM figures the metric asks for, "
+                    "issue_frac / mfma_frac say what actually bounds the kernel",
+        }
         result = {
             "metric": "structures/sec (GNN polarizability eval)",
-            "value": world * args.frames * args.steps / elapsed,
+            "value": total * args.steps / elapsed,
             "unit": "structures/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"],
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"PotGNN eval, rocksalt {cells[0]}x{cells[1]}x{cells[2]} "
-                            f"({n} atoms, E={e}, cutoff 3.2 A), {args.frames} MD frames per GPU, "
-                            f"Fn={fn} Fe={fe} P={passes}",
-                "frames_per_gpu": args.frames,
+                "workload": f"BASELINE config {args.config}: PotGNN eval, rocksalt {cells[0]}x{cells[1]}x{cells[2]} "
+                            f"({n} atoms, E={e}, cutoff 3.2 A), "
+                            + (f"one {total}-frame MD trajectory sharded over {world} GPU(s)" if strong
+                               else f"{per} MD frames per GPU")
+                            + f", Fn={fn} Fe={fe} P={passes}",
+                "total_frames": total,
+                "frames_per_gpu": per,
                 "hparams": args.hparams,
-                "parallelism": f"frames sharded x{world}, one all-gather of alpha" if world > 1
-                               else "single GPU",
+                "parallelism": (f"frames sharded x{world} in contiguous blocks "
+                                f"({'strong' if strong else 'weak'} scaling), one RCCL all-gather of alpha per step"
+                                if world > 1 else "single GPU"),
             },
-            "roofline": {
-                "kernel": ("edge_block_fused_kernel (EdgeBlock: MFMA projections + triplet scatter-aggregate)"
-                           if fused else "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)"),
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "GB/s",
-                "frac": achieved / peak if achieved else None,
-                "traffic": measured_traffic(n, e, fn, fe, args.frames, passes, args.steps, agg_launches, fused),
-                "launches": agg_launches,
-                "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
-                "algorithmic_bytes_per_structure_pass": algorithmic_bytes_edge_block(n, e, fn, fe),
-                "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): ~17 VALU instructions "
-                        "incl. 3 transcendentals per (triplet, feature pair), and fp32 MFMA shares the "
-                        "issue port; achieved/peak are the HBM figures the metric asks for",
-            },
-            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, args.frames, passes, args.steps,
-                                                     fused),
-            "roofline_projection": projection_roofline(times, e, fn, fe, args.frames, passes, args.steps),
+            "roofline": roofline,
+            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused),
+            "roofline_projection": projection_roofline(times, e, fn, fe, mine, passes, args.steps),
             "host_buffers_structures_per_s": host_rate,
         }
         if args.profile_all:
             result["kernel_ms"] = {k: round(v[0], 3) for k, v in times.items()}
         if world == 1 and not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, args.frames))
+            result["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, mine), args.cpu_reps)
         for key in ("roofline_nodeblock", "roofline_projection"):
             if result.get(key) is None:
                 result.pop(key, None)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -121,6 +121,15 @@ int rn_potgnn_forward_device(rn_potgnn *h, const double *d_positions, int64_t S,
 int rn_potgnn_forward(rn_potgnn *h, const double *positions, int64_t S, float *vec6);
 
 /*
+ * PotGNN.forward(lattice[S,3,3], atomic_numbers, positions[S,N,3]) with a lattice PER SAMPLE
+ * (_gnn.py:603-611: the minimum-image displacements of sample s are mapped to Cartesian with
+ * lattice[s]; the graph topology stays the reference structure's): host f64 lattices[S*9]
+ * (row-major, rows are lattice vectors), host f64 positions -> host f32[S*6], eval mode.
+ */
+int rn_potgnn_forward_lattices(rn_potgnn *h, const double *lattices, const double *positions,
+                               int64_t S, float *vec6);
+
+/*
  * Replaces the finite-difference loop of Phonons.get_raman_spectrum
  * (ramannoodle/dynamics/_phonon.py:93-106) with ONE batched evaluation of the 2M
  * displaced cells in double precision on the device:

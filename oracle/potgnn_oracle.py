@@ -258,14 +258,20 @@ def batch_indices(model: OracleModel, s: int):
     return model._trip_cache[s]
 
 
-def geometry(model: OracleModel, positions: torch.Tensor, faithful: bool):
+def geometry(model: OracleModel, positions: torch.Tensor, faithful: bool, lattices=None):
     """Per-frame unit vectors ``[S*E,3]`` and distances ``[S*E,1]``
-    (ramannoodle/pmodel/torch/_gnn.py:602-615, _utils.py:78-84)."""
+    (ramannoodle/pmodel/torch/_gnn.py:602-615, _utils.py:78-84).  ``lattices`` ``[S,3,3]``:
+    one lattice per sample, as ``forward`` receives it (_gnn.py:607-610); default: the
+    reference structure's lattice for every sample (what ``calc_polarizabilities`` passes,
+    _gnn.py:694-700)."""
     s = positions.size(0)
     a, b = model.edges[1], model.edges[2]
-    lat = torch.from_numpy(model.lattice).type(positions.dtype)
+    if lattices is None:
+        lat = torch.from_numpy(model.lattice).type(positions.dtype).unsqueeze(0).expand(s, -1, -1)
+    else:
+        lat = torch.as_tensor(lattices).type(positions.dtype)
     if faithful:
-        cart = min_image_cart(lat.unsqueeze(0).expand(s, -1, -1), positions)
+        cart = min_image_cart(lat, positions)
         dist_m = torch.sqrt(torch.sum(cart**2, dim=-1))
         g = torch.arange(s).repeat_interleave(a.numel())
         aa, bb = a.repeat(s), b.repeat(s)
@@ -338,7 +344,7 @@ def readout_mlp(sd, edge, train: bool = False):
 
 
 def forward(model: OracleModel, positions, faithful: bool = True, stages: dict | None = None,
-            grad: bool = False, train: bool = False):
+            grad: bool = False, train: bool = False, lattices=None):
     """Standardised polarizability 6-vectors ``[S,6]``
     (ramannoodle/pmodel/torch/_gnn.py:617-665).  ``grad=True`` keeps the autograd graph (used
     to check the device's reverse-mode Jacobian d alpha / d r)."""
@@ -347,7 +353,7 @@ def forward(model: OracleModel, positions, faithful: bool = True, stages: dict |
     e = model.num_edges
     sd = model.sd
     with torch.set_grad_enabled(grad):
-        unit, dist = geometry(model, positions, faithful)
+        unit, dist = geometry(model, positions, faithful, lattices)
         node = node_embedding(model, s)
         edge = gaussian_rbf(model, dist)
         trip, off_e = batch_indices(model, s)

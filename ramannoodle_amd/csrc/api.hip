@@ -151,7 +151,7 @@ struct rn_potgnn {
   Precision<float> f32;
   Precision<double> f64;
   // cached I/O staging for the host entry points
-  DeviceBuf io_pos, io_alpha, io_vec6;
+  DeviceBuf io_pos, io_alpha, io_vec6, io_lat;
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
   double bn_count = 0;  // rows the pending step's BatchNorm statistics cover (all ranks)
@@ -356,6 +356,13 @@ void pack_weights(rn_potgnn *h, const float *w) {
   transpose(L.W5T, HP, 32, L.t_W5);
 }
 
+// Frames per device work chunk in precision T.  The workspace budget is counted in bytes, so
+// the float64 lanes (created on first use, next to the float32 ones) take half the frames.
+template <typename T>
+int chunk_frames(const rn_potgnn *h) {
+  return sizeof(T) == 8 ? std::max(1, h->chunk / 2) : h->chunk;
+}
+
 template <typename T>
 Precision<T> &prec(rn_potgnn *h);
 template <>
@@ -464,7 +471,7 @@ void ensure_precision(rn_potgnn *h) {
   P.node_table = w + L.node_table;
   P.ones = w + L.ones;
 
-  const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges, S = h->chunk;
+  const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges, S = chunk_frames<T>(h);
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
   const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
   for (int l = 0; l < h->num_lanes; ++l) {
@@ -552,6 +559,7 @@ struct ChunkRun {
   double *d_alpha;
   float *d_vec6;
   double *d_alpha_raw;
+  const T *d_lat = nullptr;  // per-frame lattices [S][9] of this chunk, or null: the reference structure's
   int cur = 0;
   T *node[2], *edge[2], *unit4, *npc1, *np3, *bufA, *bufB;
   int64_t MN, ME;
@@ -592,8 +600,8 @@ struct ChunkRun {
     Precision<T> &P = prec<T>(h);
     {
       Timer t(h, st(), K_GEOM);
-      launch_geom_rbf<T>(d_pos, S, h->g, P.lattice.template as<T>(), P.offsets,
-                         (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
+      launch_geom_rbf<T>(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
+                         P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
     }
     {
       Timer t(h, st(), K_NODE_INIT);
@@ -709,8 +717,9 @@ struct ChunkRun {
 
 template <typename T>
 void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_alpha,
-               float *d_vec6, double *d_alpha_raw) {
+               float *d_vec6, double *d_alpha_raw, const T *d_lat) {
   ChunkRun<T> c(h, ln, d_pos, S, d_alpha, d_vec6, d_alpha_raw);
+  c.d_lat = d_lat;
   c.begin();
   for (int p = 0; p < h->cfg.num_message_passes; ++p) {
     c.stage_project(p);
@@ -746,7 +755,7 @@ void run_pair(rn_potgnn *h, ChunkRun<T> &a, ChunkRun<T> &b) {
 
 template <typename T>
 void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alpha, float *d_vec6,
-                    double *d_alpha_raw, hipStream_t user, bool sync) {
+                    double *d_alpha_raw, hipStream_t user, bool sync, const T *d_lat = nullptr) {
   ensure_precision<T>(h);
   Precision<T> &P = prec<T>(h);
   const int N = h->cfg.num_atoms;
@@ -754,25 +763,30 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
   const int lanes = h->num_lanes;
   for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(P.lanes[l].stream, h->ev_start, 0));
   auto make = [&](int lane, int64_t first, int s) {
-    return ChunkRun<T>(h, P.lanes[lane], d_pos + first * N * 3, s,
-                       d_alpha ? d_alpha + first * 9 : nullptr, d_vec6 ? d_vec6 + first * 6 : nullptr,
-                       d_alpha_raw ? d_alpha_raw + first * 9 : nullptr);
+    ChunkRun<T> c(h, P.lanes[lane], d_pos + first * N * 3, s,
+                  d_alpha ? d_alpha + first * 9 : nullptr, d_vec6 ? d_vec6 + first * 6 : nullptr,
+                  d_alpha_raw ? d_alpha_raw + first * 9 : nullptr);
+    c.d_lat = d_lat ? d_lat + first * 9 : nullptr;
+    return c;
   };
   int64_t done = 0;
+  const int chunk = chunk_frames<T>(h);
+  h->train_S = 0;  // lane 0's workspace is about to be overwritten: a pending train_forward is void
   while (done < S) {
     const int64_t left = S - done;
     if (lanes == 2 && h->interleave && !h->keep_stages && left > 1) {
       // split what is left of this round evenly over the two lanes
-      const int64_t both = std::min<int64_t>(left, 2 * (int64_t)h->chunk);
+      const int64_t both = std::min<int64_t>(left, 2 * (int64_t)chunk);
       const int sa = (int)((both + 1) / 2), sb = (int)(both - sa);
       ChunkRun<T> a = make(0, done, sa), b = make(1, done + sa, sb);
       run_pair<T>(h, a, b);
       h->last_chunk_structs = sa;
       done += both;
     } else {
-      const int s = (int)std::min<int64_t>(h->chunk, left);
+      const int s = (int)std::min<int64_t>(chunk, left);
       run_chunk<T>(h, P.lanes[0], d_pos + done * N * 3, s, d_alpha ? d_alpha + done * 9 : nullptr,
-                   d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr);
+                   d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr,
+                   d_lat ? d_lat + done * 9 : nullptr);
       h->last_chunk_structs = s;
       done += s;
     }
@@ -976,6 +990,7 @@ void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*
   ensure_precision<T>(h);
   Precision<T> &P = prec<T>(h);
   const int N = h->g.N;
+  h->train_S = 0;  // the tape and lane 0 are reused: a pending train_forward is void
   h->io_pos.ensure((size_t)N * 3 * sizeof(double));
   HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice));
   ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), 1);
@@ -1507,6 +1522,29 @@ int rn_potgnn_forward(rn_potgnn *h, const double *positions, int64_t S, float *v
   });
 }
 
+int rn_potgnn_forward_lattices(rn_potgnn *h, const double *lattices, const double *positions, int64_t S,
+                               float *vec6) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!lattices || !positions || !vec6))) {
+    set_error(h, "invalid lattices / positions / vec6 / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    const size_t pb = (size_t)S * h->cfg.num_atoms * 3 * sizeof(double);
+    std::vector<float> lat32((size_t)S * 9);  // the reference's forward computes in float32
+    for (size_t i = 0; i < lat32.size(); ++i) lat32[i] = (float)lattices[i];
+    h->io_pos.ensure(pb);
+    h->io_lat.ensure(lat32.size() * sizeof(float));
+    h->io_vec6.ensure((size_t)S * 6 * sizeof(float));
+    HIP_TRY(hipMemcpy(h->io_pos.p, positions, pb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->io_lat.p, lat32.data(), lat32.size() * sizeof(float), hipMemcpyHostToDevice));
+    forward_device<float>(h, h->io_pos.as<double>(), S, nullptr, h->io_vec6.as<float>(), nullptr,
+                          nullptr, true, h->io_lat.as<float>());
+    HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
 int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions, const double *displacements,
                             int64_t M, double delta, double *raman) {
   if (!h) return RN_ERR_INVALID_ARGUMENT;
@@ -1619,7 +1657,8 @@ int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
     return RN_ERR_INVALID_ARGUMENT;
   }
   if (h->train_S <= 0) {
-    set_error(h, "train_backward needs a preceding train_forward");
+    set_error(h, "train_backward needs a preceding train_forward (an evaluation or Jacobian call in "
+                 "between discards its tape)");
     return RN_ERR_INVALID_ARGUMENT;
   }
   return guarded(h, [&]() { train_backward(h, dvec6, grads); });

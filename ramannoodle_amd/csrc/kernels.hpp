@@ -77,6 +77,7 @@ void launch_setup(const T *emb, const T *W2, const T *b2, const T *W4, const T *
 
 template <typename T>
 void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
+                     int lat_stride /* 0: one lattice for every frame; 9: lattice[S][9] */,
                      const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st);
 
 template <typename T>

@@ -100,7 +100,8 @@ __device__ __forceinline__ T wrap_min_image(T d) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict__ pos, int S,
-                                                       Graph g, const T *__restrict__ lat,
+                                                       Graph g, const T *__restrict__ lat_base,
+                                                       int lat_stride,  // 0: one lattice; 9: one per frame
                                                        const T *__restrict__ offs, T coef,
                                                        Dims d, T *__restrict__ unit4,
                                                        T *__restrict__ edge0) {
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict_
   if (row < total) {
     const int s = (int)(row / g.E), e = (int)(row % g.E);
     const int a = g.edge_a[e], b = g.edge_b[e];
+    const T *lat = lat_base + (int64_t)s * lat_stride;  // _gnn.py:607-610: the sample's own lattice
     const double *pa = pos + ((int64_t)s * g.N + a) * 3;
     const double *pb = pos + ((int64_t)s * g.N + b) * 3;
     T f[3];
@@ -146,16 +148,16 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict_
 }
 
 template <typename T>
-void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
+void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice, int lat_stride,
                      const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st) {
   const int64_t total = (int64_t)S * g.E;
   if (total == 0) return;
-  geom_rbf_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, offsets,
-                                                                      coef, d, unit4, edge0);
+  geom_rbf_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride,
+                                                                      offsets, coef, d, unit4, edge0);
 }
-template void launch_geom_rbf<float>(const double *, int, const Graph &, const float *,
+template void launch_geom_rbf<float>(const double *, int, const Graph &, const float *, int,
                                      const float *, float, Dims, float *, float *, hipStream_t);
-template void launch_geom_rbf<double>(const double *, int, const Graph &, const double *,
+template void launch_geom_rbf<double>(const double *, int, const Graph &, const double *, int,
                                       const double *, double, Dims, double *, double *,
                                       hipStream_t);
 

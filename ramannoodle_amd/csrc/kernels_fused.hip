@@ -78,6 +78,11 @@ __host__ __device__ inline FusedLds fused_lds(int maxR, int maxD, int maxN) {
   return L;
 }
 
+// Retire this wave's outstanding LDS-DMA writes.  An s_barrier does not wait for vmcnt, so every
+// wave runs this before the barrier that publishes the operand tiles to the other waves (the
+// compiler happens to drain vmcnt earlier today; the protocol must not rest on that).
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // 16-byte LDS-DMA: lane l's 16 bytes at `src` land at lds_wave_base + 16 l.
 __device__ __forceinline__ void dma16(const float *src, float *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       store4(row + FP + c0, c);
       if (q4 == 0) sq[r] = ss;
     }
+    dma_wait();  // round 0's operand rows (issued before the frame loop / in the last round)
     __syncthreads();
 
     // ================= destination edges, 16 per round (one per lane group)
@@ -469,7 +475,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2.v[k] + c3.v[k]);
         store4(a.edge_out + drow * FP + c0, out);
       }
-      __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten
+      dma_wait();
+      __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten; next operand rows landed
     }
   }
 }
@@ -574,6 +581,7 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
       const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
       store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.npc1 + (nrow0 + j0 + n) * (2 * FP) + c));
     }
+    dma_wait();
     __syncthreads();  // the DMA'd operand rows of round 0 (every wave's share) have landed
     for (int r = 0; r < nrounds; ++r) {
       {
@@ -610,6 +618,7 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
         const LnParams<float> pc{load4<float>(s_c1g + FP + c0), load4<float>(s_c1b + FP + c0)};
         store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
       }
+      dma_wait();
       __syncthreads();  // S2: bufP may be rewritten, next round's operand rows landed; after the last round: gated complete
     }
     // ---- per atom: sum over its in-edges (ascending, as the reference's scatter), LayerNorm, residual

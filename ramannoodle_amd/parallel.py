@@ -15,15 +15,19 @@ import torch.distributed as dist
 
 
 def shard_bounds(num_items: int, world_size: int, rank: int) -> tuple[int, int, int]:
-    """Contiguous block ``[lo, hi)`` of rank ``rank`` and the padded per-rank length."""
-    per = -(-num_items // world_size) if num_items else 0
-    lo = min(rank * per, num_items)
-    hi = min(lo + per, num_items)
-    return lo, hi, per
+    """Contiguous block ``[lo, hi)`` of rank ``rank`` and the largest block length (the
+    per-rank length the all-gather pads to).  Balanced: block sizes differ by at most one
+    (the first ``num_items % world_size`` ranks take the extra item), so no rank is left
+    empty while ``num_items >= world_size``."""
+    base, extra = divmod(num_items, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi, base + (1 if extra else 0)
 
 
 def all_gather_frames(local: torch.Tensor, num_items: int, group=None) -> torch.Tensor:
-    """All-gather per-rank blocks ``[S_local, ...]`` (padded to equal length) and trim."""
+    """All-gather per-rank blocks ``[S_local, ...]`` (padded to equal length) and drop the
+    padding row of the shorter blocks."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     _, _, per = shard_bounds(num_items, world, rank)
@@ -32,7 +36,11 @@ def all_gather_frames(local: torch.Tensor, num_items: int, group=None) -> torch.
     padded[: local.shape[0]] = local
     gathered = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, padded, group=group)
-    return gathered[:num_items]
+    if num_items == world * per:
+        return gathered
+    blocks = gathered.view((world, per) + tail)
+    sizes = [hi - lo for lo, hi, _ in (shard_bounds(num_items, world, r) for r in range(world))]
+    return torch.cat([blocks[r, : sizes[r]] for r in range(world)])
 
 
 def calc_polarizabilities_sharded(model, positions_batch: np.ndarray, group=None) -> np.ndarray:
@@ -73,8 +81,10 @@ def calc_raman_tensors_sharded(model, ref_positions: np.ndarray, displacements: 
 
 
 def average_gradients(model, group=None) -> None:
-    """Data-parallel training step, after ``loss.backward()``: replace every parameter
-    gradient by its mean over the ranks (ONE flat all-reduce, <= 1.2 MB for Fn=Fe=64)."""
+    """Data-parallel training step, after ``backward()``: replace every parameter gradient by
+    its mean over the ranks (ONE flat all-reduce, <= 1.2 MB for Fn=Fe=64).  For a ragged
+    mini-batch the caller scales each rank's loss by ``rank_loss_weight`` BEFORE ``backward()``,
+    which makes this plain mean the gradient of the mean loss over the whole mini-batch."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     params = [p for p in model.parameters() if p.grad is not None]
@@ -91,6 +101,17 @@ def average_gradients(model, group=None) -> None:
         offset += n
 
 
+def rank_loss_weight(local_items: int, global_items: int, group=None) -> float:
+    """Factor for this rank's mean-reduced loss before ``backward()``: ``W * S_local / S``.
+    The mean over ranks of the weighted losses is the mean loss over the whole mini-batch, and
+    every rank back-propagates cotangents on the same scale (``W *`` those of the global loss),
+    so the all-reduced BatchNorm sums of the device step mix consistently and the plain mean
+    of ``average_gradients`` is exact for unequal blocks too.  1.0 for equal blocks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1.0
+    return dist.get_world_size(group) * local_items / global_items
+
+
 def batch_shard(tensors, group=None):
     """This rank's contiguous block of every tensor of a mini-batch (first dimension)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -98,3 +119,14 @@ def batch_shard(tensors, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, _ = shard_bounds(tensors[0].shape[0], world, rank)
     return tuple(t[lo:hi] for t in tensors)
+
+
+def mean_over_ranks(value: float, group=None) -> float:
+    """Mean of a per-rank scalar over the ranks (one small all-reduce)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    buf = torch.tensor([float(value)], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        buf = buf.cuda()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return float(buf.cpu()[0]) / dist.get_world_size(group)

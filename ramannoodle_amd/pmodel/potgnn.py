@@ -340,27 +340,36 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         return out
 
     def forward(self, lattice, atomic_numbers, positions) -> torch.Tensor:
-        """Standardised 6-vectors ``[S,6]`` (``_gnn.py:617-665``, eval mode).  ``lattice``
-        ``[S,3,3]`` and ``atomic_numbers`` ``[S,N]`` must repeat the reference structure's
-        (the graph, and hence the device model, is frozen to it)."""
+        """Standardised 6-vectors ``[S,6]`` (``_gnn.py:617-665``).  ``lattice`` ``[S,3,3]`` is
+        used per sample in the geometry, as the reference does (``_gnn.py:603-611``); the graph
+        topology is the reference structure's.  ``atomic_numbers`` ``[S,N]`` must repeat the
+        reference structure's species (the frozen graph and the per-type embedding table of the
+        device model are built from them)."""
         pos = np.ascontiguousarray(torch.as_tensor(positions).detach().cpu().numpy(), dtype=np.float64)
         verify_ndarray_shape("positions", pos, (None, self.num_atoms, 3))
-        lat = torch.as_tensor(lattice).detach().cpu().numpy().astype(np.float64)
+        lat = np.ascontiguousarray(torch.as_tensor(lattice).detach().cpu().numpy(), dtype=np.float64)
         zs = torch.as_tensor(atomic_numbers).detach().cpu().numpy()
         if lat.shape != (pos.shape[0], 3, 3) or zs.shape != (pos.shape[0], self.num_atoms):
             raise ValueError("lattice / atomic_numbers do not match positions")
-        if pos.shape[0] and (
-                not np.allclose(lat, self._ref_structure.lattice[None], rtol=1e-6, atol=1e-9)
-                or not np.array_equal(zs, np.broadcast_to(
-                    np.asarray(self._ref_structure.atomic_numbers), zs.shape))):
-            raise NotImplementedError("per-sample lattices / species that differ from the "
-                                      "reference structure are not supported")
+        if pos.shape[0] and not np.array_equal(zs, np.broadcast_to(
+                np.asarray(self._ref_structure.atomic_numbers), zs.shape)):
+            raise NotImplementedError("atomic_numbers that differ from the reference structure's "
+                                      "are not supported")
+        same_lattice = (not pos.shape[0]) or np.allclose(lat, self._ref_structure.lattice[None],
+                                                         rtol=1e-6, atol=1e-9)
         if self.training:
+            if not same_lattice:
+                raise NotImplementedError("training mode supports only the reference structure's "
+                                          "lattice (PolarizabilityDataset holds a single lattice)")
             return _TrainStep.apply(self, pos, *self.parameters())
         out = np.empty((pos.shape[0], 6), dtype=np.float32)
         handle = self._ensure_handle()
-        rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), pos.shape[0], _ptr(out))
-        _lib.check(rc, handle, "rn_potgnn_forward")
+        if same_lattice:
+            rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), pos.shape[0], _ptr(out))
+            _lib.check(rc, handle, "rn_potgnn_forward")
+        else:
+            rc = _lib.load().rn_potgnn_forward_lattices(handle, _ptr(lat), _ptr(pos), pos.shape[0], _ptr(out))
+            _lib.check(rc, handle, "rn_potgnn_forward_lattices")
         return torch.from_numpy(out)
 
     # -- training step pieces used by _TrainStep ------------------------------------------

@@ -24,7 +24,7 @@ def train_single_epoch(model, training_set, validation_set, batch_size: int, opt
     # data-parallel (``model.enable_data_parallel()``): every rank draws the same shuffled
     # mini-batches (same generator state), evaluates its contiguous block of each with the
     # BatchNorm statistics of the whole batch, and the gradients are averaged over the ranks,
-    # so a step equals the single-process step on the full mini-batch (equal block sizes).
+    # so a step equals the single-process step on the full mini-batch (blocks weighted by size).
     group = getattr(model, "data_parallel_group", None)
     # The host side of a step (loss, optimiser on <= 1.2 MB of parameters) is tiny: torch's
     # intra-op thread pool only adds wake-up stalls there (measured on a 1-GPU MI355X box:
@@ -41,17 +41,24 @@ def _run_epoch(model, train_loader, validation_loader, optimizer, loss_function,
     model.train()
     train_losses = []
     for batch in train_loader:
+        weight = 1.0
         if group is not None:
-            if batch[0].shape[0] < torch.distributed.get_world_size(group):
+            global_items = batch[0].shape[0]
+            if global_items < torch.distributed.get_world_size(group):
                 continue  # a block would be empty: every rank skips the same batch
-            batch = parallel.batch_shard(tuple(batch), group)
+            batch = parallel.batch_shard(tuple(batch), group)  # balanced blocks, none empty
+            # blocks of a ragged batch differ by one structure: weight the rank's loss by its
+            # share so that the averaged step is the full-batch step
+            weight = parallel.rank_loss_weight(batch[0].shape[0], global_items, group)
         lattice, atomic_numbers, position, polarizability = batch
         out = model.forward(lattice, atomic_numbers, position)
-        loss = loss_function(out, polarizability)
-        train_losses.append(float(loss.detach()))
+        loss = loss_function(out, polarizability) * weight
         loss.backward()
         if group is not None:
             parallel.average_gradients(model, group)
+            train_losses.append(parallel.mean_over_ranks(float(loss.detach()), group))
+        else:
+            train_losses.append(float(loss.detach()))
         optimizer.step()
         optimizer.zero_grad()
 
@@ -59,7 +66,7 @@ def _run_epoch(model, train_loader, validation_loader, optimizer, loss_function,
     validation_losses, validation_vars = [], []
     for lattice, atomic_numbers, position, polarizability in validation_loader:
         out = model.forward(lattice, atomic_numbers, position)
-        validation_losses.append(float(loss_function(out, polarizability)))
+        validation_losses.append(float(loss_function(out, polarizability).detach()))
         validation_vars.append(torch.var(out, dim=0).detach().cpu().numpy().copy())
     return (float(np.mean(train_losses)), float(np.mean(validation_losses)),
             np.mean(validation_vars, axis=0))

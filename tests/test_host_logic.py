@@ -335,3 +335,44 @@ def test_reset_parameters():
     fresh = PotGNN(_ref(), 3.0, 8, 12, 2, 0.0, 4.0, g["mean"], g["std"]).state_dict()
     for k in after:
         assert torch.equal(after[k], fresh[k]), k
+
+
+def test_config1_plumbing_linear_model_phonon_spectrum():
+    """BASELINE config 1 (CPU plumbing, no GPU): an 8-atom rocksalt cell, a seeded linear
+    ``PolarizabilityModel`` (what an order-1 P1 InterpolationModel evaluates,
+    ``pmodel/_interpolation.py:239-244``) and 24 modes through ``Phonons.get_raman_spectrum`` ->
+    ``PhononRamanSpectrum.measure``, against what the reference's own classes produced
+    (tests/golden/make_golden_r2.py).  Exercises the generic per-mode loop of
+    ``dynamics/_phonon.py:93-106`` (the model has no ``calc_raman_tensors``)."""
+    from ramannoodle_amd.abstract import PolarizabilityModel
+    from ramannoodle_amd.dynamics import Phonons
+
+    g = load_golden("config1_plumbing")
+
+    class LinearModel(PolarizabilityModel):
+        def __init__(self):
+            self.calls = 0
+
+        def calc_polarizabilities(self, positions_batch):
+            self.calls += 1
+            d = (positions_batch - g["positions"][None]).reshape(positions_batch.shape[0], -1)
+            return g["alpha0"][None] + np.einsum("sk,kij->sij", d, g["coeff"])
+
+    model = LinearModel()
+    spectrum = Phonons(g["positions"], g["wavenumbers"], g["displacements"]).get_raman_spectrum(model)
+    assert model.calls == 2 * 24  # +-delta per mode, batch of one each (the reference's loop)
+    np.testing.assert_allclose(spectrum.raman_tensors, g["raman_tensors"], rtol=0,
+                               atol=1e-12 * np.abs(g["raman_tensors"]).max())
+    w, i = spectrum.measure()
+    np.testing.assert_array_equal(w, g["out_wavenumbers"])
+    np.testing.assert_allclose(i, g["int_raw"], rtol=1e-10)
+    w, i = spectrum.measure(laser_correction=True, laser_wavelength=522, bose_einstein_correction=True,
+                            temperature=300)
+    np.testing.assert_allclose(i, g["int_corr"], rtol=1e-10)
+    # a model that rejects the shape surfaces as the reference's "incompatible" ValueError
+    class Wrong(PolarizabilityModel):
+        def calc_polarizabilities(self, positions_batch):
+            raise ValueError("positions_batch has wrong shape")
+
+    with pytest.raises(ValueError, match="incompatible"):
+        Phonons(g["positions"], g["wavenumbers"], g["displacements"]).get_raman_spectrum(Wrong())

@@ -64,3 +64,24 @@ def test_phonon_raman_tensors_f64():
     r = O.raman_tensors_fd(m, g["positions"], g["ph/displacements"])
     scale = np.abs(g["ph/raman_tensors"]).max()
     np.testing.assert_allclose(r, g["ph/raman_tensors"], rtol=0, atol=2e-5 * scale)
+
+
+def test_forward_with_per_sample_lattices_matches_reference():
+    """``forward(lattice[S,3,3], ...)`` uses each sample's own lattice in the geometry
+    (_gnn.py:603-611); fixture: the reference's forward on six strained cells, float32 and
+    float64 (tests/golden/make_golden_r2.py)."""
+    from tests.conftest import load_golden
+    g, r = load_golden("triclinic20"), load_golden("triclinic20_r2")
+    m = O.model_from_arrays(g)
+    out = O.forward(m, r["lat/positions"], faithful=True, lattices=r["lat/lattices"]).numpy()
+    np.testing.assert_array_equal(out, r["lat/forward"])
+    sane = O.forward(m, r["lat/positions"], faithful=False, lattices=r["lat/lattices"]).numpy()
+    np.testing.assert_allclose(sane, r["lat/forward"], rtol=0, atol=2e-7)
+    m64 = O.model_from_arrays(g).to(torch.float64)
+    # (a float64 reference model derives its Gaussian coefficient from a float64 linspace, _gnn.py:63-64)
+    m64.coefficient = -0.5 / ((float(g["hp"][5]) - float(g["hp"][4])) / (int(g["hp"][2]) - 1)) ** 2
+    out64 = O.forward(m64, r["lat/positions"], faithful=False, lattices=r["lat/lattices"]).numpy()
+    np.testing.assert_allclose(out64, r["lat/forward64"], rtol=0, atol=1e-13)
+    # sample 0 carries the reference lattice: same as the plain call
+    plain = O.forward(m, r["lat/positions"][:1], faithful=True).numpy()
+    np.testing.assert_array_equal(plain[0], r["lat/forward"][0])
