@@ -218,7 +218,9 @@ int rn_md_raman_intensities(const double *alpha, int64_t S, int device, double *
                             int64_t num_bins);
 
 /* Introspection: bit 0 = the fused EdgeBlock kernel is in use (float32, Fn and Fe padded to
- * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop. */
+ * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop; bit 2 = the fused
+ * kernels' matrix products run as split-f16 MFMA (default; RN_POTGNN_MFMA=f32 at create time
+ * selects the exact-f32 MFMA). */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

@@ -142,6 +142,7 @@ struct rn_potgnn {
   bool use_fused = false;
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
+  bool mfma_f16 = true;  // fused kernels: split-f16 MFMA products (RN_POTGNN_MFMA=f32: exact-f32 MFMA)
   Graph g{};
   DeviceBuf g_ints;
   double lattice[9], mean[9], stdv[9];
@@ -627,7 +628,7 @@ struct ChunkRun {
     if constexpr (sizeof(T) == 4) {
       if (fused() && h->use_node_fused) {  // c1 edge projection + aggregation in one launch
         Timer t(h, st(), K_NODE_AGG);
-        launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, st());
+        launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, h->mfma_f16, st());
         node_fused = true;
       }
     }
@@ -668,7 +669,7 @@ struct ChunkRun {
     {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
-        if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, st());
+        if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
         launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
@@ -689,7 +690,7 @@ struct ChunkRun {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
         if (fused() && h->use_readout_fused) {  // the three layers in one launch
-          launch_readout_fused(edge[cur], ME, P.ro, bufA, st());
+          launch_readout_fused(edge[cur], ME, P.ro, bufA, h->mfma_f16, st());
           done = true;
         }
       }
@@ -1267,6 +1268,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   h->debug_sync = getenv("RN_POTGNN_DEBUG_SYNC") && atoi(getenv("RN_POTGNN_DEBUG_SYNC")) != 0;
   if (const char *e = getenv("RN_POTGNN_INTERLEAVE")) h->interleave = atoi(e) != 0;
   if (const char *e = getenv("RN_POTGNN_LANES")) h->num_lanes = std::max(1, std::min(2, atoi(e)));
+  if (const char *e = getenv("RN_POTGNN_MFMA")) h->mfma_f16 = !(e[0] == 'f' && e[1] == '3');
 
   // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets
   h->edge_a.assign(edge_a, edge_a + E);
@@ -1694,7 +1696,7 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
-  int flags = h->use_fused ? 1 : 0;
+  int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0);
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);

@@ -185,4 +185,31 @@ __device__ __forceinline__ Vec4<T> ln_row(const Vec4<T> &x, const LnParams<T> &p
   return out;
 }
 
+// ---------------------------------------------------------------- split-f16 matrix products
+// The f32-input MFMA runs at the vector rate (1/16 of the f16/bf16 rate) and blocks the SIMD's
+// VALU issue while it does.  A two-way f16 split  x = hi + lo  (hi = f16(x), lo = f16(x - hi):
+// 22 significant bits, absolute error <= 2^-25 below the f16 normal range) and the three products
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_16x16x32_f16 (f16 products are exact in f32,
+// accumulation in f32) reproduce the f32 product to ~3e-7 * sum|a||b| -- the size of f32's own
+// rounding in a K = 64 dot product -- in 3/16 of the matrix-pipe time, and leave the VALU free.
+// Operand values here are tanh outputs / normalised rows and O(1) weights: far inside f16 range.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// 8 consecutive k of one operand row -> (hi, lo) fragments of v_mfma_f32_16x16x32_f16
+__device__ __forceinline__ void split_f16x8(const float *x, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (_Float16)x[j];
+    lo[j] = (_Float16)(x[j] - (float)hi[j]);
+  }
+}
+// acc += A * B for one 16x16x32 step, smallest terms first
+__device__ __forceinline__ f32x4_t mfma_split3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh,
+                                               const f16x8 &bl, f32x4_t acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+}
+
 }  // namespace rn

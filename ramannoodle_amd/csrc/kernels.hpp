@@ -173,10 +173,12 @@ constexpr size_t kFusedLdsBudget = 80 * 1024;
 size_t edge_fused_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
 bool edge_fused_supported(const Graph &g, Dims d);
 size_t node_fused_lds_bytes(const Graph &g);
-void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, hipStream_t st);
+// `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
+void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
+                          hipStream_t st);
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
-                       const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);
+                       const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
-                       int S, const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);
+                       int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
 
 }  // namespace rn

@@ -5,8 +5,11 @@
 //   Q'_e = W5 edge_e + Wi node[b_e]                        edges e leaving the tile's atoms
 //   P'_d = W4 edge_d + Wj node[b_d] + Wk node[a_d] + bias  edges d entering them
 //   c2_d = c2_linear(node[b_d] * node[a_d])
-// by exact-fp32 MFMA (v_mfma_f32_16x16x4_f32; W4 and the c2 weight stay in VGPRs as
-// B-fragments for the whole kernel, W5 is re-read from L2 once per frame), then the
+// by MFMA (W4 and the c2 weight stay in VGPRs as B-fragments for the whole kernel, W5 is re-read
+// from L2 once per frame) -- by default as three split-f16 products on v_mfma_f32_16x16x32_f16
+// (device_utils.hpp: f32-grade accuracy at 3/16 of the f32 matrix-pipe time, and the f16 pipe
+// does not block the VALU as the f32-input MFMA does), or exact-fp32 v_mfma_f32_16x16x4_f32
+// (RN_POTGNN_MFMA=f32) -- then the
 // triplet stage of _EdgeBlock (_gnn.py:270-291): add -> LayerNorm(2Fe) -> sigmoid*tanh ->
 // sum over e -> LayerNorm(Fe), plus c2 (_gnn.py:223-228) and the residual tanh
 // (_gnn.py:351).  The node terms (Wi|Wj|Wk) node come from the small per-atom projection
@@ -45,8 +48,8 @@ struct EdgeFusedArgs {
 };
 
 #ifndef RN_FUSED_EXPERIMENT
-#define RN_FUSED_EXPERIMENT 0  // timing-only variants (wrong results): 1 no triplet loop, 2 no round MFMA,
-#endif                        // 3 no Q' MFMA, 4 no epilogue transcendental work
+#define RN_FUSED_EXPERIMENT 0  // timing-only variant (wrong results): 1 no triplet loop
+#endif
 #ifndef RN_FUSED_PAIRWISE
 #define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
 #endif
@@ -88,9 +91,56 @@ __device__ __forceinline__ void dma16(const float *src, float *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+
+// One wave's B operand of a [64 x N] weight matrix W (row-major, leading dimension ld): the 32
+// columns colbase .. colbase+31 as two 16-column MFMA tiles, resident in VGPRs.  `product`
+// accumulates  acc[t] += A * W[:, tile t]  for a 16-row A tile of which this lane (row l15, quad)
+// holds the 16 consecutive k = 16 quad .. 16 quad + 15 in `af`.
+template <bool F16>
+struct WaveB;
+template <>
+struct WaveB<false> {  // exact f32: v_mfma_f32_16x16x4_f32, k = 16 quad + step
+  float w[2][KS];
+  __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = W[(size_t)(quad * KS + k) * ld + colbase + 16 * t + l15];
+  }
+  __device__ __forceinline__ void product(const float (&af)[KS], f32x4 (&acc)[2]) const {
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], w[t][k], acc[t], 0, 0, 0);
+  }
+};
+template <>
+struct WaveB<true> {  // split f16: v_mfma_f32_16x16x32_f16, step s covers k = 16 quad + 8 s + j
+  f16x8 h[2][2], l[2][2];
+  __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = W[(size_t)(quad * KS + 8 * s + j) * ld + colbase + 16 * t + l15];
+        split_f16x8(tmp, h[t][s], l[t][s]);
+      }
+  }
+  __device__ __forceinline__ void product(const float (&af)[KS], f32x4 (&acc)[2]) const {
+    f16x8 ah[2], al[2];
+    split_f16x8(af, ah[0], al[0]);
+    split_f16x8(af + 8, ah[1], al[1]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = mfma_split3(ah[s], al[s], h[t][s], l[t][s], acc[t]);
+  }
+};
 }  // namespace
 
-template <bool PAD, bool FASTG>
+template <bool PAD, bool FASTG, bool F16>
 __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
@@ -154,16 +204,10 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   }
 
   // ---- B fragments resident for the whole kernel: lane (n = l15, quad) holds
-  //      W[k = 16 quad + s][colbase + 16 t + n]
-  float bW4[2][KS], bWc[2][KS];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = quad * KS + s, col = colbase + 16 * t + l15;
-      bW4[t][s] = a.w.c3_WeT[(size_t)k * (4 * FP) + col];
-      bWc[t][s] = a.w.c2_WT[(size_t)k * (2 * FP) + col];
-    }
+  //      W[k = 16 quad ..+15][colbase + 16 t + n]
+  WaveB<F16> bW4, bWc;
+  bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad);
+  bWc.load(a.w.c2_WT, 2 * FP, colbase, l15, quad);
   float c2bias[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) c2bias[t] = a.w.c2_bias[colbase + 16 * t + l15];
@@ -211,12 +255,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     // (batching the operand loads of several 16-row tiles, or fetching the Wi node[b_e] terms
     //  ahead of the barrier, measured no faster: the extra registers spill)
     {
-      float bW5[2][KS];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-          bW5[t][k] = a.w.c3_WeT[(size_t)(quad * KS + k) * (4 * FP) + 2 * FP + colbase + 16 * t + l15];
+      WaveB<F16> bW5;
+      bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad);
       for (int mt = 0; mt * 16 < rows; ++mt) {
         float af[KS];
         const float *src = a.edge_in + (erow0 + eo0 + min(mt * 16 + l15, rows - 1)) * FP + quad * KS;
@@ -226,11 +266,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           af[s4] = v.x; af[s4 + 1] = v.y; af[s4 + 2] = v.z; af[s4 + 3] = v.w;
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int k = 0; k < (RN_FUSED_EXPERIMENT == 3 ? 1 : KS); ++k)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW5[t][k], acc[t], 0, 0, 0);
+        bW5.product(af, acc);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int r = mt * 16 + 4 * quad + rr;
@@ -303,11 +339,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
         }
         f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int k = 0; k < (RN_FUSED_EXPERIMENT == 2 ? 1 : KS); ++k)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            accP[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW4[t][k], accP[t], 0, 0, 0);
+        bW4.product(af, accP);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int off = l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4;
@@ -316,11 +348,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           af[4 * j] = x.x * y.x; af[4 * j + 1] = x.y * y.y; af[4 * j + 2] = x.z * y.z; af[4 * j + 3] = x.w * y.w;
         }
         f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int k = 0; k < (RN_FUSED_EXPERIMENT == 2 ? 1 : KS); ++k)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bWc[t][k], accC[t], 0, 0, 0);
+        bWc.product(af, accC);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int i = 4 * quad + rr;  // row of the 16x16 output tile held in register rr
@@ -518,7 +546,7 @@ __host__ __device__ inline NodeFusedLds node_fused_lds(int maxD, int maxN) {
 }
 }  // namespace
 
-template <bool PAD>
+template <bool PAD, bool F16>
 __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
@@ -556,11 +584,8 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
     d_edge[i] = e;
     d_bl[i] = g.edge_b[e] - j0;
   }
-  float bW[2][KS];  // B fragments of the edge part of c1_linear, resident
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int k = 0; k < KS; ++k) bW[t][k] = a.w.c1_WeT[(size_t)(quad * KS + k) * (2 * FP) + colbase + 16 * t + l15];
+  WaveB<F16> bW;  // B fragments of the edge part of c1_linear, resident
+  bW.load(a.w.c1_WeT, 2 * FP, colbase, l15, quad);
 
   const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
   const int nvalid = min(max(a.d.Fn - c0, 0), 4);
@@ -592,10 +617,7 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
           af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bW[t][k], acc[t], 0, 0, 0);
+        bW.product(af, acc);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -644,12 +666,13 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
 size_t node_fused_lds_bytes(const Graph &g) { return node_fused_lds(g.max_tile_in_rows, g.max_tile_nodes).total; }
 
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
-                       const Graph &g, Dims d, const PassW<float> &w, hipStream_t st) {
+                       const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
   if (S == 0 || g.N == 0) return;
   NodeFusedArgs a{edge, node_in, npc1, node_out, S, g, d, w};
   const size_t lds = node_fused_lds_bytes(g);
   const bool pad = d.Fn != d.FnP;
-  auto kern = pad ? &node_block_fused_kernel<true> : &node_block_fused_kernel<false>;
+  auto kern = f16 ? (pad ? &node_block_fused_kernel<true, true> : &node_block_fused_kernel<false, true>)
+                         : (pad ? &node_block_fused_kernel<true, false> : &node_block_fused_kernel<false, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -683,22 +706,35 @@ struct ReadoutFusedArgs {
   ReadoutW<float> w;
 };
 
-template <int DUMMY>
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs a, int tiles_per_wave) {
-  constexpr int LDW = FP + 4;
-  __shared__ __attribute__((aligned(16))) float w0t[FP * LDW], w3t[FP * LDW], w5t[16 * LDW];
+  constexpr int LDW = FP + 4;  // floats: row stride of the transposed f32 weights and of the slabs
+  constexpr int LDH = FP + 8;  // halves: row stride of the transposed split-f16 weights
+  // transposed weights [n][k]: f32 (LDW) or split f16, hi then lo (LDH)
+  constexpr int kW64 = F16 ? 2 * FP * LDH * 2 : FP * LDW * 4, kW16 = F16 ? 2 * 16 * LDH * 2 : 16 * LDW * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char w0_raw[kW64], w3_raw[kW64], w5_raw[kW16];
   __shared__ __attribute__((aligned(16))) float slab_all[4 * 16 * LDW];
   __shared__ float s_scale0[FP], s_shift0[FP], s_b3[FP], s_b5[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
+  auto put = [&](unsigned char *raw, int rows, int n, int k, float v) {
+    if constexpr (F16) {
+      _Float16 *h = reinterpret_cast<_Float16 *>(raw), *l = h + rows * LDH;
+      const _Float16 hi = (_Float16)v;
+      h[n * LDH + k] = hi;
+      l[n * LDH + k] = (_Float16)(v - (float)hi);
+    } else {
+      reinterpret_cast<float *>(raw)[n * LDW + k] = v;
+    }
+  };
   for (int i = tid; i < FP * FP; i += 256) {
     const int k = i / FP, n = i % FP;  // W?T is [K][N] row-major
-    w0t[n * LDW + k] = a.w.W0T[i];
-    w3t[n * LDW + k] = a.w.W3T[i];
+    put(w0_raw, FP, n, k, a.w.W0T[i]);
+    put(w3_raw, FP, n, k, a.w.W3T[i]);
   }
   for (int i = tid; i < FP * 16; i += 256) {
     const int k = i / 16, n = i % 16;
-    w5t[n * LDW + k] = a.w.W5T[k * 32 + n];
+    put(w5_raw, 16, n, k, a.w.W5T[k * 32 + n]);
   }
   if (tid < FP) {
     s_scale0[tid] = a.w.scale0[tid];
@@ -712,16 +748,32 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
   const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
 
   // one 16 x 64 times 64 x (16 NT) product: A in registers (k = 16 quad + s), B rows from LDS
-  auto product = [&](const float (&af)[KS], const float *wt, int nt, f32x4 &acc) {
-    const float *wp = wt + (nt * 16 + l15) * LDW + quad * KS;
+  f16x8 ah[2], al[2];  // split-f16 image of the A rows in `af` (F16 only; refreshed by `operand`)
+  auto operand = [&](const float (&af)[KS]) {
+    if constexpr (F16) {
+      split_f16x8(af, ah[0], al[0]);
+      split_f16x8(af + 8, ah[1], al[1]);
+    }
+  };
+  auto product = [&](const float (&af)[KS], const unsigned char *raw, int rows, int nt, f32x4 &acc) {
     acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (F16) {
+      const _Float16 *h = reinterpret_cast<const _Float16 *>(raw) + (nt * 16 + l15) * LDH + quad * KS;
+      const _Float16 *l = h + rows * LDH;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 b = *reinterpret_cast<const float4 *>(wp + 4 * j);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j], b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 1], b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 2], b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 3], b.w, acc, 0, 0, 0);
+      for (int s = 0; s < 2; ++s)
+        acc = mfma_split3(ah[s], al[s], *reinterpret_cast<const f16x8 *>(h + 8 * s),
+                          *reinterpret_cast<const f16x8 *>(l + 8 * s), acc);
+    } else {
+      const float *wp = reinterpret_cast<const float *>(raw) + (nt * 16 + l15) * LDW + quad * KS;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4 *>(wp + 4 * j);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j], b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 1], b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 2], b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * j + 3], b.w, acc, 0, 0, 0);
+      }
     }
   };
   auto load_slab = [&](float (&af)[KS]) {
@@ -753,9 +805,10 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
     if (it + 1 < tiles_per_wave && tile + 1 < num_tiles) fetch(tile + 1);
     f32x4 acc;
     // h1 = ssp(BN(edge W0^T))
+    operand(af);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      product(af, w0t, nt, acc);
+      product(af, w0_raw, FP, nt, acc);
       const int col = nt * 16 + l15;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
@@ -763,16 +816,18 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
     }
     load_slab(af);
     // h2 = ssp(h1 W3^T + b3)
+    operand(af);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      product(af, w3t, nt, acc);
+      product(af, w3_raw, FP, nt, acc);
       const int col = nt * 16 + l15;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) slab[(4 * quad + rr) * LDW + col] = ssp_fast(acc[rr] + s_b3[col]);
     }
     load_slab(af);
     // pol = h2 W5^T + b5
-    product(af, w5t, 0, acc);
+    operand(af);
+    product(af, w5_raw, 16, 0, acc);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int64_t row = tile * 16 + 4 * quad + rr;
@@ -781,12 +836,15 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
   }
 }
 
-void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, hipStream_t st) {
+void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
+                          hipStream_t st) {
   if (M == 0) return;
   ReadoutFusedArgs a{edge, pol, M, w};
   const int64_t tiles = (M + 15) / 16;
   const int tpw = 8;
-  readout_fused_kernel<0><<<(unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), 256, 0, st>>>(a, tpw);
+  const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
+  if (f16) readout_fused_kernel<true><<<blocks, 256, 0, st>>>(a, tpw);
+  else readout_fused_kernel<false><<<blocks, 256, 0, st>>>(a, tpw);
 }
 
 size_t edge_fused_lds_bytes(const Graph &g) {
@@ -799,9 +857,9 @@ bool edge_fused_supported(const Graph &g, Dims d) {
   return d.FnP == 64 && d.FeP == 64 && g.E > 0 && edge_fused_lds_bytes(g) <= kFusedLdsBudget;
 }
 
-template <bool PAD, bool FASTG>
+template <bool PAD, bool FASTG, bool F16>
 static void launch_cfg(const EdgeFusedArgs &a, size_t lds, hipStream_t st) {
-  auto kern = &edge_block_fused_kernel<PAD, FASTG>;
+  auto kern = &edge_block_fused_kernel<PAD, FASTG, F16>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -822,17 +880,18 @@ static void launch_cfg(const EdgeFusedArgs &a, size_t lds, hipStream_t st) {
 }
 
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
-                       int S, const Graph &g, Dims d, const PassW<float> &w, hipStream_t st) {
+                       int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
   EdgeFusedArgs a{edge_in, edge_out, node, np3, S, g, d, w};
   const size_t lds = edge_fused_lds_bytes(g);
   const bool pad = d.Fe != d.FeP;
-  if (pad) {
-    if (w.c3_fast & 1) launch_cfg<true, true>(a, lds, st);
-    else launch_cfg<true, false>(a, lds, st);
+  const bool fast = (w.c3_fast & 1) != 0;
+  if (f16) {
+    if (pad) fast ? launch_cfg<true, true, true>(a, lds, st) : launch_cfg<true, false, true>(a, lds, st);
+    else fast ? launch_cfg<false, true, true>(a, lds, st) : launch_cfg<false, false, true>(a, lds, st);
   } else {
-    if (w.c3_fast & 1) launch_cfg<false, true>(a, lds, st);
-    else launch_cfg<false, false>(a, lds, st);
+    if (pad) fast ? launch_cfg<true, true, false>(a, lds, st) : launch_cfg<true, false, false>(a, lds, st);
+    else fast ? launch_cfg<false, true, false>(a, lds, st) : launch_cfg<false, false, false>(a, lds, st);
   }
 }
 

@@ -327,6 +327,30 @@ def test_fused_edge_block_equals_unfused(monkeypatch):
     np.testing.assert_array_equal(seq, unfused)
 
 
+def test_split_f16_mfma_matches_exact_f32_mfma(monkeypatch):
+    """The fused kernels' matrix products run as three split-f16 MFMAs (hi/lo operands, f32
+    accumulation) by default; RN_POTGNN_MFMA=f32 selects the exact-f32 MFMA.  Both must agree with
+    each other to float32 round-off and with the float64 oracle to the same margin."""
+    from bench import make_workload
+    from oracle import potgnn_oracle as O
+    wl = make_workload(num_cells=(2, 2, 2), frames=6, hparams="perf", seed=3)
+    monkeypatch.setenv("RN_POTGNN_MFMA", "f32")
+    m32 = wl["model"]()
+    a32 = m32.calc_polarizabilities(wl["positions"])
+    assert not m32.config_flags()["split_f16_mfma"]
+    monkeypatch.delenv("RN_POTGNN_MFMA")
+    m16 = wl["model"]()
+    a16 = m16.calc_polarizabilities(wl["positions"])
+    assert m16.config_flags()["split_f16_mfma"] and m16.config_flags()["fused_edge_block"]
+    oracle = wl["oracle"]().to(torch.float64)
+    want = O.calc_polarizabilities(oracle, wl["positions"], faithful=False)
+    std = lambda a: (a - oracle.mean) / oracle.std  # noqa: E731
+    e16, e32 = _rel_err(std(a16), std(want)), _rel_err(std(a32), std(want))
+    print(f"standardised alpha vs float64 oracle: split-f16 MFMA {e16:.2e}, exact-f32 MFMA {e32:.2e}, "
+          f"between them {_rel_err(std(a16), std(a32)):.2e}")
+    assert e16 < REL / 2 and e32 < REL / 2 and _rel_err(std(a16), std(a32)) < REL / 2
+
+
 def _random_model(g, cutoff, fn, fe, passes, seed):
     """Product model + oracle with identical random weights on a fixture's geometry."""
     from oracle import potgnn_oracle as O
