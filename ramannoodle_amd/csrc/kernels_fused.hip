@@ -425,10 +425,13 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           auto triplet = [&](int rq, float (&sumk)[4]) {
             const float *qr = bufQ + rq * LDQ + c0;
             const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
-            float dot = 0.f;
+            float dotf = pdf[0] * qf.v[0], dotc = pdc[0] * qc.v[0];  // two short chains, not one of eight
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dot += pdf[k] * qf.v[k] + pdc[k] * qc.v[k];
-            dot = lg_sum<LG>(dot);
+            for (int k = 1; k < 4; ++k) {
+              dotf = fmaf(pdf[k], qf.v[k], dotf);
+              dotc = fmaf(pdc[k], qc.v[k], dotc);
+            }
+            float dot = lg_sum<LG>(dotf + dotc);
             float ve = dot + (spe + sq[rq]);
             ve = ve > 1e-5f ? ve : 1e-5f;
             const float rstd = fast_rsq(ve);
@@ -436,7 +439,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             for (int k = 0; k < 4; ++k) {
               const float e1 = fast_exp2((pf[k] + qf.v[k]) * rstd + b3f[k]);
               const float e2 = fast_exp2((pc[k] + qc.v[k]) * rstd + b3c[k]);
-              sumk[k] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
+              const float t2 = 1.0f + e2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+              sumk[k] = fmaf(e2 - 1.0f, fast_rcp(fmaf(e1, t2, t2)), sumk[k]);
             }
           };
 #if RN_FUSED_PAIRWISE
