@@ -103,6 +103,24 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
                                     double *alpha);
 
 /*
+ * Pipelined host entry for streamed trajectories: the call enqueues the
+ * host-to-device copy of `positions` on the handle's copy stream, the evaluation behind it and the
+ * device-to-host copy of the result, and returns without waiting, so that the copy of block k+1
+ * (and whatever the caller does meanwhile, e.g. parsing block k+2) overlaps the evaluation of
+ * block k.  Two staging slots: a third call first waits for the first one.  `positions` must stay
+ * untouched and `alpha` unread until rn_potgnn_wait returns; both should be page-locked
+ * (rn_host_buffer_alloc) -- pageable memory works but makes the copies synchronous.
+ */
+int rn_potgnn_calc_polarizabilities_async(rn_potgnn *h, const double *positions, int64_t S,
+                                          double *alpha);
+/* Blocks until every rn_potgnn_calc_polarizabilities_async call issued so far has finished. */
+int rn_potgnn_wait(rn_potgnn *h);
+
+/* Page-locked host memory for the pipelined entry (hipHostMalloc / hipHostFree). */
+int rn_host_buffer_alloc(size_t bytes, int device, void **out);
+void rn_host_buffer_free(void *p);
+
+/*
  * Same computation on device-resident buffers (what bench.py times):
  *   d_positions device f64[S*N*3];  d_alpha device f64[S*9] or NULL;
  *   d_vec6 device f32[S*6] or NULL -- standardised (xx,yy,zz,xy,xz,yz), i.e. the value

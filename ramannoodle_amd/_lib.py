@@ -50,6 +50,10 @@ SIGNATURES = {
     "rn_potgnn_destroy": (None, [_P]),
     "rn_potgnn_calc_polarizabilities": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int]),
+    "rn_potgnn_calc_polarizabilities_async": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "rn_potgnn_wait": (C.c_int, [_P]),
+    "rn_host_buffer_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(_P)]),
+    "rn_host_buffer_free": (None, [_P]),
     "rn_potgnn_forward": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_lattices": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "rn_potgnn_raman_tensors": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, _P]),
@@ -75,6 +79,14 @@ SIGNATURES = {
     "rn_xdatcar_species": (C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_int32)]),
     "rn_xdatcar_read": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int]),
     "rn_xdatcar_last_error": (C.c_char_p, [_P]),
+    "rn_vasprun_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "rn_vasprun_close": (None, [_P]),
+    "rn_vasprun_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "rn_vasprun_read": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int]),
+    "rn_vasprun_timestep": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "rn_vasprun_initial_num_atoms": (C.c_int64, [_P]),
+    "rn_vasprun_initial_structure": (C.c_int, [_P, C.POINTER(C.c_int32), _P, _P, C.c_int64, _P, C.c_int64]),
+    "rn_vasprun_last_error": (C.c_char_p, [_P]),
 }
 
 _lib = None

@@ -153,6 +153,14 @@ struct rn_potgnn {
   Precision<double> f64;
   // cached I/O staging for the host entry points
   DeviceBuf io_pos, io_alpha, io_vec6, io_lat;
+  // pipelined host entry (rn_potgnn_calc_polarizabilities_async): two staging slots
+  struct Slot {
+    DeviceBuf pos, alpha;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool busy = false;
+  } slots[2];
+  hipStream_t copy_stream = nullptr, exec_stream = nullptr;
+  int next_slot = 0;
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
   double bn_count = 0;  // rows the pending step's BatchNorm statistics cover (all ranks)
@@ -1467,6 +1475,12 @@ void rn_potgnn_destroy(rn_potgnn *h) {
     if (h->f64.lanes[l].stream) (void)hipStreamDestroy(h->f64.lanes[l].stream);
     if (h->f64.lanes[l].done) (void)hipEventDestroy(h->f64.lanes[l].done);
   }
+  for (auto &sl : h->slots) {
+    if (sl.copied) (void)hipEventDestroy(sl.copied);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  if (h->exec_stream) (void)hipStreamDestroy(h->exec_stream);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   for (int i = 0; i < 2; ++i)
     if (h->ev_g[i]) (void)hipEventDestroy(h->ev_g[i]);
@@ -1504,6 +1518,70 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
                           nullptr, true);
     HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
   });
+}
+
+int rn_potgnn_calc_polarizabilities_async(rn_potgnn *h, const double *positions, int64_t S, double *alpha) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !alpha))) {
+    set_error(h, "invalid positions / alpha / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    if (!h->copy_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
+      for (auto &sl : h->slots) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+      }
+    }
+    auto &sl = h->slots[h->next_slot];
+    h->next_slot ^= 1;
+    if (sl.busy) HIP_TRY(hipEventSynchronize(sl.done));  // its staging buffers are about to be reused
+    const size_t pb = (size_t)S * h->cfg.num_atoms * 3 * sizeof(double);
+    sl.pos.ensure(pb);
+    sl.alpha.ensure((size_t)S * 9 * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(sl.pos.p, positions, pb, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipEventRecord(sl.copied, h->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(h->exec_stream, sl.copied, 0));
+    forward_device<float>(h, sl.pos.as<double>(), S, sl.alpha.as<double>(), nullptr, nullptr, h->exec_stream,
+                          false);
+    HIP_TRY(hipMemcpyAsync(alpha, sl.alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost,
+                           h->exec_stream));
+    HIP_TRY(hipEventRecord(sl.done, h->exec_stream));
+    sl.busy = true;
+  });
+}
+
+int rn_potgnn_wait(rn_potgnn *h) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  return guarded(h, [&]() {
+    for (auto &sl : h->slots)
+      if (sl.busy) {
+        HIP_TRY(hipEventSynchronize(sl.done));
+        sl.busy = false;
+      }
+    resolve_timers(h);
+  });
+}
+
+int rn_host_buffer_alloc(size_t bytes, int device, void **out) {
+  if (!out || bytes == 0) return RN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error(nullptr, "no usable HIP device (count=%d, requested=%d)", ndev, device);
+    return RN_ERR_NO_DEVICE;
+  }
+  return guarded(nullptr, [&]() {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  });
+}
+
+void rn_host_buffer_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int rn_potgnn_forward(rn_potgnn *h, const double *positions, int64_t S, float *vec6) {

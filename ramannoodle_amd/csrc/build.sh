@@ -15,11 +15,14 @@ for f in api kernels_agg kernels_gemm kernels_fused kernels_bwd spectrum; do
     pids+=($!)
   fi
 done
-if [ ! -f "$here/build/ingest.o" ] || [ "$here/ingest.cpp" -nt "$here/build/ingest.o" ] || \
-   [ "$here/../../include/rn_ingest.h" -nt "$here/build/ingest.o" ]; then
-  g++ -O3 -std=c++17 -fPIC -Wall -pthread -c "$here/ingest.cpp" -o "$here/build/ingest.o" &
-  pids+=($!)
-fi
+for f in ingest ingest_vasprun; do
+  if [ ! -f "$here/build/$f.o" ] || [ "$here/$f.cpp" -nt "$here/build/$f.o" ] || \
+     [ "$here/ingest_common.hpp" -nt "$here/build/$f.o" ] || \
+     [ "$here/../../include/rn_ingest.h" -nt "$here/build/$f.o" ]; then
+    g++ -O3 -std=c++17 -fPIC -Wall -pthread -c "$here/$f.cpp" -o "$here/build/$f.o" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "$here/build/api.o" "$here/build/kernels_agg.o" "$here/build/kernels_gemm.o" "$here/build/kernels_fused.o" "$here/build/kernels_bwd.o" "$here/build/spectrum.o" "$here/build/ingest.o" -lpthread -ldl
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "$here/build/api.o" "$here/build/kernels_agg.o" "$here/build/kernels_gemm.o" "$here/build/kernels_fused.o" "$here/build/kernels_bwd.o" "$here/build/spectrum.o" "$here/build/ingest.o" "$here/build/ingest_vasprun.o" -lpthread -ldl
 echo "built $out"

@@ -1,0 +1,104 @@
+"""Streamed evaluation of a trajectory file: parse block k+1 on a worker
+thread (the native readers release the GIL) while the device evaluates block k.
+
+With the device model (``PotGNN``) the blocks are parsed straight into page-locked buffers
+(``rn_host_buffer_alloc``) and handed to ``rn_potgnn_calc_polarizabilities_async``: the
+host-to-device copy of block k+1 runs on the handle's copy stream while block k is still being
+evaluated, and results come back into a page-locked array.  Any other ``PolarizabilityModel`` is
+called block by block through ``calc_polarizabilities``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from ramannoodle_amd import _lib
+
+
+class PinnedArray:
+    """A float64 numpy view of page-locked host memory (``hipHostMalloc``)."""
+
+    def __init__(self, shape, device: int = 0) -> None:
+        self._lib = _lib.load()
+        count = int(np.prod(shape))
+        ptr = C.c_void_p()
+        rc = self._lib.rn_host_buffer_alloc(max(count, 1) * 8, int(device), C.byref(ptr))
+        _lib.check(rc, None, "rn_host_buffer_alloc")
+        self._ptr = ptr
+        self.array = np.ctypeslib.as_array((C.c_double * max(count, 1)).from_address(ptr.value))[:count].reshape(shape)
+
+    def free(self) -> None:
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._lib.rn_host_buffer_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def _wrap_in_place(block: np.ndarray) -> None:
+    """``apply_pbc`` (``x - x // 1``, ``structure/utils.py:13-29``) without a temporary copy."""
+    np.subtract(block, np.floor_divide(block, 1.0), out=block)
+
+
+def stream_polarizabilities(model, reader, chunk_frames: int = 2000) -> np.ndarray:
+    """Polarizabilities ``(S,3,3)`` of every frame ``reader`` (an ``XdatcarReader`` /
+    ``VasprunReader``) holds, wrapped into the cell as ``Trajectory`` does."""
+    total, atoms = reader.num_frames, reader.num_atoms
+    bounds = [(lo, min(lo + chunk_frames, total)) for lo in range(0, total, chunk_frames)]
+    pipelined = hasattr(model, "calc_polarizabilities_async")
+    pinned = []
+    if pipelined:
+        device = model.device_index
+        pinned = [PinnedArray((chunk_frames, atoms, 3), device) for _ in range(3)]
+        out_pin = PinnedArray((total, 3, 3), device)
+        pinned.append(out_pin)
+        buffers, result = [p.array for p in pinned[:3]], out_pin.array
+    else:
+        buffers = [np.empty((chunk_frames, atoms, 3), dtype=np.float64) for _ in range(2)]
+        result = np.empty((total, 3, 3), dtype=np.float64)
+    errors: list[BaseException] = []
+
+    def parse(k):
+        lo, hi = bounds[k]
+        try:
+            block = buffers[k % len(buffers)][: hi - lo]
+            reader.read(lo, hi - lo, out=block)
+            _wrap_in_place(block)
+        except BaseException as exc:  # pylint: disable=broad-except  (re-raised by the caller)
+            errors.append(exc)
+
+    try:
+        if bounds:
+            parse(0)
+        for k, (lo, hi) in enumerate(bounds):
+            if errors:
+                raise errors[0]
+            worker = None
+            if k + 1 < len(bounds):
+                # (three input buffers when pipelined: block k-1 may still be in flight on the device
+                #  while block k is submitted and block k+1 is parsed)
+                worker = threading.Thread(target=parse, args=(k + 1,))
+                worker.start()
+            block = buffers[k % len(buffers)][: hi - lo]
+            if pipelined:
+                model.calc_polarizabilities_async(block, result[lo:hi])
+            else:
+                result[lo:hi] = model.calc_polarizabilities(block)
+            if worker is not None:
+                worker.join()
+        if pipelined:
+            model.wait()
+        if errors:
+            raise errors[0]
+        return np.array(result)  # (a copy: the page-locked staging memory is released below)
+    finally:
+        if pipelined:
+            try:
+                model.wait()
+            finally:
+                for p in pinned:
+                    p.free()

@@ -1,2 +1,2 @@
 """VASP file formats (mirrors ``ramannoodle.io.vasp``: only the trajectory side of the hot path)."""
-from ramannoodle_amd.io.vasp import xdatcar  # noqa: F401
+from ramannoodle_amd.io.vasp import vasprun, xdatcar  # noqa: F401

@@ -10,7 +10,6 @@ device evaluating chunk k (``stream_polarizabilities``).
 from __future__ import annotations
 
 import ctypes as C
-import threading
 from pathlib import Path
 
 import numpy as np
@@ -113,37 +112,11 @@ def read_trajectory(filepath, timestep: float):
 
 
 def stream_polarizabilities(model, filepath, chunk_frames: int = 2000) -> NDArray[np.float64]:
-    """Polarizabilities ``(S, 3, 3)`` of every frame of an XDATCAR file without holding the
-    trajectory in memory: a worker thread parses block k+1 (the native reader releases the GIL)
-    while the device evaluates block k.  Positions are wrapped into the cell as ``Trajectory`` does."""
-    from ramannoodle_amd.structure import apply_pbc
+    """Polarizabilities ``(S, 3, 3)`` of every frame of the file without holding the trajectory
+    in memory: a worker thread parses block k+1 (the native reader releases the GIL) while the
+    device evaluates block k; with the device model the blocks go through page-locked buffers and
+    the pipelined entry point (``ramannoodle_amd.io._stream``).  Positions are wrapped into the
+    cell as ``Trajectory`` does."""
+    from ramannoodle_amd.io._stream import stream_polarizabilities as _stream
     with XdatcarReader(filepath) as reader:
-        total = reader.num_frames
-        result = np.empty((total, 3, 3), dtype=np.float64)
-        buffers = [np.empty((chunk_frames, reader.num_atoms, 3), dtype=np.float64) for _ in range(2)]
-        bounds = [(lo, min(lo + chunk_frames, total)) for lo in range(0, total, chunk_frames)]
-        errors: list[BaseException] = []
-
-        def parse(k):
-            lo, hi = bounds[k]
-            try:
-                reader.read(lo, hi - lo, out=buffers[k % 2][: hi - lo])
-            except BaseException as exc:  # pylint: disable=broad-except  (re-raised by the caller)
-                errors.append(exc)
-
-        worker = None
-        if bounds:
-            parse(0)
-        for k, (lo, hi) in enumerate(bounds):
-            if errors:
-                raise errors[0]
-            if k + 1 < len(bounds):
-                worker = threading.Thread(target=parse, args=(k + 1,))
-                worker.start()
-            result[lo:hi] = model.calc_polarizabilities(apply_pbc(buffers[k % 2][: hi - lo]))
-            if worker is not None:
-                worker.join()
-                worker = None
-        if errors:
-            raise errors[0]
-        return result
+        return _stream(model, reader, chunk_frames)

@@ -319,6 +319,35 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities")
         return out
 
+    @property
+    def device_index(self) -> int:
+        """HIP ordinal the model evaluates on."""
+        if self._device is not None:
+            return int(self._device)
+        return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+    def calc_polarizabilities_async(self, positions_batch: NDArray[np.float64],
+                                    out: NDArray[np.float64]) -> None:
+        """Pipelined form of ``calc_polarizabilities`` (``rn_potgnn_calc_polarizabilities_async``):
+        enqueues copy-in, evaluation and copy-out and returns; ``out`` ``(S,3,3)`` is valid after
+        ``wait()``.  ``positions_batch`` and ``out`` must be C-contiguous float64 arrays that stay
+        alive and untouched until then (page-locked memory makes the copies asynchronous)."""
+        verify_ndarray_shape("positions_batch", positions_batch, (None, self.num_atoms, 3))
+        s = positions_batch.shape[0]
+        for name, arr, shape in (("positions_batch", positions_batch, positions_batch.shape), ("out", out, (s, 3, 3))):
+            if arr.dtype != np.float64 or not arr.flags.c_contiguous or tuple(arr.shape) != tuple(shape):
+                raise ValueError(f"{name} must be a C-contiguous float64 array of shape {tuple(shape)}")
+        self.eval()
+        handle = self._ensure_handle()
+        rc = _lib.load().rn_potgnn_calc_polarizabilities_async(handle, _ptr(positions_batch), s, _ptr(out))
+        _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities_async")
+
+    def wait(self) -> None:
+        """Block until every ``calc_polarizabilities_async`` call has delivered its result."""
+        if self._handle is not None:
+            rc = _lib.load().rn_potgnn_wait(self._handle)
+            _lib.check(rc, self._handle, "rn_potgnn_wait")
+
     def calc_polarizabilities_device(self, positions: torch.Tensor, out: torch.Tensor | None = None,
                                      synchronize: bool = False) -> torch.Tensor:
         """Same computation on a device-resident ``float64[S,N,3]`` tensor; returns a device

@@ -138,7 +138,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(os.listdir(os.path.join(ROOT, "include"))):  # every header of the C ABI
         header = open(os.path.join(ROOT, "include", name)).read()
         header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-        declared |= set(re.findall(r"\b(rn_(?:potgnn|xdatcar|md)_\w+)\s*\(", header))
+        declared |= set(re.findall(r"\b(rn_(?:potgnn|xdatcar|vasprun|host|md)_\w+)\s*\(", header))
     declared -= {"rn_potgnn_reduce_fn"}  # a function-pointer typedef, not an entry point
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = ctypes.CDLL(_lib.library_path())
