@@ -234,6 +234,14 @@ double rn_potgnn_train_row_count(const rn_potgnn *h);
  */
 int rn_md_raman_intensities(const double *alpha, int64_t S, int device, double *intensities,
                             int64_t num_bins);
+/*
+ * The same reduction for a time series that is already in HBM (the output of
+ * rn_potgnn_forward_device, produced on `stream`): d_alpha is a device float64[S][3][3]; only the
+ * num_bins intensities travel to the host (intensities: host float64[num_bins]).  hipFFT plans and
+ * work buffers are cached per (device, S) by both entry points.
+ */
+int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device, double *intensities,
+                                   int64_t num_bins, void *stream);
 
 /* Introspection: bit 0 = the fused EdgeBlock kernel is in use (float32, Fn and Fe padded to
  * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop; bit 2 = the fused

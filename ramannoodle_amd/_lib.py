@@ -72,6 +72,7 @@ SIGNATURES = {
     "rn_potgnn_last_error": (C.c_char_p, [_P]),
     "rn_potgnn_version": (C.c_char_p, []),
     "rn_md_raman_intensities": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64]),
+    "rn_md_raman_intensities_device": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, _P]),
     # include/rn_ingest.h (host-only trajectory reader)
     "rn_xdatcar_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "rn_xdatcar_close": (None, [_P]),

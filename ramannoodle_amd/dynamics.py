@@ -91,8 +91,23 @@ class Trajectory(Dynamics, Sequence):
     def timestep(self) -> float:
         return self._timestep
 
-    def get_raman_spectrum(self, polarizability_model: PolarizabilityModel) -> MDRamanSpectrum:
+    def get_raman_spectrum(self, polarizability_model: PolarizabilityModel,
+                           on_device: bool = False) -> MDRamanSpectrum:
+        """``dynamics/_trajectory.py:71-90``.  ``on_device=True`` (an addition; needs the device
+        PotGNN): the polarizability time series stays in HBM and the returned
+        ``DeviceMDRamanSpectrum`` reduces it there, so only the intensities reach the host."""
         try:
+            if on_device:
+                import torch
+                from ramannoodle_amd.spectrum import DeviceMDRamanSpectrum
+                evaluate = getattr(polarizability_model, "calc_polarizabilities_device", None)
+                if evaluate is None:
+                    raise TypeError("on_device=True needs a model with calc_polarizabilities_device")
+                verify_ndarray_shape("positions_batch", self._positions_ts,
+                                     (None, polarizability_model.num_atoms, 3))
+                positions = torch.tensor(self._positions_ts, dtype=torch.float64,
+                                         device=f"cuda:{polarizability_model.device_index}")
+                return DeviceMDRamanSpectrum(evaluate(positions), self._timestep)
             polarizability_ts = polarizability_model.calc_polarizabilities(self._positions_ts)
         except ValueError as exc:
             raise ValueError("polarizability_model and trajectory are incompatible") from exc

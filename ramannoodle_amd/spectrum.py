@@ -118,6 +118,29 @@ def _md_intensities_on_device(polarizability_ts: NDArray[np.float64], timestep: 
     return wavenumbers[1:bins + 1], intensities
 
 
+def _md_intensities_device_resident(alpha_device, timestep: float):
+    """The same reduction for a time series that already lives in HBM (a torch CUDA tensor
+    ``float64[S,3,3]``): ``rn_md_raman_intensities_device`` -- only the intensities reach the host."""
+    import ctypes as C
+
+    import torch
+
+    from ramannoodle_amd import _lib
+    n = alpha_device.shape[0] - 1
+    if n < 2:
+        raise ValueError("the device reduction needs at least three time steps")
+    bins = (n + 1) // 2 - 1
+    intensities = np.empty(bins, dtype=np.float64)
+    device = alpha_device.device.index if alpha_device.device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(alpha_device.device).cuda_stream
+    rc = _lib.load().rn_md_raman_intensities_device(C.c_void_p(alpha_device.data_ptr()), alpha_device.shape[0],
+                                                    device, C.c_void_p(intensities.ctypes.data), bins,
+                                                    C.c_void_p(stream))
+    _lib.check(rc, None, "rn_md_raman_intensities_device")
+    wavenumbers = scipy.fftpack.fftfreq(n, timestep) * _PER_FS_TO_CM1
+    return wavenumbers[1:bins + 1], intensities
+
+
 class PhononRamanSpectrum(RamanSpectrum):
     """First-order spectrum from phonon wavenumbers ``(M,)`` and Raman tensors ``(M,3,3)``
     (``spectrum/_raman.py:72-194``)."""
@@ -202,3 +225,44 @@ class MDRamanSpectrum(RamanSpectrum):
         intensities = _apply_corrections(wavenumbers, intensities, laser_correction,
                                          laser_wavelength, bose_einstein_correction, temperature)
         return wavenumbers, intensities
+
+
+class DeviceMDRamanSpectrum(MDRamanSpectrum):
+    """``MDRamanSpectrum`` whose polarizability time series stays where the evaluator wrote it
+    (HBM, a contiguous torch CUDA tensor ``float64[S,3,3]``): ``measure`` reduces it on that GPU
+    and only the intensities travel to the host.  ``polarizability_ts``
+    copies the series to the host on first use, for callers that want the numbers themselves."""
+
+    def __init__(self, polarizability_ts_device, timestep: float):  # pylint: disable=super-init-not-called
+        shape = tuple(polarizability_ts_device.shape)
+        if len(shape) != 3 or shape[1:] != (3, 3):
+            raise ValueError(f"polarizability_ts has wrong shape: {shape} != (_,3,3)")
+        if not (polarizability_ts_device.is_cuda and polarizability_ts_device.is_contiguous()
+                and str(polarizability_ts_device.dtype) == "torch.float64"):
+            raise ValueError("polarizability_ts must be a contiguous float64 CUDA tensor")
+        self._device_ts = polarizability_ts_device
+        self._host_ts = None
+        self._timestep = timestep
+
+    @property
+    def polarizability_ts(self):
+        if self._host_ts is None:
+            self._host_ts = self._device_ts.cpu().numpy()
+        return self._host_ts
+
+    @property
+    def _polarizability_ts(self):  # what the host path of MDRamanSpectrum.measure reads
+        return self.polarizability_ts
+
+    def _measure_on_device(self, device: int):
+        if device != (self._device_ts.device.index or 0):
+            return _md_intensities_on_device(self.polarizability_ts, self._timestep, device)
+        return _md_intensities_device_resident(self._device_ts, self._timestep)
+
+    def measure(self, orientation="polycrystalline", laser_correction=False, laser_wavelength=522,
+                bose_einstein_correction=False, temperature=300, device=None, host=False):
+        """As ``MDRamanSpectrum.measure``; reduces on the tensor's GPU unless ``host=True``."""
+        if device is None and not host:
+            device = self._device_ts.device.index or 0
+        return super().measure(orientation, laser_correction, laser_wavelength, bose_einstein_correction,
+                               temperature, device=None if host else device)

@@ -217,6 +217,88 @@ def test_md_spectrum_on_device_matches_reference_fixture():
     assert np.abs(i_host - g["md/int_raw"]).max() < 1e-9 * np.abs(g["md/int_raw"]).max()
 
 
+def test_md_spectrum_device_resident_and_plan_cache():
+    """SURVEY 8f item 3 as designed: ``Trajectory.get_raman_spectrum(model, on_device=True)`` keeps
+    alpha(t) in HBM and ``measure`` reduces it there (``rn_md_raman_intensities_device``, cached
+    hipFFT plans): same spectrum as the host path from the same alpha(t); more series lengths than
+    the plan cache holds, revisited, still give the right answer."""
+    from ramannoodle_amd.dynamics import Trajectory
+    from ramannoodle_amd.spectrum import DeviceMDRamanSpectrum, MDRamanSpectrum
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g)
+    traj = Trajectory(g["md/positions"], float(g["md/timestep"]))
+    on_host = traj.get_raman_spectrum(model)
+    on_dev = traj.get_raman_spectrum(model, on_device=True)
+    assert isinstance(on_dev, DeviceMDRamanSpectrum) and on_dev._device_ts.is_cuda
+    for kwargs in ({}, {"laser_correction": True, "laser_wavelength": 532, "bose_einstein_correction": True,
+                        "temperature": 250}):
+        w_h, i_h = on_host.measure(**kwargs)
+        w_d, i_d = on_dev.measure(**kwargs)
+        np.testing.assert_array_equal(w_d, w_h)
+        assert np.abs(i_d - i_h).max() < 1e-10 * np.abs(i_h).max()
+        w_x, i_x = on_dev.measure(host=True, **kwargs)  # host reduction of the same device series
+        assert np.abs(i_x - i_h).max() < 1e-12 * np.abs(i_h).max()
+    np.testing.assert_array_equal(on_dev.polarizability_ts, on_host.polarizability_ts)
+    rng = np.random.default_rng(1)
+    series = {}
+    for steps in (50, 51, 64, 100, 257, 1000, 50, 257, 51):  # 6 lengths > 4 cache entries, then revisits
+        if steps not in series:
+            a = rng.normal(size=(steps, 3, 3))
+            series[steps] = a + np.swapaxes(a, 1, 2)
+        a = series[steps]
+        w_h, i_h = MDRamanSpectrum(a, 0.7).measure()
+        w_d, i_d = DeviceMDRamanSpectrum(torch.tensor(a, device="cuda"), 0.7).measure()
+        np.testing.assert_array_equal(w_d, w_h)
+        assert np.abs(i_d - i_h).max() < 1e-10 * np.abs(i_h).max(), steps
+    with pytest.raises(ValueError, match="incompatible"):
+        Trajectory(g["md/positions"][:, :-1], 1.0).get_raman_spectrum(model, on_device=True)
+
+
+def test_streamed_trajectory_files(tmp_path):
+    """SURVEY 8f item 4 end to end on the GPU: XDATCAR and vasprun.xml written from one trajectory,
+    streamed block by block through page-locked buffers and the pipelined entry point
+    (``rn_potgnn_calc_polarizabilities_async``: parse k+2 | copy k+1 | evaluate k) -- same bits as
+    evaluating the parsed trajectory in one call."""
+    from ramannoodle_amd.io.vasp import vasprun, xdatcar
+    g = load_golden("rocksalt64_parity")
+    model = product_model_from_golden(g)
+    rng = np.random.default_rng(4)
+    frames, n = 333, g["positions"].shape[0]
+    pos = g["positions"][None] + rng.normal(scale=4e-3, size=(frames, n, 3))  # some coordinates < 0: wrapped
+    xd = tmp_path / "XDATCAR"
+    with open(xd, "w", encoding="utf-8") as f:
+        lat = g["lattice"]
+        f.write("cell\n 1.0\n" + "".join("  %.10f %.10f %.10f\n" % tuple(r) for r in lat))
+        f.write(" Mg O\n %d %d\n" % (n // 2, n - n // 2))
+        for k in range(frames):
+            f.write(f"Direct configuration= {k + 1}\n" + "".join("  %.12f %.12f %.12f\n" % tuple(r) for r in pos[k]))
+    vr = tmp_path / "vasprun.xml"
+    with open(vr, "w", encoding="utf-8") as f:
+        f.write('<?xml version="1.0"?>\n<modeling>\n <parameters><separator name="ionic"><i name="POTIM"> 1.5</i>'
+                "</separator></parameters>\n")
+        for k in range(frames):
+            f.write(' <structure>\n  <varray name="positions" >\n'
+                    + "".join("   <v> %.12f %.12f %.12f </v>\n" % tuple(r) for r in pos[k]) + "  </varray>\n </structure>\n")
+        f.write("</modeling>\n")
+    parsed = xdatcar.read_positions_ts(xd)
+    np.testing.assert_array_equal(parsed, vasprun.read_positions_ts(vr))
+    want = model.calc_polarizabilities(parsed - parsed // 1)
+    for reader, path in ((xdatcar, xd), (vasprun, vr)):
+        for chunk in (64, 1000):
+            got = reader.stream_polarizabilities(model, path, chunk_frames=chunk)
+            np.testing.assert_array_equal(got, want)
+    traj = vasprun.read_trajectory(vr)
+    assert traj.timestep == 1.5
+    np.testing.assert_array_equal(traj.get_raman_spectrum(model).polarizability_ts, want)
+    # the pipelined entry point on its own, pageable memory, three calls in flight
+    outs = [np.empty((100, 3, 3)) for _ in range(3)]
+    blocks = [np.ascontiguousarray((parsed - parsed // 1)[100 * k:100 * (k + 1)]) for k in range(3)]
+    for b, o in zip(blocks, outs):
+        model.calc_polarizabilities_async(b, o)
+    model.wait()
+    np.testing.assert_array_equal(np.concatenate(outs), want[:300])
+
+
 def test_full_size_properties():
     """Config 2 size (128 atoms, 18 neighbours, perf widths): properties that need no
     oracle -- chunk independence, lattice-translation invariance, symmetric output."""
