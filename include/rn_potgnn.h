@@ -246,7 +246,8 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
 /* Introspection: bit 0 = the fused EdgeBlock kernel is in use (float32, Fn and Fe padded to
  * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop; bit 2 = the fused
  * kernels' matrix products run as split-f16 MFMA (default; RN_POTGNN_MFMA=f32 at create time
- * selects the exact-f32 MFMA). */
+ * selects the exact-f32 MFMA); bit 3 = the narrow-width kernels (one lane per row; Fn, Fe <= 16 in
+ * an instantiated pair, e.g. the documented Fn = 5, Fe = 14) are in use. */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

@@ -142,6 +142,7 @@ struct rn_potgnn {
   bool use_fused = false;
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
+  bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
   bool mfma_f16 = true;  // fused kernels: split-f16 MFMA products (RN_POTGNN_MFMA=f32: exact-f32 MFMA)
   Graph g{};
   DeviceBuf g_ints;
@@ -627,6 +628,13 @@ struct ChunkRun {
     const Graph &g = h->g;
     const Dims d = h->d;
     const int nxt = cur ^ 1;
+    if constexpr (sizeof(T) == 4) {
+      if (narrow()) {  // the whole NodeBlock, projections included, in one launch
+        Timer t(h, st(), K_NODE_AGG);
+        launch_node_narrow(edge[cur], node[cur], node[nxt], S, g, d, w, st());
+        return;
+      }
+    }
     {
       Timer t(h, st(), K_PROJ_NODE);
       launch_rowgemm<T>(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, nullptr, w.c1_bias, false,
@@ -677,7 +685,8 @@ struct ChunkRun {
     {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
-        if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, h->mfma_f16, st());
+        if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, h->g, h->d, w, st());
+        else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
         launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
@@ -692,6 +701,16 @@ struct ChunkRun {
     Precision<T> &P = prec<T>(h);
     const Graph &g = h->g;
     const Dims d = h->d;
+    if constexpr (sizeof(T) == 4) {
+      if (narrow()) {  // readout MLP + edge tensors + per-frame mean in one launch
+        Timer t(h, st(), K_READOUT_MLP);
+        const double *ms = h->d_mean_std.as<double>();
+        launch_readout_narrow(edge[cur], unit4, S, g, d, P.ro, ms, ms + 9, d_vec6, d_alpha, d_alpha_raw,
+                              h->keep_stages ? bufA : nullptr, st());
+        HIP_TRY(hipGetLastError());
+        return;
+      }
+    }
     {
       Timer t(h, st(), K_READOUT_MLP);
       const int HP = std::max(d.FeP, 32);
@@ -718,6 +737,7 @@ struct ChunkRun {
     HIP_TRY(hipGetLastError());
   }
   bool fused() const { return sizeof(T) == 4 && h->use_fused && !prec<T>(h).tape_on; }
+  bool narrow() const { return sizeof(T) == 4 && h->use_narrow && !prec<T>(h).tape_on; }
   T *tape_agg(int p) {  // where the EdgeBlock's pre-LayerNorm sums are recorded (taped runs only)
     Precision<T> &P = prec<T>(h);
     return P.tape_on ? P.tape_agg[p].template as<T>() : nullptr;
@@ -1332,8 +1352,15 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   // fused EdgeBlock (kernels_fused.hip): its LDS footprint bounds the tile instead
   const bool want_fused = getenv("RN_POTGNN_FUSED") ? atoi(getenv("RN_POTGNN_FUSED")) != 0 : true;
   const bool fused_mode = want_fused && d.FnP == 64 && d.FeP == 64;
+  // narrow-width kernels (kernels_narrow.hip): one lane per destination edge, so a tile should bring
+  // about one workgroup's worth (256) of destination edges and keep its LDS rows within ~40 KiB
+  const bool want_narrow = getenv("RN_POTGNN_NARROW") ? atoi(getenv("RN_POTGNN_NARROW")) != 0 : true;
+  const bool narrow_mode = want_narrow && narrow_supported(d);
   int max_rows = 0;
-  if (getenv("RN_POTGNN_TILE_KB") || vpl8) {
+  if (narrow_mode && !getenv("RN_POTGNN_TILE_KB")) {
+    const size_t per_row = edge_narrow_lds_bytes(d.Fe, 1024, 1024) / 1024 + 1;
+    max_rows = build_tiles(std::max<size_t>(1, std::min<size_t>(256, (size_t)40 * 1024 / per_row)), h->tile_begin);
+  } else if (getenv("RN_POTGNN_TILE_KB") || vpl8) {
     const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB")) : 64;
     max_rows = build_tiles(std::max<size_t>(1, tile_kb * 1024 / row_bytes), h->tile_begin);
   } else {
@@ -1434,18 +1461,20 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // The fused kernels (kernels_fused.hip) are the default where they apply (float32, Fn and
     // Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
+    hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
+                                                          hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
     // Chunk size and lanes.  Throughput rises monotonically with the frames per launch
     // (profiles/r01_chunk_sweep.txt, profiles/r01/overlap_experiments.txt section 7) and the
     // Infinity Cache does not reward small chunks.  The fused kernels take a whole CU each, so a
     // second lane has nothing to overlap with: ONE lane with an 8 GiB workspace (of 288 GB HBM)
     // beats two lanes of 1.5 GiB (63.7 k vs 62.1 k structures/s at 4000 frames).  The unfused
     // pipeline keeps two alternating lanes of 1.5 GiB.
-    if (!getenv("RN_POTGNN_LANES")) hp->num_lanes = hp->use_fused ? 1 : 2;
+    if (!getenv("RN_POTGNN_LANES")) hp->num_lanes = (hp->use_fused || hp->use_narrow) ? 1 : 2;
     int chunk = cfg->max_chunk_structures;
     if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
     if (chunk <= 0) {
       const size_t per = per_structure_elems(hp) * sizeof(float);
-      size_t budget = hp->use_fused ? ((size_t)8192 << 20) : ((size_t)1536 << 20);
+      size_t budget = (hp->use_fused || hp->use_narrow) ? ((size_t)8192 << 20) : ((size_t)1536 << 20);
       size_t free_b = 0, total_b = 0;  // on a shared GPU: at most 1/8 of what is free right now
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
         budget = std::min(budget, std::max<size_t>(free_b / 8 / (size_t)hp->num_lanes, (size_t)64 << 20));
@@ -1774,9 +1803,9 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
-  int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0);
+  int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0);
   bool fast = !h->f32.pass.empty();
-  for (const auto &p : h->f32.pass) fast = fast && (p.c3_fast & (h->use_fused ? 1 : 2));
+  for (const auto &p : h->f32.pass) fast = fast && (p.c3_fast & ((h->use_fused || h->use_narrow) ? 1 : 2));
   return flags | (fast ? 2 : 0);
 }
 

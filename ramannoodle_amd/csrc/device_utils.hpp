@@ -189,14 +189,14 @@ __device__ __forceinline__ Vec4<T> ln_row(const Vec4<T> &x, const LnParams<T> &p
 // The f32-input MFMA runs at the vector rate (1/16 of the f16/bf16 rate) and blocks the SIMD's
 // VALU issue while it does.  A two-way f16 split  x = hi + lo  (hi = f16(x), lo = f16(x - hi):
 // 22 significant bits, absolute error <= 2^-25 below the f16 normal range) and the three products
-// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_16x16x32_f16 (f16 products are exact in f32,
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the f16 MFMA (f16 products are exact in f32,
 // accumulation in f32) reproduce the f32 product to ~3e-7 * sum|a||b| -- the size of f32's own
 // rounding in a K = 64 dot product -- in 3/16 of the matrix-pipe time, and leave the VALU free.
 // Operand values here are tanh outputs / normalised rows and O(1) weights: far inside f16 range.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// 8 consecutive k of one operand row -> (hi, lo) fragments of v_mfma_f32_16x16x32_f16
+// 8 consecutive k of one operand row -> (hi, lo) fragments of one K = 32 slice
 __device__ __forceinline__ void split_f16x8(const float *x, f16x8 &hi, f16x8 &lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -204,12 +204,26 @@ __device__ __forceinline__ void split_f16x8(const float *x, f16x8 &hi, f16x8 &lo
     lo[j] = (_Float16)(x[j] - (float)hi[j]);
   }
 }
-// acc += A * B for one 16x16x32 step, smallest terms first
+// acc += A * B over one K = 32 slice (8 k per lane), smallest terms first.
+// Each product is issued as TWO v_mfma_f32_16x16x16_f16 (the halves of the 8-element fragments; A
+// and B use the same lane-local element order, so the k pairing is consistent), not as one
+// v_mfma_f32_16x16x32_f16: with the K = 32 instruction (new on gfx950) the fused EdgeBlock was not
+// reproducible under hipcc / ROCm 7.2 -- repeated evaluations of one trajectory differed in 0.03-3 %
+// of the frames (one destination row slightly off), whatever staged the operands (LDS-DMA or
+// registers) and whichever conversion instructions built the fragments; with the K = 16 instruction
+// 60 000 frames repeat bit for bit (profiles/r02/determinism.txt).  The matrix pipe is a few percent
+// of these kernels' time either way.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_t mfma_split3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh,
                                                const f16x8 &bl, f32x4_t acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  const f16x4 ah0 = ah.lo, ah1 = ah.hi, al0 = al.lo, al1 = al.hi;
+  const f16x4 bh0 = bh.lo, bh1 = bh.hi, bl0 = bl.lo, bl1 = bl.hi;
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al0, bh0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al1, bh1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah0, bl0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah1, bl1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah0, bh0, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah1, bh1, acc, 0, 0, 0);
 }
 
 }  // namespace rn

@@ -181,4 +181,15 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
                        int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
 
+// Narrow-width kernels (kernels_narrow.hip): one lane per row, compile-time (Fn, Fe) <= 16, float32.
+bool narrow_supported(Dims d);
+size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows);
+void launch_node_narrow(const float *edge, const float *node_in, float *node_out, int S, const Graph &g, Dims d,
+                        const PassW<float> &w, hipStream_t st);
+void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node, int S, const Graph &g, Dims d,
+                        const PassW<float> &w, hipStream_t st);
+void launch_readout_narrow(const float *edge, const float *unit4, int S, const Graph &g, Dims d,
+                           const ReadoutW<float> &w, const double *mean9, const double *std9, float *vec6,
+                           double *alpha, double *alpha_raw, float *pol /* optional [S*E,32] */, hipStream_t st);
+
 }  // namespace rn

@@ -6,7 +6,7 @@
 //   P'_d = W4 edge_d + Wj node[b_d] + Wk node[a_d] + bias  edges d entering them
 //   c2_d = c2_linear(node[b_d] * node[a_d])
 // by MFMA (W4 and the c2 weight stay in VGPRs as B-fragments for the whole kernel, W5 is re-read
-// from L2 once per frame) -- by default as three split-f16 products on v_mfma_f32_16x16x32_f16
+// from L2 once per frame) -- by default as three split-f16 products on v_mfma_f32_16x16x16_f16
 // (device_utils.hpp: f32-grade accuracy at 3/16 of the f32 matrix-pipe time, and the f16 pipe
 // does not block the VALU as the f32-input MFMA does), or exact-fp32 v_mfma_f32_16x16x4_f32
 // (RN_POTGNN_MFMA=f32) -- then the
@@ -115,7 +115,7 @@ struct WaveB<false> {  // exact f32: v_mfma_f32_16x16x4_f32, k = 16 quad + step
   }
 };
 template <>
-struct WaveB<true> {  // split f16: v_mfma_f32_16x16x32_f16, step s covers k = 16 quad + 8 s + j
+struct WaveB<true> {  // split f16 (device_utils.hpp: mfma_split3), K = 32 slice s covers k = 16 quad + 8 s + j
   f16x8 h[2][2], l[2][2];
   __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad) {
 #pragma unroll

@@ -409,6 +409,21 @@ def test_fused_edge_block_equals_unfused(monkeypatch):
     np.testing.assert_array_equal(seq, unfused)
 
 
+def test_repeated_evaluation_is_bit_identical():
+    """No kernel uses atomics: evaluating the same frames again must give the same bits, whichever
+    workgroup a frame lands in.  (The first split-f16 build of round 2 -- on the K = 32 f16 MFMA --
+    failed this in ~0.5 % of the frames; profiles/r02/determinism.txt.)  Perf and parity widths."""
+    from bench import make_workload
+    for hparams, frames in (("perf", 3000), ("parity", 3000)):
+        wl = make_workload(num_cells=(4, 4, 2), frames=frames, hparams=hparams, seed=33)
+        model = wl["model"]()
+        first = model.calc_polarizabilities(wl["positions"])
+        for _ in range(2):
+            np.testing.assert_array_equal(model.calc_polarizabilities(wl["positions"]), first)
+        half = model.calc_polarizabilities(wl["positions"][frames // 2:])
+        np.testing.assert_array_equal(half, first[frames // 2:])
+
+
 def test_split_f16_mfma_matches_exact_f32_mfma(monkeypatch):
     """The fused kernels' matrix products run as three split-f16 MFMAs (hi/lo operands, f32
     accumulation) by default; RN_POTGNN_MFMA=f32 selects the exact-f32 MFMA.  Both must agree with
