@@ -166,7 +166,7 @@ def committed_profile(name, n, e, fn, fe):
     return None
 
 
-def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused):
+def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow=False):
     """The other scatter-aggregate of a pass: B_NB = 4 (E Fe + 2 N Fn) algorithmic bytes per
     structure and pass over the HIP-event time of the NodeBlock kernel."""
     ms, launches = times.get("node_agg", (0.0, 0))
@@ -175,10 +175,13 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused):
     per = 4 * (e * fe + 2 * n * fn)
     achieved = per * frames * passes * steps / (ms * 1e-3) / 1e9
     traffic = None
-    rec = committed_profile("node_fused_traffic.json", n, e, fn, fe) if fused else None
+    rec = committed_profile("node_narrow_traffic.json" if narrow else "node_fused_traffic.json", n, e, fn, fe) \
+        if (fused or narrow) else None
     if rec:
         traffic = rec["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
-    return {"kernel": "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
+    return {"kernel": "node_narrow_kernel (NodeBlock scatter-aggregate, projections included: one lane per atom "
+                      "gathers its in-edge rows)" if narrow
+            else "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
             else "node_agg_kernel (NodeBlock scatter-aggregate; its c1 projection is a separate launch)",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": traffic, "launches": launches, "avg_launch_ms": ms / launches,
@@ -379,16 +382,21 @@ def main():
 
     if rank == 0:
         agg_ms, agg_launches = times.get("edge_agg", (0.0, 0))
-        fused = bool(model.config_flags()["fused_edge_block"])
+        flags = model.config_flags()
+        fused, narrow = bool(flags["fused_edge_block"]), bool(flags["narrow_kernels"])
         per_pass = algorithmic_bytes_edge_block(n, e, fn, fe)
         total_bytes = per_pass * mine * passes * args.steps
         achieved = total_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         peak = 8000.0
-        traffic_rec = committed_profile("edge_fused_traffic.json" if fused else "edge_agg_traffic.json", n, e, fn, fe)
-        issue_rec = committed_profile("edge_fused_issue.json", n, e, fn, fe) if fused else None
+        traffic_rec = committed_profile("edge_narrow_traffic.json" if narrow else "edge_fused_traffic.json" if fused
+                                        else "edge_agg_traffic.json", n, e, fn, fe)
+        issue_rec = committed_profile("edge_narrow_issue.json" if narrow else "edge_fused_issue.json", n, e, fn, fe) \
+            if (fused or narrow) else None
         frames_per_launch = mine * passes * args.steps / agg_launches if agg_launches else None
         roofline = {
-            "kernel": ("edge_block_fused_kernel (EdgeBlock: MFMA projections + triplet scatter-aggregate)"
+            "kernel": ("edge_narrow_kernel (EdgeBlock: projections + triplet scatter-aggregate, one lane per "
+                       "destination edge)" if narrow
+                       else "edge_block_fused_kernel (EdgeBlock: MFMA projections + triplet scatter-aggregate)"
                        if fused else "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)"),
             "bound": "hbm",
             "achieved": achieved,
@@ -405,12 +413,15 @@ def main():
             # counter pass of this kernel on this workload; mfma_frac = its fp32 MFMA FLOP/s, measured
             # live, over the 157.3 TFLOP/s fp32 peak.
             "issue_frac": issue_rec["valu_plus_mfma_busy"] if issue_rec else None,
+            # matrix work of the kernel (three [E,64]x[64,128] products per pass, as 3 split-f16 products
+            # each on the f16 MFMA) in fp32-equivalent FLOP/s over the 157.3 TFLOP/s fp32 peak
             "mfma_frac": (edge_block_mfma_flops(e, fn, fe) * mine * passes * args.steps / (agg_ms * 1e-3) / 157.3e12
-                          if fused and agg_ms > 0 else None),
+                          if fused and not narrow and agg_ms > 0 else None),
             "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): ~17 VALU instructions "
-                    "incl. 3 transcendentals per (triplet, feature pair), and fp32 MFMA shares the "
-                    "issue port; achieved/peak/frac are the HBM figures the metric asks for, "
-                    "issue_frac / mfma_frac say what actually bounds the kernel",
+                    "incl. 3 transcendentals per (triplet, feature pair); achieved/peak/frac are the HBM "
+                    "figures the metric asks for, issue_frac (VALU-busy + MFMA-busy share of SIMD cycles, "
+                    "from the committed SQ counter pass) says what actually bounds the kernel; "
+                    "roofline_nodeblock is the pass's other scatter-aggregate, the one that streams",
         }
         result = {
             "metric": "structures/sec (GNN polarizability eval)",
@@ -439,7 +450,7 @@ def main():
                                 if world > 1 else "single GPU"),
             },
             "roofline": roofline,
-            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused),
+            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused, narrow),
             "roofline_projection": projection_roofline(times, e, fn, fe, mine, passes, args.steps),
             "host_buffers_structures_per_s": host_rate,
         }

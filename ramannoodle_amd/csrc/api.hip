@@ -84,6 +84,7 @@ struct PackedLayout {
     size_t c1_WnT, c1_WeT, c1_bias, c1n_g, c1n_b, fin_g, fin_b;
     size_t c2_WT, c2_bias, c2n1_g, c2n1_b, c2n2_g, c2n2_b;
     size_t c3_WnT, c3_nshift, c3_WeT, c3n1_g, c3n1_b, c3n2_g, c3n2_b;
+    size_t c3n1_gs, c3n1_bs;  // c3_norm_1 with the gate's exp2 scale folded in (-log2e | 2 log2e): narrow kernels
     size_t t_c3We, t_c3Wn, t_c2W, t_c1We, t_c1Wn;  // transposed copies [N][K] (reverse pass)
   };
   std::vector<Pass> pass;
@@ -229,6 +230,8 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3n1_b = L.take(2 * FeP);
     p.c3n2_g = L.take(FeP);
     p.c3n2_b = L.take(FeP);
+    p.c3n1_gs = L.take(2 * FeP);
+    p.c3n1_bs = L.take(2 * FeP);
     p.t_c3We = L.take((size_t)4 * FeP * FeP);
     p.t_c3Wn = L.take((size_t)6 * FeP * FnP);
     p.t_c2W = L.take((size_t)2 * FeP * FnP);
@@ -325,6 +328,12 @@ void pack_weights(rn_potgnn *h, const float *w) {
     copy(q.c2n2_b, Fe);
     copy(q.c3n2_g, Fe);
     copy(q.c3n2_b, Fe);
+    for (int k = 0; k < FeP; ++k) {  // sigmoid(f) tanh(c) through exp2: exp2(-log2e f), exp2(2 log2e c)
+      o[q.c3n1_gs + k] = -1.4426950408889634f * o[q.c3n1_g + k];
+      o[q.c3n1_bs + k] = -1.4426950408889634f * o[q.c3n1_b + k];
+      o[q.c3n1_gs + FeP + k] = 2.0f * 1.4426950408889634f * o[q.c3n1_g + FeP + k];
+      o[q.c3n1_bs + FeP + k] = 2.0f * 1.4426950408889634f * o[q.c3n1_b + FeP + k];
+    }
   }
   {  // readout
     const float *W0 = c;
@@ -474,6 +483,7 @@ void ensure_precision(rn_potgnn *h) {
     o.c3_WeT = w + q.c3_WeT;
     o.c3_norm_1 = {w + q.c3n1_g, w + q.c3n1_b};
     o.c3_norm_2 = {w + q.c3n2_g, w + q.c3n2_b};
+    o.c3_norm_1s = {w + q.c3n1_gs, w + q.c3n1_bs};
   }
   refresh_pass_flags<T>(h);
   P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5};
@@ -1805,7 +1815,7 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0);
   bool fast = !h->f32.pass.empty();
-  for (const auto &p : h->f32.pass) fast = fast && (p.c3_fast & ((h->use_fused || h->use_narrow) ? 1 : 2));
+  for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);
 }
 

@@ -50,6 +50,7 @@ struct PassW {
   const T *c3_WeT;   // [FeP][4FeP]   (W_4 | W_5) edge parts: dest-edge | source-edge
   Ln<T> c3_norm_1;   // [2FeP]
   Ln<T> c3_norm_2;   // [FeP]
+  Ln<T> c3_norm_1s;  // [2FeP] c3_norm_1 times the gate's exp2 scales (-log2e on the filter half, 2 log2e on the core half)
   int c3_fast;       // host-side decision: c3_norm_1 admits the folded-scale triplet loop
                      // (bit 0: in the fused EdgeBlock kernel, bit 1: in edge_agg_kernel)
 };

@@ -63,6 +63,20 @@ __device__ __forceinline__ constexpr int gcol(int c) {
   return c < F ? c : HP + (c - F);
 }
 
+// acc[c] += sum_k W[k * LD + OFF + gcol(c)] * x[k] for the 2F gated columns of a padded [filter|core]
+// weight block.  k is the OUTER loop: the 2F weights of one k are two contiguous runs in memory, i.e.
+// one or two s_load batches that are consumed at once -- with the column loop outside, the compiler
+// loaded every weight up front and spilled hundreds of SGPRs to VGPR lanes (v_writelane/v_readlane).
+template <int K, int F, int HP, int LD, int OFF>
+__device__ __forceinline__ void gated_matvec(cptr W, const float (&x)[K], float (&acc)[2 * F]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int c = 0; c < 2 * F; ++c) acc[c] = fmaf(W[k * LD + OFF + gcol<F, HP>(c)], x[k], acc[c]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // LayerNorm(2F) -> sigmoid * tanh over a row held by one lane (torch semantics: biased variance,
 // eps 1e-5); g/b are the padded [filter|core] parameter arrays (wave-uniform -> SGPRs).
 template <int F, int HP>
@@ -129,12 +143,8 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
   // node part of c1 (+ bias): the same for every edge entering b
   float base[2 * FN];
 #pragma unroll
-  for (int c = 0; c < 2 * FN; ++c) {
-    float v = bias[gcol<FN, FnP>(c)];
-#pragma unroll
-    for (int k = 0; k < FN; ++k) v = fmaf(WnT[k * 2 * FnP + gcol<FN, FnP>(c)], nb[k], v);
-    base[c] = v;
-  }
+  for (int c = 0; c < 2 * FN; ++c) base[c] = bias[gcol<FN, FnP>(c)];
+  gated_matvec<FN, FN, FnP, 2 * FnP, 0>(WnT, nb, base);
   float acc[FN];
 #pragma unroll
   for (int k = 0; k < FN; ++k) acc[k] = 0.f;
@@ -145,12 +155,8 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
     load_row<FE>(erow0 + (int64_t)a.g.in_edge[idx] * FeP, x);
     float c1[2 * FN];
 #pragma unroll
-    for (int c = 0; c < 2 * FN; ++c) {
-      float v = base[c];
-#pragma unroll
-      for (int k = 0; k < FE; ++k) v = fmaf(WeT[k * 2 * FnP + gcol<FN, FnP>(c)], x[k], v);
-      c1[c] = v;
-    }
+    for (int c = 0; c < 2 * FN; ++c) c1[c] = base[c];
+    gated_matvec<FE, FN, FnP, 2 * FnP, 0>(WeT, x, c1);
     float gt[FN];
     ln_gate_row<FN, FnP>(c1, c1g, c1b, gt);
 #pragma unroll
@@ -174,7 +180,8 @@ struct EdgeNarrowArgs {
   // c3_nshift [6FeP] = (0 | bias | 0), c2_WT [FnP][2FeP]
   const float *__restrict__ c3WeT, *__restrict__ c3WnT, *__restrict__ c3shift, *__restrict__ c2WT,
       *__restrict__ c2bias;
-  const float *__restrict__ c3n1g, *__restrict__ c3n1b, *__restrict__ c3n2g, *__restrict__ c3n2b;
+  const float *__restrict__ c3n1gs, *__restrict__ c3n1bs;  // c3_norm_1 with the gate's exp2 scales folded in
+  const float *__restrict__ c3n2g, *__restrict__ c3n2b;
   const float *__restrict__ c2n1g, *__restrict__ c2n1b, *__restrict__ c2n2g, *__restrict__ c2n2b;
 };
 
@@ -199,8 +206,8 @@ template <int FN, int FE, bool FASTG>
 __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
   constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE), W2 = 2 * FE;
   const cptr c3WeT = as_const(a.c3WeT), c3WnT = as_const(a.c3WnT), c3shift = as_const(a.c3shift),
-             c2WT = as_const(a.c2WT), c2bias = as_const(a.c2bias), c3n1g = as_const(a.c3n1g),
-             c3n1b = as_const(a.c3n1b), c3n2g = as_const(a.c3n2g), c3n2b = as_const(a.c3n2b),
+             c2WT = as_const(a.c2WT), c2bias = as_const(a.c2bias), c3n1gs = as_const(a.c3n1gs),
+             c3n1bs = as_const(a.c3n1bs), c3n2g = as_const(a.c3n2g), c3n2b = as_const(a.c3n2b),
              c2n1g = as_const(a.c2n1g), c2n1b = as_const(a.c2n1b), c2n2g = as_const(a.c2n2g),
              c2n2b = as_const(a.c2n2b);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -238,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
   __syncthreads();
 
   // c3_norm_1 with the exp2 scale of the gate folded in (wave-uniform values: SGPRs)
-  auto g3 = [&](int c) { return c3n1g[gcol<FE, FeP>(c)] * (c < FE ? -kLog2e : 2.0f * kLog2e); };
-  auto b3 = [&](int c) { return c3n1b[gcol<FE, FeP>(c)] * (c < FE ? -kLog2e : 2.0f * kLog2e); };
+  auto g3 = [&](int c) { return c3n1gs[gcol<FE, FeP>(c)]; };
+  auto b3 = [&](int c) { return c3n1bs[gcol<FE, FeP>(c)]; };
   constexpr float inv2n = 1.0f / W2;
 
   for (int s = sg; s < a.S; s += nsg) {
@@ -251,15 +258,11 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
       load_row<FN>(a.node + (nrow0 + qb[r]) * FnP, nb);
       float q[W2], sum = 0.f;
 #pragma unroll
-      for (int c = 0; c < W2; ++c) {
-        float v = 0.f;
+      for (int c = 0; c < W2; ++c) q[c] = 0.f;
+      gated_matvec<FE, FE, FeP, 4 * FeP, 2 * FeP>(c3WeT, x, q);
+      gated_matvec<FN, FE, FeP, 6 * FeP, 0>(c3WnT, nb, q);
 #pragma unroll
-        for (int k = 0; k < FE; ++k) v = fmaf(c3WeT[k * 4 * FeP + 2 * FeP + gcol<FE, FeP>(c)], x[k], v);
-#pragma unroll
-        for (int k = 0; k < FN; ++k) v = fmaf(c3WnT[k * 6 * FeP + gcol<FE, FeP>(c)], nb[k], v);
-        q[c] = v;
-        sum += v;
-      }
+      for (int c = 0; c < W2; ++c) sum += q[c];
       const float mean = sum * inv2n;
       float ss = 0.f;
 #pragma unroll
@@ -296,18 +299,12 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
         load_row<FN>(njrow, nj);
         load_row<FN>(nkrow, nk);
 #pragma unroll
-        for (int c = 0; c < W2; ++c) {
-          float v = c3shift[2 * FeP + gcol<FE, FeP>(c)];
+        for (int c = 0; c < W2; ++c) p[c] = c3shift[2 * FeP + gcol<FE, FeP>(c)];
+        gated_matvec<FE, FE, FeP, 4 * FeP, 0>(c3WeT, x, p);
+        gated_matvec<FN, FE, FeP, 6 * FeP, 2 * FeP>(c3WnT, nj, p);
+        gated_matvec<FN, FE, FeP, 6 * FeP, 4 * FeP>(c3WnT, nk, p);
 #pragma unroll
-          for (int k = 0; k < FE; ++k) v = fmaf(c3WeT[k * 4 * FeP + gcol<FE, FeP>(c)], x[k], v);
-#pragma unroll
-          for (int k = 0; k < FN; ++k) {
-            v = fmaf(c3WnT[k * 6 * FeP + 2 * FeP + gcol<FE, FeP>(c)], nj[k], v);
-            v = fmaf(c3WnT[k * 6 * FeP + 4 * FeP + gcol<FE, FeP>(c)], nk[k], v);
-          }
-          p[c] = v;
-          sum += v;
-        }
+        for (int c = 0; c < W2; ++c) sum += p[c];
       }
       const float mean = sum * inv2n;
       float sp = 0.f;
@@ -396,14 +393,12 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
       load_row<FN>(njrow, nj);
       load_row<FN>(nkrow, nk);
       load_row<FE>(xrow, x);
-      float c2pre[W2];
+      float c2pre[W2], z[FN];
 #pragma unroll
-      for (int c = 0; c < W2; ++c) {
-        float v = c2bias[gcol<FE, FeP>(c)];
+      for (int k = 0; k < FN; ++k) z[k] = nj[k] * nk[k];
 #pragma unroll
-        for (int k = 0; k < FN; ++k) v = fmaf(c2WT[k * 2 * FeP + gcol<FE, FeP>(c)], nj[k] * nk[k], v);
-        c2pre[c] = v;
-      }
+      for (int c = 0; c < W2; ++c) c2pre[c] = c2bias[gcol<FE, FeP>(c)];
+      gated_matvec<FN, FE, FeP, 2 * FeP, 0>(c2WT, z, c2pre);
       float g2[FE], c2[FE], out[FE];
       ln_gate_row<FE, FeP>(c2pre, c2n1g, c2n1b, g2);
       ln_row1<FE>(g2, c2n2g, c2n2b, c2);
@@ -554,14 +549,15 @@ void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node
                         const PassW<float> &w, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
   EdgeNarrowArgs a{edge_in, edge_out, node, S, g, w.c3_WeT, w.c3_WnT, w.c3_nshift, w.c2_WT, w.c2_bias,
-                   w.c3_norm_1.g, w.c3_norm_1.b, w.c3_norm_2.g, w.c3_norm_2.b,
+                   w.c3_norm_1s.g, w.c3_norm_1s.b, w.c3_norm_2.g, w.c3_norm_2.b,
                    w.c2_norm_1.g, w.c2_norm_1.b, w.c2_norm_2.g, w.c2_norm_2.b};
   const size_t lds = edge_narrow_lds_bytes(d.Fe, g.max_tile_out_rows, g.max_tile_in_rows);
-  const bool fast = (w.c3_fast & 1) != 0;
+  // The folded-scale triplet loop (FASTG, kernels_fused.hip) keeps 2 Fe more values per lane alive;
+  // here that costs a wave per SIMD (132 vs 100 VGPRs at Fe = 14) and measured 5 % slower than the
+  // general loop (4.23 vs 4.03 us per 256-atom structure), so the general loop is always used.
 #define X(FN, FE)                                        \
   if (d.Fn == FN && d.Fe == FE) {                        \
-    if (fast) launch_edge_cfg<FN, FE, true>(a, lds, st); \
-    else launch_edge_cfg<FN, FE, false>(a, lds, st);     \
+    launch_edge_cfg<FN, FE, false>(a, lds, st);          \
     return;                                              \
   }
   RN_NARROW_PAIRS(X)
