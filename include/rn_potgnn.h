@@ -205,6 +205,16 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
 int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads);
 
 /*
+ * The same step evaluated in float64 on the device (every kernel of the forward and of the
+ * reverse pass has a double instantiation): what the float32 gradients are validated against,
+ * next to float64 autograd through the oracle.  vec6 / batch_mean / batch_var / dvec6 / grads
+ * are host float64 arrays with the layouts of the float32 entry points.
+ */
+int rn_potgnn_train_forward_f64(rn_potgnn *h, const double *positions, int64_t S, double *vec6,
+                                double *batch_mean, double *batch_var);
+int rn_potgnn_train_backward_f64(rn_potgnn *h, const double *dvec6, double *grads);
+
+/*
  * Data-parallel training (gradient all-reduce plus all-reduced BatchNorm batch
  * statistics for single-device parity).  With a reducer installed, rn_potgnn_train_forward /
  * _backward hand it the float64 column sums of the readout BatchNorm (forward: sum z, sum z^2

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rn_potgnn_set_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "rn_potgnn_train_forward": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     "rn_potgnn_train_backward": (C.c_int, [_P, _P, _P]),
+    "rn_potgnn_train_forward_f64": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
+    "rn_potgnn_train_backward_f64": (C.c_int, [_P, _P, _P]),
     "rn_potgnn_num_triplets": (C.c_int64, [_P]),
     "rn_potgnn_debug_triplets": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "rn_potgnn_debug_stage": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t,

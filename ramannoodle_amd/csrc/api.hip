@@ -165,6 +165,7 @@ struct rn_potgnn {
   int next_slot = 0;
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
+  int train_prec = 4;  // sizeof of the precision it ran in
   double bn_count = 0;  // rows the pending step's BatchNorm statistics cover (all ranks)
   rn_potgnn_reduce_fn reducer = nullptr;  // data-parallel training: sums doubles over ranks
   void *reducer_ctx = nullptr;
@@ -1049,12 +1050,12 @@ void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*
   (void)P;
 }
 
-// ---- training (float32): forward with batch-statistics BatchNorm, then parameter gradients
-void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, float *batch_mean,
-                   float *batch_var) {
-  typedef float T;
+// ---- training: forward with batch-statistics BatchNorm, then parameter gradients (float32 for
+// the product path; float64 for validating the reverse pass against float64 autograd)
+template <typename T>
+void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batch_mean, T *batch_var) {
   ensure_precision<T>(h);
-  Precision<T> &P = h->f32;
+  Precision<T> &P = prec<T>(h);
   const PackedLayout &L = h->lay;
   const Graph &g = h->g;
   const Dims d = h->d;
@@ -1065,19 +1066,19 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, flo
   ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), S);
   hipStream_t st = c.st();
   const int64_t R = (int64_t)S * g.E;
-  T *Wd = P.weights.as<T>();
+  T *Wd = P.weights.template as<T>();
   P.tape_z1.ensure((size_t)R * HP * sizeof(T));
   P.bn_stats.ensure(sizeof(double) * 6 * HP);  // forward sums (+ row count during the reduction) | backward sums | own copy
   DeviceBuf &mv = P.mv;
   mv.ensure(sizeof(T) * 2 * HP);
-  const T *edgeP = P.tape_edge[h->cfg.num_message_passes].as<T>();
+  const T *edgeP = P.tape_edge[h->cfg.num_message_passes].template as<T>();
   // z1 = edge W0^T + b0 ; h1 = ssp(BN_batch(z1)) ; then the rest of the readout as in eval
-  launch_rowgemm<T>(edgeP, R, d.FeP, P.ro.W0T, HP, P.tape_z1.as<T>(), nullptr, Wd + L.b0p, false, 0,
+  launch_rowgemm<T>(edgeP, R, d.FeP, P.ro.W0T, HP, P.tape_z1.template as<T>(), nullptr, Wd + L.b0p, false, 0,
                     nullptr, g, st);
   {
     // batch statistics over every row of the batch -- of all ranks in a data-parallel run
-    double *stats = P.bn_stats.as<double>();
-    launch_bn_col_sums<T>(P.tape_z1.as<T>(), R, HP, stats, st);
+    double *stats = P.bn_stats.template as<double>();
+    launch_bn_col_sums<T>(P.tape_z1.template as<T>(), R, HP, stats, st);
     h->bn_count = (double)R;
     if (h->reducer) {
       const double rows = (double)R;  // slot 2HP is outside the range col_sums clears
@@ -1085,17 +1086,27 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, flo
       reduce_over_ranks(h, stats, (size_t)2 * HP + 1, st);  // [sum z | sum z^2 | rows]
       HIP_TRY(hipMemcpy(&h->bn_count, stats + 2 * HP, sizeof(double), hipMemcpyDeviceToHost));
     }
-    launch_bn_train_apply<T>(P.tape_z1.as<T>(), R, HP, d.Fe, stats, h->bn_count, Wd + L.bn_w, Wd + L.bn_b,
-                             c.bufA, mv.as<T>(), st);
+    launch_bn_train_apply<T>(P.tape_z1.template as<T>(), R, HP, d.Fe, stats, h->bn_count, Wd + L.bn_w, Wd + L.bn_b,
+                             c.bufA, mv.template as<T>(), st);
   }
   launch_rowgemm<T>(c.bufA, R, HP, P.ro.W3T, HP, c.bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
   launch_rowgemm<T>(c.bufB, R, HP, P.ro.W5T, 32, c.bufA, nullptr, P.ro.b5, false, 0, nullptr, g, st);
   h->io_vec6.ensure((size_t)S * 6 * sizeof(float));
+  h->io_alpha.ensure((size_t)S * 9 * sizeof(double));
   const double *ms = h->d_mean_std.as<double>();
-  launch_readout_reduce<T>(c.bufA, c.unit4, S, g, ms, ms + 9, h->io_vec6.as<float>(), nullptr, nullptr, st);
+  launch_readout_reduce<T>(c.bufA, c.unit4, S, g, ms, ms + 9, h->io_vec6.as<float>(), nullptr,
+                           h->io_alpha.as<double>() /* standardised 3x3 in double */, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  if constexpr (sizeof(T) == 4) {
+    HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  } else {  // (xx,yy,zz,xy,xz,yz) of the standardised tensor, at full precision
+    std::vector<double> raw((size_t)S * 9);
+    HIP_TRY(hipMemcpy(raw.data(), h->io_alpha.p, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int pick[6] = {0, 4, 8, 1, 2, 5};
+    for (int s = 0; s < S; ++s)
+      for (int k = 0; k < 6; ++k) vec6[(size_t)s * 6 + k] = (T)raw[(size_t)s * 9 + pick[k]];
+  }
   std::vector<T> mvh(2 * HP);
   HIP_TRY(hipMemcpy(mvh.data(), mv.p, sizeof(T) * 2 * HP, hipMemcpyDeviceToHost));
   for (int k = 0; k < d.Fe; ++k) {
@@ -1103,15 +1114,18 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, float *vec6, flo
     batch_var[k] = mvh[HP + k];
   }
   h->train_S = S;
+  h->train_prec = (int)sizeof(T);
 }
 
-void unpack_grads(const rn_potgnn *h, const float *gp, float *out);
+template <typename T>
+void unpack_grads(const rn_potgnn *h, const T *gp, T *out);
 
-void train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
-  typedef float T;
-  Precision<T> &P = h->f32;
+template <typename T>
+void train_backward(rn_potgnn *h, const T *dvec6, T *grads) {
+  Precision<T> &P = prec<T>(h);
   const int S = h->train_S;
-  if (S <= 0) throw HipError{hipErrorInvalidValue, "train_backward without train_forward"};
+  if (S <= 0 || h->train_prec != (int)sizeof(T))
+    throw HipError{hipErrorInvalidValue, "train_backward without a train_forward of the same precision"};
   ChunkRun<T> c(h, P.lanes[0], h->io_pos.as<double>(), S, nullptr, nullptr, nullptr);
   hipStream_t st = c.st();
   DeviceBuf &seeds = P.seeds;
@@ -1119,28 +1133,29 @@ void train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
   HIP_TRY(hipMemcpy(seeds.p, dvec6, (size_t)S * 6 * sizeof(T), hipMemcpyHostToDevice));
   P.grad.ensure(h->lay.total * sizeof(T));
   HIP_TRY(hipMemsetAsync(P.grad.p, 0, h->lay.total * sizeof(T), st));
-  Reverse<T> rv{S, 1, seeds.as<T>(), nullptr, P.grad.as<T>(), true};
+  Reverse<T> rv{S, 1, seeds.template as<T>(), nullptr, P.grad.template as<T>(), true};
   reverse_pass<T>(h, c, rv);
   HIP_TRY(hipStreamSynchronize(st));
-  std::vector<float> gp(h->lay.total);
-  HIP_TRY(hipMemcpy(gp.data(), P.grad.p, gp.size() * sizeof(float), hipMemcpyDeviceToHost));
-  unpack_grads(h, gp.data(), grads);
+  std::vector<T> gp(h->lay.total);
+  HIP_TRY(hipMemcpy(gp.data(), P.grad.p, gp.size() * sizeof(T), hipMemcpyDeviceToHost));
+  unpack_grads<T>(h, gp.data(), grads);
   h->train_S = 0;
 }
 
 // inverse of pack_weights for a gradient blob in the packed layout -> state_dict order
-void unpack_grads(const rn_potgnn *h, const float *gp, float *out) {
+template <typename T>
+void unpack_grads(const rn_potgnn *h, const T *gp, T *out) {
   const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP, FeP = h->d.FeP,
             P = h->cfg.num_message_passes;
   const int HP = std::max(FeP, 32);
   const PackedLayout &L = h->lay;
-  float *c = out;
+  T *c = out;
   auto copy = [&](size_t src, size_t n) {
-    std::memcpy(c, gp + src, n * sizeof(float));
+    std::memcpy(c, gp + src, n * sizeof(T));
     c += n;
   };
   auto zeros = [&](size_t n) {
-    std::memset(c, 0, n * sizeof(float));
+    std::memset(c, 0, n * sizeof(T));
     c += n;
   };
   copy(L.emb, (size_t)K * Fn);
@@ -1758,7 +1773,33 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
               h->chunk);
     return RN_ERR_INVALID_ARGUMENT;
   }
-  return guarded(h, [&]() { train_forward(h, positions, (int)S, vec6, batch_mean, batch_var); });
+  return guarded(h, [&]() { train_forward<float>(h, positions, (int)S, vec6, batch_mean, batch_var); });
+}
+
+int rn_potgnn_train_forward_f64(rn_potgnn *h, const double *positions, int64_t S, double *vec6,
+                                double *batch_mean, double *batch_var) {
+  if (!h || S <= 0 || !positions || !vec6 || !batch_mean || !batch_var) {
+    set_error(h, "invalid arguments to train_forward_f64");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S > chunk_frames<double>(h)) {
+    set_error(h, "training batch of %lld frames exceeds the float64 chunk of %d frames", (long long)S,
+              chunk_frames<double>(h));
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_forward<double>(h, positions, (int)S, vec6, batch_mean, batch_var); });
+}
+
+int rn_potgnn_train_backward_f64(rn_potgnn *h, const double *dvec6, double *grads) {
+  if (!h || !dvec6 || !grads) {
+    set_error(h, "invalid arguments to train_backward_f64");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (h->train_S <= 0 || h->train_prec != 8) {
+    set_error(h, "train_backward_f64 needs a preceding train_forward_f64");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_backward<double>(h, dvec6, grads); });
 }
 
 int rn_potgnn_set_stat_reducer(rn_potgnn *h, rn_potgnn_reduce_fn fn, void *ctx) {
@@ -1775,12 +1816,12 @@ int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
     set_error(h, "invalid arguments to train_backward");
     return RN_ERR_INVALID_ARGUMENT;
   }
-  if (h->train_S <= 0) {
+  if (h->train_S <= 0 || h->train_prec != 4) {
     set_error(h, "train_backward needs a preceding train_forward (an evaluation or Jacobian call in "
                  "between discards its tape)");
     return RN_ERR_INVALID_ARGUMENT;
   }
-  return guarded(h, [&]() { train_backward(h, dvec6, grads); });
+  return guarded(h, [&]() { train_backward<float>(h, dvec6, grads); });
 }
 
 int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32_t num_atoms,

@@ -481,6 +481,38 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             offset += n
         return grads
 
+    def train_gradients_f64(self, positions, targets):
+        """One training step's forward and backward in float64 on the device
+        (``rn_potgnn_train_forward_f64`` / ``_backward_f64``) for an MSE loss against ``targets``
+        ``[S,6]``: returns ``(out [S,6] float64, loss, {parameter name: gradient float64})``.
+        Validation aid: what the float32 step is measured against; running statistics are not
+        updated."""
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        verify_ndarray_shape("positions", pos, (None, self.num_atoms, 3))
+        tgt = np.ascontiguousarray(targets, dtype=np.float64)
+        s = pos.shape[0]
+        handle = self._ensure_handle()
+        self._install_reducer(handle)
+        lib = _lib.load()
+        out = np.empty((s, 6), dtype=np.float64)
+        mean, var = np.empty(self._fe), np.empty(self._fe)
+        rc = lib.rn_potgnn_train_forward_f64(handle, _ptr(pos), s, _ptr(out), _ptr(mean), _ptr(var))
+        _lib.check(rc, handle, "rn_potgnn_train_forward_f64")
+        loss = float(np.mean((out - tgt) ** 2))
+        dvec6 = np.ascontiguousarray(2.0 * (out - tgt) / out.size)
+        blob = np.empty(sum(v.numel() for v in self._state.values() if v.is_floating_point()), dtype=np.float64)
+        rc = lib.rn_potgnn_train_backward_f64(handle, _ptr(dvec6), _ptr(blob))
+        _lib.check(rc, handle, "rn_potgnn_train_backward_f64")
+        grads, offset = {}, 0
+        for key, value in self._state.items():
+            if not value.is_floating_point():
+                continue
+            n = value.numel()
+            if self._is_trainable(key):
+                grads[key] = blob[offset:offset + n].reshape(tuple(value.shape)).copy()
+            offset += n
+        return out, loss, grads
+
     __call__ = forward
 
     def calc_raman_tensors(self, ref_positions, displacements,
