@@ -205,6 +205,24 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
 int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads);
 
 /*
+ * Device-resident optimisation (_train.py:63-76 without host round trips).  With device training
+ * enabled, rn_potgnn_train_forward also updates the BatchNorm running statistics where the weights
+ * live (torch semantics: momentum 0.1, unbiased variance); rn_potgnn_train_backward_device leaves the
+ * parameter gradients in HBM (packed layout; rn_potgnn_gradient_buffer exposes the float32 buffer so
+ * that data-parallel ranks can all-reduce it in place over RCCL), and rn_potgnn_adam_step applies
+ * torch.optim.Adam (no amsgrad; weight_decay is added to the gradient; `step` counts from 1) to the
+ * parameters in HBM and recomputes what depends on them.  A step uploads dL/dvec6 (24 B per structure)
+ * and downloads S*6 outputs and 2*Fe statistics.  rn_potgnn_get_weights returns the current values
+ * in the layout of rn_potgnn_create's `weights` (state_dict order, buffers included).
+ */
+int rn_potgnn_set_device_training(rn_potgnn *h, int enabled);
+int rn_potgnn_train_backward_device(rn_potgnn *h, const float *dvec6);
+int rn_potgnn_gradient_buffer(rn_potgnn *h, void **device_ptr, size_t *count);
+int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int64_t step);
+int rn_potgnn_get_weights(rn_potgnn *h, float *weights, size_t num_weights);
+
+/*
  * The same step evaluated in float64 on the device (every kernel of the forward and of the
  * reverse pass has a double instantiation): what the float32 gradients are validated against,
  * next to float64 autograd through the oracle.  vec6 / batch_mean / batch_var / dvec6 / grads

@@ -62,6 +62,11 @@ SIGNATURES = {
     "rn_potgnn_set_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "rn_potgnn_train_forward": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     "rn_potgnn_train_backward": (C.c_int, [_P, _P, _P]),
+    "rn_potgnn_set_device_training": (C.c_int, [_P, C.c_int]),
+    "rn_potgnn_train_backward_device": (C.c_int, [_P, _P]),
+    "rn_potgnn_gradient_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "rn_potgnn_adam_step": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]),
+    "rn_potgnn_get_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "rn_potgnn_train_forward_f64": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     "rn_potgnn_train_backward_f64": (C.c_int, [_P, _P, _P]),
     "rn_potgnn_num_triplets": (C.c_int64, [_P]),

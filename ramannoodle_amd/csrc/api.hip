@@ -166,6 +166,13 @@ struct rn_potgnn {
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
   int train_prec = 4;  // sizeof of the precision it ran in
+  // device-resident optimisation (rn_potgnn_adam_step): gradients stay in f32.grad, Adam moments and
+  // the trainable mask live next to the weights; the host copy `packed` is refreshed on demand
+  bool device_training = false;  // BatchNorm running statistics are updated on the device
+  bool grads_on_device = false;  // f32.grad holds the gradients of the last backward
+  bool host_stale = false;       // the device weights are ahead of `packed`
+  DeviceBuf adam_m, adam_v, trainable_mask, derived_ops;
+  int num_derived_ops = 0;
   double bn_count = 0;  // rows the pending step's BatchNorm statistics cover (all ranks)
   rn_potgnn_reduce_fn reducer = nullptr;  // data-parallel training: sums doubles over ranks
   void *reducer_ctx = nullptr;
@@ -601,14 +608,16 @@ struct ChunkRun {
     ME = (int64_t)S * h->g.E;
   }
   hipStream_t st() const { return ln->stream; }
+  // With the tape on, the embeddings after pass p are written straight into tape slot p+1 (the
+  // ping-pong pair is re-pointed pass by pass), so recording costs no copies.
+  void target_tape(int slot, int which) {
+    Precision<T> &P = prec<T>(h);
+    if (!P.tape_on) return;
+    node[which] = P.tape_node[slot].template as<T>();
+    edge[which] = P.tape_edge[slot].template as<T>();
+  }
   void snapshot(int p) {
     Precision<T> &P = prec<T>(h);
-    if (P.tape_on) {
-      HIP_TRY(hipMemcpyAsync(P.tape_node[p].p, node[cur], (size_t)MN * h->d.FnP * sizeof(T),
-                             hipMemcpyDeviceToDevice, st()));
-      HIP_TRY(hipMemcpyAsync(P.tape_edge[p].p, edge[cur], (size_t)ME * h->d.FeP * sizeof(T),
-                             hipMemcpyDeviceToDevice, st()));
-    }
     if (!h->keep_stages) return;
     HIP_TRY(hipMemcpyAsync(P.snap_node[p].p, node[cur], (size_t)MN * h->d.FnP * sizeof(T),
                            hipMemcpyDeviceToDevice, st()));
@@ -619,6 +628,7 @@ struct ChunkRun {
   // geometry + radial basis, initial node embedding
   void begin() {
     Precision<T> &P = prec<T>(h);
+    target_tape(0, 0);
     {
       Timer t(h, st(), K_GEOM);
       launch_geom_rbf<T>(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
@@ -639,6 +649,7 @@ struct ChunkRun {
     const Graph &g = h->g;
     const Dims d = h->d;
     const int nxt = cur ^ 1;
+    target_tape(p + 1, nxt);
     if constexpr (sizeof(T) == 4) {
       if (narrow()) {  // the whole NodeBlock, projections included, in one launch
         Timer t(h, st(), K_NODE_AGG);
@@ -952,10 +963,10 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
                        b[DNP3], b[DC2], C, B, g, d, w, G ? &gw : nullptr, st);
     back_gemm(b[DPQ], ce, 4 * d.FeP, L.pass[p].c3_WeT, L.pass[p].t_c3We, d.FeP, de_prev, true);
     // node_{p+1} cotangent: incoming + projections + c2 operand
-    HIP_TRY(hipMemcpyAsync(b[DNX], dn_next, cn * d.FnP * sizeof(T), hipMemcpyDeviceToDevice, st));
-    back_gemm(b[DNP3], cn, 6 * d.FeP, L.pass[p].c3_WnT, L.pass[p].t_c3Wn, d.FnP, b[DNX], true);
+    // (accumulated in place: dn_next is dead once this pass's NodeBlock has consumed it)
+    back_gemm(b[DNP3], cn, 6 * d.FeP, L.pass[p].c3_WnT, L.pass[p].t_c3Wn, d.FnP, dn_next, true);
     back_gemm(b[DC2], ce, 2 * d.FeP, L.pass[p].c2_WT, L.pass[p].t_c2W, d.FnP, b[DPROD], false);
-    launch_prod_bwd<T>(b[DPROD], node1, b[DNX], C, B, g, d, st);
+    launch_prod_bwd<T>(b[DPROD], node1, dn_next, C, B, g, d, st);
     if (G) {
       const auto &q = L.pass[p];
       launch_gemm_tn<T>(edge0, d.FeP, b[DPQ], 4 * d.FeP, ce, d.FeP, 4 * d.FeP, G + q.c3_WeT, 4 * d.FeP, nullptr, 0, nullptr, g, st);
@@ -964,7 +975,7 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     }
     // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
     launch_rowgemm<T>(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
-    launch_node_bwd<T>(c.npc1, bufA, node1, b[DNX], dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w,
+    launch_node_bwd<T>(c.npc1, bufA, node1, dn_next, dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w,
                        G ? &gw : nullptr, st);
     back_gemm(b[DBC1], ce, 2 * d.FnP, L.pass[p].c1_WeT, L.pass[p].t_c1We, d.FeP, de_prev, true);
     back_gemm(b[DNPC1], cn, 2 * d.FnP, L.pass[p].c1_WnT, L.pass[p].t_c1Wn, d.FnP, dn_prev, true);
@@ -1050,6 +1061,62 @@ void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*
   (void)P;
 }
 
+// ---- device-resident optimisation step: which entries of the packed blob are parameters, which are
+// functions of parameters (and how to recompute them on the device)
+
+std::vector<DerivedOp> derived_ops(const rn_potgnn *h) {
+  const PackedLayout &L = h->lay;
+  const int FnP = h->d.FnP, FeP = h->d.FeP, Fe = h->d.Fe, HP = std::max(FeP, 32);
+  std::vector<DerivedOp> ops;
+  auto transpose = [&](size_t src, int K, int N, size_t dst) { ops.push_back({0, K, N, 1.0f, src, dst}); };
+  auto scaled = [&](size_t src, int n, float sc, size_t dst) { ops.push_back({1, n, 1, sc, src, dst}); };
+  for (const auto &q : L.pass) {
+    transpose(q.c3_WeT, FeP, 4 * FeP, q.t_c3We);
+    transpose(q.c3_WnT, FnP, 6 * FeP, q.t_c3Wn);
+    transpose(q.c2_WT, FnP, 2 * FeP, q.t_c2W);
+    transpose(q.c1_WeT, FeP, 2 * FnP, q.t_c1We);
+    transpose(q.c1_WnT, FnP, 2 * FnP, q.t_c1Wn);
+    scaled(q.c3n1_g, FeP, -1.4426950408889634f, q.c3n1_gs);
+    scaled(q.c3n1_b, FeP, -1.4426950408889634f, q.c3n1_bs);
+    scaled(q.c3n1_g + FeP, FeP, 2.0f * 1.4426950408889634f, q.c3n1_gs + FeP);
+    scaled(q.c3n1_b + FeP, FeP, 2.0f * 1.4426950408889634f, q.c3n1_bs + FeP);
+  }
+  transpose(L.W0T, FeP, HP, L.t_W0);
+  transpose(L.W3T, HP, HP, L.t_W3);
+  transpose(L.W5T, HP, 32, L.t_W5);
+  scaled(L.b0p, Fe, 1.0f, L.b0);  // the bias of readout Linear 0 lives twice (eval fold / training forward)
+  return ops;
+}
+
+// 1 where a packed entry is a trainable parameter: pack a state dict of ones, then drop the buffers
+// and every derived range
+std::vector<unsigned char> trainable_mask(rn_potgnn *h) {
+  std::vector<float> ones(rn_potgnn_weight_count(&h->cfg), 1.0f);
+  const std::vector<float> keep = h->packed;
+  pack_weights(h, ones.data());
+  std::vector<unsigned char> mask(h->packed.size());
+  for (size_t i = 0; i < mask.size(); ++i) mask[i] = h->packed[i] != 0.0f;
+  h->packed = keep;
+  const PackedLayout &L = h->lay;
+  const int HP = std::max(h->d.FeP, 32);
+  auto clear = [&](size_t o, size_t n) { std::fill(mask.begin() + o, mask.begin() + o + n, (unsigned char)0); };
+  for (const DerivedOp &op : derived_ops(h)) clear(op.dst, (size_t)op.K * (op.kind == 0 ? op.N : 1));
+  clear(L.ones, HP);
+  clear(L.offsets, h->d.FeP);  // buffers of the state dict: Gaussian offsets, BatchNorm running statistics
+  clear(L.bn_rm, h->d.Fe);
+  clear(L.bn_rv, h->d.Fe);
+  return mask;
+}
+
+// refresh `packed` (and the float64 copy, when it exists) from the device weights
+void sync_host(rn_potgnn *h) {
+  if (!h->host_stale) return;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->packed.data(), h->f32.weights.p, h->packed.size() * sizeof(float), hipMemcpyDeviceToHost));
+  h->host_stale = false;
+  if (h->f64.ready) upload_weights<double>(h);
+}
+
 // ---- training: forward with batch-statistics BatchNorm, then parameter gradients (float32 for
 // the product path; float64 for validating the reverse pass against float64 autograd)
 template <typename T>
@@ -1107,6 +1174,18 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
     for (int s = 0; s < S; ++s)
       for (int k = 0; k < 6; ++k) vec6[(size_t)s * 6 + k] = (T)raw[(size_t)s * 9 + pick[k]];
   }
+  if constexpr (sizeof(T) == 4) {
+    if (h->device_training) {  // running statistics where the weights live (torch: momentum 0.1, unbiased variance)
+      const double rows = h->bn_count;
+      launch_bn_running(Wd + L.bn_rm, Wd + L.bn_rv, mv.template as<float>(), mv.template as<float>() + HP, d.Fe,
+                        0.1, rows / std::max(rows - 1.0, 1.0), st);
+      launch_setup<float>(Wd + L.emb, Wd + L.W2, Wd + L.b2, Wd + L.W4, Wd + L.b4, h->cfg.num_atom_types, h->d,
+                          Wd + L.node_table, Wd + L.b0, Wd + L.bn_w, Wd + L.bn_b, Wd + L.bn_rm, Wd + L.bn_rv,
+                          Wd + L.scale0, Wd + L.shift0, st);
+      h->host_stale = true;
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
   std::vector<T> mvh(2 * HP);
   HIP_TRY(hipMemcpy(mvh.data(), mv.p, sizeof(T) * 2 * HP, hipMemcpyDeviceToHost));
   for (int k = 0; k < d.Fe; ++k) {
@@ -1118,10 +1197,10 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
 }
 
 template <typename T>
-void unpack_grads(const rn_potgnn *h, const T *gp, T *out);
+void unpack_grads(const rn_potgnn *h, const T *gp, T *out, bool buffers);
 
 template <typename T>
-void train_backward(rn_potgnn *h, const T *dvec6, T *grads) {
+void train_backward(rn_potgnn *h, const T *dvec6, T *grads /* null: leave the gradients on the device */) {
   Precision<T> &P = prec<T>(h);
   const int S = h->train_S;
   if (S <= 0 || h->train_prec != (int)sizeof(T))
@@ -1136,15 +1215,17 @@ void train_backward(rn_potgnn *h, const T *dvec6, T *grads) {
   Reverse<T> rv{S, 1, seeds.template as<T>(), nullptr, P.grad.template as<T>(), true};
   reverse_pass<T>(h, c, rv);
   HIP_TRY(hipStreamSynchronize(st));
+  h->train_S = 0;
+  if (sizeof(T) == 4) h->grads_on_device = true;
+  if (!grads) return;
   std::vector<T> gp(h->lay.total);
   HIP_TRY(hipMemcpy(gp.data(), P.grad.p, gp.size() * sizeof(T), hipMemcpyDeviceToHost));
-  unpack_grads<T>(h, gp.data(), grads);
-  h->train_S = 0;
+  unpack_grads<T>(h, gp.data(), grads, false);
 }
 
 // inverse of pack_weights for a gradient blob in the packed layout -> state_dict order
 template <typename T>
-void unpack_grads(const rn_potgnn *h, const T *gp, T *out) {
+void unpack_grads(const rn_potgnn *h, const T *gp, T *out, bool buffers /* true: gp holds WEIGHTS */) {
   const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP, FeP = h->d.FeP,
             P = h->cfg.num_message_passes;
   const int HP = std::max(FeP, 32);
@@ -1158,12 +1239,16 @@ void unpack_grads(const rn_potgnn *h, const T *gp, T *out) {
     std::memset(c, 0, n * sizeof(T));
     c += n;
   };
+  auto buffer = [&](size_t src, size_t n) {  // a non-trainable entry: zero gradient / its value
+    if (buffers) copy(src, n);
+    else zeros(n);
+  };
   copy(L.emb, (size_t)K * Fn);
   copy(L.W2, (size_t)Fn * Fn);
   copy(L.b2, Fn);
   copy(L.W4, (size_t)Fn * Fn);
   copy(L.b4, Fn);
-  zeros(Fe);  // "_edge_embedding.offset" is a buffer
+  buffer(L.offsets, Fe);  // "_edge_embedding.offset" is a buffer
   for (int p = 0; p < P; ++p) {
     const auto &q = L.pass[p];
     for (int r = 0; r < 2 * Fn; ++r) {
@@ -1206,8 +1291,8 @@ void unpack_grads(const rn_potgnn *h, const T *gp, T *out) {
   copy(L.b0p, Fe);
   copy(L.bn_w, Fe);
   copy(L.bn_b, Fe);
-  zeros(Fe);  // running_mean
-  zeros(Fe);  // running_var
+  buffer(L.bn_rm, Fe);  // running_mean
+  buffer(L.bn_rv, Fe);  // running_var
   for (int r = 0; r < Fe; ++r)
     for (int k = 0; k < Fe; ++k) *c++ = gp[L.W3T + (size_t)k * HP + r];
   copy(L.b3, Fe);
@@ -1697,6 +1782,7 @@ int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions, const dou
         pos[(2 * m) * n3 + i] = ref_positions[i] + eps;
         pos[(2 * m + 1) * n3 + i] = ref_positions[i] - eps;
       }
+    sync_host(h);  // (device-resident training may have moved the weights ahead of the float64 copy)
     h->io_pos.ensure(pos.size() * sizeof(double));
     h->io_alpha.ensure((size_t)2 * M * 9 * sizeof(double));
     HIP_TRY(hipMemcpy(h->io_pos.p, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1716,8 +1802,12 @@ int rn_potgnn_alpha_jacobian(rn_potgnn *h, const double *positions, int use_floa
     return RN_ERR_INVALID_ARGUMENT;
   }
   return guarded(h, [&]() {
-    if (use_float64) jacobian<double>(h, positions, jac);
-    else jacobian<float>(h, positions, jac);
+    if (use_float64) {
+      sync_host(h);
+      jacobian<double>(h, positions, jac);
+    } else {
+      jacobian<float>(h, positions, jac);
+    }
   });
 }
 
@@ -1731,6 +1821,7 @@ int rn_potgnn_raman_tensors_analytic(rn_potgnn *h, const double *ref_positions,
   return guarded(h, [&]() {
     const size_t n3 = (size_t)h->cfg.num_atoms * 3;
     std::vector<double> jac(6 * n3);
+    sync_host(h);
     jacobian<double>(h, ref_positions, jac.data());
     // R_m = 2 * sigma (.) (J d_m): the reference divides its +-delta difference by delta, not
     // 2 delta (dynamics/_phonon.py:106), i.e. it returns twice the directional derivative
@@ -1757,6 +1848,8 @@ int rn_potgnn_set_weights(rn_potgnn *h, const float *weights, size_t num_weights
   return guarded(h, [&]() {
     HIP_TRY(hipDeviceSynchronize());
     pack_weights(h, weights);
+    h->host_stale = false;
+    h->grads_on_device = false;
     if (h->f32.ready) upload_weights<float>(h);
     if (h->f64.ready) upload_weights<double>(h);
   });
@@ -1787,7 +1880,10 @@ int rn_potgnn_train_forward_f64(rn_potgnn *h, const double *positions, int64_t S
               chunk_frames<double>(h));
     return RN_ERR_INVALID_ARGUMENT;
   }
-  return guarded(h, [&]() { train_forward<double>(h, positions, (int)S, vec6, batch_mean, batch_var); });
+  return guarded(h, [&]() {
+    sync_host(h);
+    train_forward<double>(h, positions, (int)S, vec6, batch_mean, batch_var);
+  });
 }
 
 int rn_potgnn_train_backward_f64(rn_potgnn *h, const double *dvec6, double *grads) {
@@ -1800,6 +1896,96 @@ int rn_potgnn_train_backward_f64(rn_potgnn *h, const double *dvec6, double *grad
     return RN_ERR_INVALID_ARGUMENT;
   }
   return guarded(h, [&]() { train_backward<double>(h, dvec6, grads); });
+}
+
+int rn_potgnn_set_device_training(rn_potgnn *h, int enabled) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  h->device_training = enabled != 0;
+  return RN_OK;
+}
+
+int rn_potgnn_train_backward_device(rn_potgnn *h, const float *dvec6) {
+  if (!h || !dvec6) {
+    set_error(h, "invalid arguments to train_backward_device");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (h->train_S <= 0 || h->train_prec != 4) {
+    set_error(h, "train_backward_device needs a preceding train_forward (an evaluation or Jacobian call "
+                 "in between discards its tape)");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_backward<float>(h, dvec6, nullptr); });
+}
+
+int rn_potgnn_gradient_buffer(rn_potgnn *h, void **device_ptr, size_t *count) {
+  if (!h || !device_ptr || !count || !h->grads_on_device) {
+    set_error(h, "no gradients on the device (call rn_potgnn_train_backward_device first)");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  *device_ptr = h->f32.grad.p;
+  *count = h->lay.total;
+  return RN_OK;
+}
+
+int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        int64_t step) {
+  if (!h || step < 1 || !(lr >= 0) || !(eps >= 0)) {
+    set_error(h, "invalid arguments to adam_step");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (!h->grads_on_device) {
+    set_error(h, "adam_step needs the gradients of a preceding train_backward_device");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() {
+    Precision<float> &P = h->f32;
+    const PackedLayout &L = h->lay;
+    const size_t n = L.total;
+    hipStream_t st = P.lanes[0].stream;
+    if (!h->trainable_mask.p) {  // first step: moments, mask and the table of derived ranges
+      h->adam_m.ensure(n * sizeof(float));
+      h->adam_v.ensure(n * sizeof(float));
+      HIP_TRY(hipMemset(h->adam_m.p, 0, n * sizeof(float)));
+      HIP_TRY(hipMemset(h->adam_v.p, 0, n * sizeof(float)));
+      const std::vector<unsigned char> mask = trainable_mask(h);
+      h->trainable_mask.ensure(mask.size());
+      HIP_TRY(hipMemcpy(h->trainable_mask.p, mask.data(), mask.size(), hipMemcpyHostToDevice));
+      const std::vector<DerivedOp> ops = derived_ops(h);
+      h->derived_ops.ensure(ops.size() * sizeof(DerivedOp));
+      HIP_TRY(hipMemcpy(h->derived_ops.p, ops.data(), ops.size() * sizeof(DerivedOp), hipMemcpyHostToDevice));
+      h->num_derived_ops = (int)ops.size();
+    }
+    float *w = P.weights.as<float>();
+    launch_adam(w, P.grad.as<float>(), h->adam_m.as<float>(), h->adam_v.as<float>(),
+                h->trainable_mask.as<unsigned char>(), n, lr, beta1, beta2, eps, weight_decay, step, st);
+    launch_refresh_derived(w, h->derived_ops.as<DerivedOp>(), h->num_derived_ops, st);
+    launch_setup<float>(w + L.emb, w + L.W2, w + L.b2, w + L.W4, w + L.b4, h->cfg.num_atom_types, h->d,
+                        w + L.node_table, w + L.b0, w + L.bn_w, w + L.bn_b, w + L.bn_rm, w + L.bn_rv,
+                        w + L.scale0, w + L.shift0, st);
+    HIP_TRY(hipGetLastError());
+    // the triplet loop's folded-scale variant is chosen on the host from c3_norm_1: fetch those 4 P FeP floats
+    for (const auto &q : L.pass) {
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 2 * (size_t)h->d.FeP * sizeof(float),
+                             hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_b, w + q.c3n1_b, 2 * (size_t)h->d.FeP * sizeof(float),
+                             hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    refresh_pass_flags<float>(h);
+    h->host_stale = true;
+    h->grads_on_device = false;
+  });
+}
+
+int rn_potgnn_get_weights(rn_potgnn *h, float *weights, size_t num_weights) {
+  if (!h || !weights || num_weights != rn_potgnn_weight_count(&h->cfg)) {
+    set_error(h, "invalid arguments to get_weights");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() {
+    sync_host(h);
+    unpack_grads<float>(h, h->packed.data(), weights, true);
+  });
 }
 
 int rn_potgnn_set_stat_reducer(rn_potgnn *h, rn_potgnn_reduce_fn fn, void *ctx) {

@@ -182,6 +182,20 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
                        int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
 
+// Device-resident optimisation step (kernels_train.hip); offsets index the packed weight blob.
+struct DerivedOp {
+  int kind;        // 0: transposed copy of a [K][N] block, 1: scaled copy of K values
+  int K, N;
+  float scale;
+  size_t src, dst;
+};
+void launch_adam(float *w, const float *g, float *m, float *v, const unsigned char *trainable, size_t n,
+                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                 hipStream_t st);
+void launch_refresh_derived(float *w, const DerivedOp *ops, int num_ops, hipStream_t st);
+void launch_bn_running(float *running_mean, float *running_var, const float *batch_mean, const float *batch_var,
+                       int F, double momentum, double unbias, hipStream_t st);
+
 // Narrow-width kernels (kernels_narrow.hip): one lane per row, compile-time (Fn, Fe) <= 16, float32.
 bool narrow_supported(Dims d);
 size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows);

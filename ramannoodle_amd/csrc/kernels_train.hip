@@ -1,0 +1,79 @@
+// Device-resident optimisation step (_train.py:63-76): the
+// parameters, their gradients and the Adam moments stay in HBM in the kernels' own packed layout;
+// a step uploads dL/d(vec6) (24 B per structure) and downloads nothing.
+//   adam_kernel            torch.optim.Adam (no amsgrad; weight_decay added to the gradient) on the
+//                          trainable entries of the packed blob
+//   refresh_derived_kernel the entries of the blob that are functions of parameters: transposed
+//                          copies for the reverse pass, the duplicate bias of readout Linear 0, the
+//                          folded c3_norm_1 constants (node_table / scale0 / shift0: setup_kernel)
+//   bn_running_kernel      BatchNorm1d running statistics, torch semantics (momentum 0.1, unbiased var)
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace rn {
+
+__global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, const unsigned char *__restrict__ trainable, size_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                            float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !trainable[i]) return;
+  float grad = g[i];
+  if (weight_decay != 0.0f) grad = fmaf(weight_decay, w[i], grad);
+  const float mi = beta1 * m[i] + (1.0f - beta1) * grad;  // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = beta2 * v[i] + (1.0f - beta2) * grad * grad;
+  m[i] = mi;
+  v[i] = vi;
+  // torch: denom = sqrt(v) / sqrt(1 - beta2^t) + eps;  w -= lr / (1 - beta1^t) * m / denom
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  w[i] -= (lr / bc1) * (mi / denom);
+}
+
+void launch_adam(float *w, const float *g, float *m, float *v, const unsigned char *trainable, size_t n,
+                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                 hipStream_t st) {
+  if (n == 0) return;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  adam_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w, g, m, v, trainable, n, (float)lr, (float)beta1,
+                                                          (float)beta2, (float)eps, (float)weight_decay,
+                                                          (float)bc1, (float)sqrt(bc2));
+}
+
+// one entry per derived range of the packed blob
+//   kind 0: dst[n*K + k] = src[k*N + n]   (transposed copy, src is [K][N])
+//   kind 1: dst[i] = src[i] * scale       (count = K: copies with scale 1, folded LayerNorm halves)
+__global__ void refresh_derived_kernel(float *__restrict__ w, const DerivedOp *__restrict__ ops, int num_ops) {
+  for (int o = blockIdx.x; o < num_ops; o += gridDim.x) {
+    const DerivedOp op = ops[o];
+    const size_t total = (size_t)op.K * (op.kind == 0 ? op.N : 1);
+    for (size_t i = threadIdx.x; i < total; i += blockDim.x) {
+      if (op.kind == 0) {
+        const size_t k = i / op.N, n = i % op.N;
+        w[op.dst + n * op.K + k] = w[op.src + i];
+      } else {
+        w[op.dst + i] = w[op.src + i] * op.scale;
+      }
+    }
+  }
+}
+void launch_refresh_derived(float *w, const DerivedOp *ops, int num_ops, hipStream_t st) {
+  if (num_ops == 0) return;
+  refresh_derived_kernel<<<num_ops, 256, 0, st>>>(w, ops, num_ops);
+}
+
+__global__ void bn_running_kernel(float *__restrict__ running_mean, float *__restrict__ running_var,
+                                  const float *__restrict__ batch_mean, const float *__restrict__ batch_var,
+                                  int F, float momentum, float unbias) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= F) return;
+  running_mean[k] = (1.0f - momentum) * running_mean[k] + momentum * batch_mean[k];
+  running_var[k] = (1.0f - momentum) * running_var[k] + momentum * (batch_var[k] * unbias);
+}
+void launch_bn_running(float *running_mean, float *running_var, const float *batch_mean, const float *batch_var,
+                       int F, double momentum, double unbias, hipStream_t st) {
+  bn_running_kernel<<<(F + 63) / 64, 64, 0, st>>>(running_mean, running_var, batch_mean, batch_var, F,
+                                                  (float)momentum, (float)unbias);
+}
+
+}  // namespace rn

@@ -87,6 +87,17 @@ def average_gradients(model, group=None) -> None:
     which makes this plain mean the gradient of the mean loss over the whole mini-batch."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    if getattr(model, "_device_training", False):  # gradients live in HBM: reduce them in place
+        buf = model.device_gradients()
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            buf.div_(dist.get_world_size(group))
+        else:  # gloo (CPU rehearsal of the multi-rank path): through the host
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            buf.copy_(host / dist.get_world_size(group))
+        torch.cuda.synchronize(buf.device)
+        return
     params = [p for p in model.parameters() if p.grad is not None]
     if not params:
         return

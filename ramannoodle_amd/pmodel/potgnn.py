@@ -110,12 +110,40 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         self._gauss_coefficient = -0.5 / (float(offset[1]) - float(offset[0])) ** 2  # _gnn.py:64
         # trainable entries become torch Parameters (so torch.optim works on them); buffers
         # (Gaussian offsets, BatchNorm running statistics) stay plain tensors
-        self._state = OrderedDict(
+        self._device_ahead = False     # DeviceAdam stepped: the device weights are newer than _state
+        self._device_training = False  # gradients / optimiser state / BatchNorm buffers live in HBM
+        self._device_anchor = torch.zeros(1, requires_grad=True)
+        self._device_batches_tracked = 0
+        self._state_store = OrderedDict(
             (k, torch.nn.Parameter(v) if self._is_trainable(k) else v) for k, v in state.items())
         self._handle = None
         self._profiling = 0
         self._uploaded_version = None
         self.training = True  # like a fresh torch Module; calc_polarizabilities switches to eval
+
+    @property
+    def _state(self) -> "OrderedDict[str, torch.Tensor]":
+        """The host copy of the parameters and buffers, refreshed from the device first when a
+        device-resident optimiser has moved the weights (``DeviceAdam``)."""
+        if self._device_ahead:
+            self._sync_from_device()
+        return self._state_store
+
+    def _sync_from_device(self) -> None:
+        store = self._state_store
+        blob = np.empty(sum(v.numel() for v in store.values() if v.is_floating_point()), dtype=np.float32)
+        rc = _lib.load().rn_potgnn_get_weights(self._handle, _ptr(blob), blob.size)
+        _lib.check(rc, self._handle, "rn_potgnn_get_weights")
+        offset = 0
+        with torch.no_grad():
+            for value in store.values():
+                if value.is_floating_point():
+                    n = value.numel()
+                    value.copy_(torch.from_numpy(blob[offset:offset + n].reshape(tuple(value.shape))))
+                    offset += n
+            store["_to_polarizability_embedding.1.num_batches_tracked"].fill_(self._device_batches_tracked)
+        self._device_ahead = False
+        self._uploaded_version = sum(int(v._version) for v in store.values())  # device == host again
 
     def _fresh_state(self) -> "OrderedDict[str, torch.Tensor]":
         """Freshly initialised tensors, created in the reference's module order so that the
@@ -258,6 +286,8 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
 
     def _ensure_handle(self):
         if self._handle is not None:
+            if self._device_ahead:  # the device copy is the current one (see the _state property)
+                return self._handle
             if self._uploaded_version != self._version():  # e.g. after optimizer.step()
                 blob = self._weights_blob()
                 rc = _lib.load().rn_potgnn_set_weights(self._handle, _ptr(blob), blob.size)
@@ -390,6 +420,8 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             if not same_lattice:
                 raise NotImplementedError("training mode supports only the reference structure's "
                                           "lattice (PolarizabilityDataset holds a single lattice)")
+            if self._device_training:  # gradients stay in HBM: nothing for autograd to route
+                return _TrainStep.apply(self, pos, self._device_anchor)
             return _TrainStep.apply(self, pos, *self.parameters())
         out = np.empty((pos.shape[0], 6), dtype=np.float32)
         handle = self._ensure_handle()
@@ -453,6 +485,10 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         rc = _lib.load().rn_potgnn_train_forward(handle, _ptr(pos), pos.shape[0], _ptr(out),
                                                  _ptr(mean), _ptr(var))
         _lib.check(rc, handle, "rn_potgnn_train_forward")
+        if self._device_training:  # the library updated the running statistics where they live
+            self._device_batches_tracked += 1
+            self._device_ahead = True
+            return out
         # BatchNorm1d running statistics, torch semantics (momentum 0.1, unbiased variance)
         rows = int(round(_lib.load().rn_potgnn_train_row_count(handle)))  # all ranks' rows
         pre = "_to_polarizability_embedding.1."
@@ -480,6 +516,38 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
                 grads.append(torch.from_numpy(blob[offset:offset + n].reshape(tuple(value.shape)).copy()))
             offset += n
         return grads
+
+    # -- device-resident optimisation (DeviceAdam) ------------------------------------------
+    def enable_device_training(self, enabled: bool = True) -> None:
+        """Keep parameter gradients, optimiser state and BatchNorm running statistics in HBM
+        (``rn_potgnn_train_backward_device`` / ``rn_potgnn_adam_step``): a training step then
+        moves only positions, outputs and ``dL/dout`` across PCIe.  ``parameters()`` /
+        ``state_dict()`` fetch the current values on demand; ``p.grad`` is not populated."""
+        handle = self._ensure_handle()
+        if not enabled:
+            _ = self._state  # bring the host copy up to date before handing control back
+        rc = _lib.load().rn_potgnn_set_device_training(handle, int(bool(enabled)))
+        _lib.check(rc, handle, "rn_potgnn_set_device_training")
+        self._device_training = bool(enabled)
+        self._device_batches_tracked = int(
+            self._state_store["_to_polarizability_embedding.1.num_batches_tracked"])
+
+    def _train_backward_device(self, dvec6: np.ndarray) -> None:
+        rc = _lib.load().rn_potgnn_train_backward_device(self._handle, _ptr(dvec6))
+        _lib.check(rc, self._handle, "rn_potgnn_train_backward_device")
+
+    def device_gradients(self) -> torch.Tensor:
+        """The float32 gradient buffer of the last device backward, as a CUDA tensor that
+        aliases the library's memory (packed layout; for in-place all-reduce over RCCL)."""
+        ptr, count = C.c_void_p(), C.c_size_t()
+        rc = _lib.load().rn_potgnn_gradient_buffer(self._handle, C.byref(ptr), C.byref(count))
+        _lib.check(rc, self._handle, "rn_potgnn_gradient_buffer")
+        return _alias_device_buffer(int(ptr.value), int(count.value), self.device_index)
+
+    def _adam_step(self, lr, beta1, beta2, eps, weight_decay, step) -> None:
+        rc = _lib.load().rn_potgnn_adam_step(self._handle, lr, beta1, beta2, eps, weight_decay, step)
+        _lib.check(rc, self._handle, "rn_potgnn_adam_step")
+        self._device_ahead = True
 
     def train_gradients_f64(self, positions, targets):
         """One training step's forward and backward in float64 on the device
@@ -650,5 +718,47 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):  # pylint: disable=arguments-differ
         dvec6 = np.ascontiguousarray(grad_out.detach().cpu().numpy(), dtype=np.float32)
+        if ctx.model._device_training:
+            ctx.model._train_backward_device(dvec6)
+            return (None, None, None)
         grads = ctx.model._train_backward(dvec6)
         return (None, None, *grads)
+
+
+class _DeviceSpan:  # pylint: disable=too-few-public-methods
+    """``__cuda_array_interface__`` carrier for a float32 range of library-owned device memory."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
+def _alias_device_buffer(ptr: int, count: int, device_index: int) -> torch.Tensor:
+    return torch.as_tensor(_DeviceSpan(ptr, count), device=torch.device("cuda", device_index))
+
+
+class DeviceAdam:
+    """``torch.optim.Adam`` (no amsgrad) applied where the weights live.  Constructing it switches
+    the model to device-resident training; ``step()`` is one ``rn_potgnn_adam_step`` (Adam on the
+    packed weights, refresh of everything derived from them), ``zero_grad()`` is a no-op (each
+    backward overwrites the gradient buffer).  Drop-in for the optimiser argument of
+    ``train_single_epoch`` (``pmodel/torch/_train.py:63-76``)."""
+
+    def __init__(self, model: PotGNN, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameters")
+        self.model = model
+        self.param_groups = [dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                                  weight_decay=float(weight_decay))]
+        self.steps = 0
+        model.enable_device_training(True)
+
+    def step(self) -> None:
+        group = self.param_groups[0]
+        self.steps += 1
+        self.model._adam_step(group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+                              group["weight_decay"], self.steps)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:  # pylint: disable=unused-argument
+        return None

@@ -30,11 +30,14 @@ def main():
              torch.tensor(g["pos_batch"][:s], dtype=torch.float32),
              torch.tensor(g["train/target"]))
     lat, zs, pos, target = parallel.batch_shard(batch)
+    if len(sys.argv) > 5 and sys.argv[5] == "device":
+        device_mode(model, lat, zs, pos, target, rank, world, out_path)
+        return
     out = model.forward(lat, zs, pos)
     loss = torch.nn.MSELoss()(out, target)
     loss.backward()
     parallel.average_gradients(model)
-    total = torch.tensor([float(loss)], dtype=torch.float64)
+    total = torch.tensor([float(loss.detach())], dtype=torch.float64)
     dist.all_reduce(total)
     gathered = [torch.zeros_like(out.detach()) for _ in range(world)]
     dist.all_gather(gathered, out.detach().contiguous())
@@ -45,6 +48,34 @@ def main():
         arrays["out"] = torch.cat(gathered).numpy()
         arrays["running_mean"] = sd["_to_polarizability_embedding.1.running_mean"].numpy()
         arrays["running_var"] = sd["_to_polarizability_embedding.1.running_var"].numpy()
+        np.savez(out_path, **arrays)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def device_mode(model, lat, zs, pos, target, rank, world, out_path):
+    """Two steps of device-resident Adam; rank 0 writes both ranks' resulting state dicts."""
+    from ramannoodle_amd import parallel
+    from ramannoodle_amd.pmodel import DeviceAdam
+
+    opt = DeviceAdam(model, lr=1e-3)
+    for _ in range(2):
+        out = model.forward(lat, zs, pos)
+        torch.nn.MSELoss()(out, target).backward()
+        parallel.average_gradients(model)
+        opt.step()
+    sd = model.state_dict()
+    flat = torch.cat([v.reshape(-1).float() for v in sd.values() if v.is_floating_point()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        arrays, offset = {}, 0
+        for key, value in sd.items():
+            if value.is_floating_point():
+                n = value.numel()
+                arrays["sd/" + key] = gathered[0][offset:offset + n].reshape(value.shape).numpy()
+                arrays["sd1/" + key] = gathered[1][offset:offset + n].reshape(value.shape).numpy()
+                offset += n
         np.savez(out_path, **arrays)
     dist.barrier()
     dist.destroy_process_group()

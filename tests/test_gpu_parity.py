@@ -681,6 +681,120 @@ def test_training_step_at_config5_shape():
     assert worst < 1e-3
 
 
+def _adam_run(model, optimizer, lat, zs, pos, targets, steps):
+    losses = []
+    model.train()
+    for it in range(steps):
+        sel = slice(0, pos.shape[0]) if it % 2 == 0 else slice(1, pos.shape[0])  # two batch sizes
+        out = model.forward(lat[sel], zs[sel], pos[sel])
+        loss = torch.nn.MSELoss()(out, targets[sel])
+        loss.backward()
+        losses.append(float(loss.detach()))
+        optimizer.step()
+        optimizer.zero_grad()
+    return losses
+
+
+def test_device_adam_matches_torch_adam():
+    """Device-resident training (gradients, Adam moments, weights and BatchNorm buffers stay in
+    HBM; ``rn_potgnn_adam_step``) against ``torch.optim.Adam`` on the host copy of the same model,
+    fed by the same device gradients (``_train.py:63-76``): six steps, with weight decay."""
+    from ramannoodle_amd.pmodel import DeviceAdam
+    g, host, lat, zs, pos = _load_train_case()
+    targets = torch.tensor(g["train/target"])
+    device = product_model_from_golden(g)
+    kw = dict(lr=2e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-3)
+    host_losses = _adam_run(host, torch.optim.Adam(host.parameters(), **kw), lat, zs, pos, targets, 6)
+    opt = DeviceAdam(device, **kw)
+    dev_losses = _adam_run(device, opt, lat, zs, pos, targets, 6)
+    assert all(p.grad is None for p in device._state_store.values() if isinstance(p, torch.nn.Parameter))
+    np.testing.assert_allclose(dev_losses, host_losses, rtol=2e-5)
+    assert host_losses[4] < host_losses[0]  # (same batch)
+    # evaluation right after the steps runs on the device's weights (no upload in between) ...
+    uploads = device._uploaded_version
+    a_dev = device.calc_polarizabilities(g["pos_batch"][:5])
+    assert device._device_ahead and device._uploaded_version == uploads
+    a_host = host.calc_polarizabilities(g["pos_batch"][:5])
+    np.testing.assert_allclose(a_dev, a_host, rtol=0, atol=2e-5 * np.abs(a_host).max())
+    # ... and state_dict() fetches them
+    sd_d, sd_h = device.state_dict(), host.state_dict()
+    assert not device._device_ahead
+    worst = {}
+    for key, ref in sd_h.items():
+        got = sd_d[key]
+        if not ref.is_floating_point():
+            assert int(got) == int(ref) == 6, key
+            continue
+        worst[key] = float((got - ref).abs().max())
+        # a step moves a weight by <= lr = 2e-3; the two Adam implementations round differently and
+        # the next step's gradients see that (measured: 1.6e-6 after six steps)
+        assert worst[key] < 1e-5, (key, worst[key])
+    print("device Adam vs torch Adam after 6 steps: worst |dw| =", max(worst.values()),
+          max(worst, key=worst.get))
+    # the float64 entry points see the stepped weights too
+    j_dev = device.alpha_jacobian(g["pos_batch"][0], float64=True)
+    j_host = host.alpha_jacobian(g["pos_batch"][0], float64=True)
+    np.testing.assert_allclose(j_dev, j_host, rtol=0, atol=1e-4 * np.abs(j_host).max())
+    # handing control back to a host optimiser keeps the values
+    device.enable_device_training(False)
+    again = device.calc_polarizabilities(g["pos_batch"][:5])
+    np.testing.assert_array_equal(again, a_dev)
+
+
+def test_device_adam_through_train_single_epoch():
+    """``train_single_epoch`` (``_train.py:20-91``) with the device-resident optimiser."""
+    from ramannoodle_amd.pmodel import DeviceAdam, train_single_epoch
+    g, host, lat, zs, pos = _load_train_case()
+    device = product_model_from_golden(g)
+    targets = torch.tensor(g["train/target"])
+    data = torch.utils.data.TensorDataset(lat, zs, pos, targets)
+    torch.manual_seed(3)
+    ref = train_single_epoch(host, data, data, 4, torch.optim.Adam(host.parameters(), lr=1e-3),
+                             torch.nn.MSELoss())
+    torch.manual_seed(3)
+    got = train_single_epoch(device, data, data, 4, DeviceAdam(device, lr=1e-3), torch.nn.MSELoss())
+    assert got[0] == pytest.approx(ref[0], rel=1e-4) and got[1] == pytest.approx(ref[1], rel=1e-4)
+    np.testing.assert_allclose(got[2], ref[2], rtol=1e-3, atol=1e-7)
+
+
+def test_device_adam_data_parallel(tmp_path):
+    """Two ranks with device-resident training: the packed gradient buffers are averaged in place
+    (``parallel.average_gradients``) before ``rn_potgnn_adam_step``; after two steps every rank holds
+    what one process training on the whole batch holds."""
+    import socket
+    import subprocess
+    import sys
+    from ramannoodle_amd.pmodel import DeviceAdam
+    g, single, lat, zs, pos = _load_train_case()
+    targets = torch.tensor(g["train/target"])
+    opt = DeviceAdam(single, lr=1e-3)
+    single.train()
+    for _ in range(2):
+        torch.nn.MSELoss()(single.forward(lat, zs, pos), targets).backward()
+        opt.step()
+    want = single.state_dict()
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = tmp_path / "dp_device.npz"
+    worker = os.path.join(os.path.dirname(__file__), "dp_train_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(out), "device"])
+             for r in range(2)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0, 0], codes
+    got = np.load(out)
+    # The bias in front of BatchNorm has no gradient in exact arithmetic (batch statistics absorb
+    # it); what reaches Adam is rounding noise, which Adam normalises to +-lr per step -- torch's
+    # does the same.  Its summation order differs between one and two ranks, so that vector, and the
+    # running mean that carries a tenth of it per step, are compared on the scale of the steps.
+    loose = {"_to_polarizability_embedding.0.bias": 2.5e-3, "_to_polarizability_embedding.1.running_mean": 5e-4}
+    for key, ref in want.items():
+        if ref.is_floating_point():
+            np.testing.assert_allclose(got["sd/" + key], ref.numpy(), rtol=0, atol=loose.get(key, 2e-5),
+                                       err_msg=key)
+            np.testing.assert_array_equal(got["sd/" + key], got["sd1/" + key], err_msg=key)  # ranks agree
+
+
 def test_data_parallel_training_step_matches_reference(tmp_path):
     """Two ranks (gloo, both on this GPU), half of the fixture batch each: BatchNorm statistics
     all-reduced inside the device step and gradients averaged over the ranks must reproduce the

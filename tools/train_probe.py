@@ -6,14 +6,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_workload, rocksalt
 hp = sys.argv[1] if len(sys.argv) > 1 else "perf"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-wl = make_workload((4, 2, 2), batch, hp, seed=55)
+cells = (4, 4, 2) if os.environ.get("RN_PROBE_256") else (4, 2, 2)
+wl = make_workload(cells, batch, hp, seed=55)
 model = wl["model"]()
-lattice, ref, zs = rocksalt(4, 2, 2)
+lattice, ref, zs = rocksalt(*cells)
 lat = torch.tensor(lattice, dtype=torch.float32).expand(batch, 3, 3)
 z = torch.tensor(zs).expand(batch, -1)
 pos = torch.tensor(wl["positions"], dtype=torch.float32)
 target = torch.randn(batch, 6)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+if os.environ.get("RN_PROBE_DEVICE"):
+    from ramannoodle_amd.pmodel import DeviceAdam
+    opt = DeviceAdam(model, lr=1e-3)
+else:
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 model.train()
 if os.environ.get("RN_PROBE_NOGC"):
     import gc
