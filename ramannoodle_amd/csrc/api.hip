@@ -205,6 +205,10 @@ void set_error(rn_potgnn *h, const char *fmt, ...) {
 // LayerNorm of logical width 2F (first F rows = filter, last F = core; _gnn.py:143).
 inline int gated_col(int r, int F, int FP) { return r < F ? r : FP + (r - F); }
 
+// Largest out-degree the tiled kernels take: the rows of one atom's outgoing edges, 2 FeP float64
+// values (+ an index) each, have to fit a 150 KB LDS tile.  590 for FeP = 16, 149 for 64, 74 for 128.
+inline size_t max_out_degree(int FeP) { return (size_t)150 * 1024 / ((size_t)2 * FeP * sizeof(double) + 4); }
+
 void pack_weights(rn_potgnn *h, const float *w) {
   const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP,
             FeP = h->d.FeP, P = h->cfg.num_message_passes;
@@ -1388,6 +1392,18 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       return RN_ERR_INVALID_ARGUMENT;
     }
 
+  {  // an atom's outgoing-edge rows (in float64) must fit one workgroup's LDS tile
+    const size_t cap = max_out_degree(pad_pow2(cfg->size_edge_embedding));
+    std::vector<int> deg(N, 0);
+    for (int e = 0; e < E; ++e) deg[edge_a[e]]++;
+    for (int n = 0; n < N; ++n)
+      if ((size_t)deg[n] > cap) {
+        set_error(nullptr, "atom %d has %d outgoing edges; more than %zu per atom is unsupported "
+                           "for size_edge_embedding=%d", n, deg[n], cap, cfg->size_edge_embedding);
+        return RN_ERR_UNSUPPORTED;
+      }
+  }
+
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 ||
       cfg->device >= ndev) {
@@ -1434,15 +1450,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   // to waste as few lane groups in the last round as possible (18 in-edges per atom and
   // G = 16: 4 atoms per tile idle 10 % of the groups, 6 atoms 4 %).
   const size_t row_bytes = (size_t)2 * d.FeP * sizeof(float);
-  const size_t cap_rows = (size_t)150 * 1024 / ((size_t)2 * d.FeP * sizeof(double) + 4);
-  for (int n = 0; n < N; ++n) {
-    const int deg = h->out_ptr[n + 1] - h->out_ptr[n];
-    if ((size_t)deg > cap_rows) {
-      set_error(nullptr, "atom %d has %d outgoing edges; more than %zu per atom is unsupported", n,
-                deg, cap_rows);
-      return RN_ERR_UNSUPPORTED;
-    }
-  }
+  const size_t cap_rows = max_out_degree(d.FeP);
   auto build_tiles = [&](size_t budget_rows, std::vector<int> &tb) {
     tb.assign(1, 0);
     int rows = 0, max_rows = 0;

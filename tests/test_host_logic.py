@@ -177,6 +177,38 @@ def test_create_rejects_bad_arguments_without_touching_the_gpu():
     assert rc == _lib.RN_ERR_INVALID_ARGUMENT
 
 
+def test_documented_size_limits_raise_not_implemented():
+    """The two limits of the device model (DESIGN.md "Limits"): embedding sizes above 128, and
+    more outgoing edges per atom than one LDS tile holds (149 at Fe = 64; the reference's
+    ``radius_graph_pbc`` keeps one edge per ordered atom pair, so this needs > 149 atoms inside
+    the cutoff sphere).  Both are refused at model creation with NotImplementedError, before
+    any device work."""
+    from bench import rocksalt
+    from ramannoodle_amd.pmodel import PotGNN
+    from ramannoodle_amd.structure import ReferenceStructure
+    lattice, ref, zs = rocksalt(1, 1, 1)
+    small = ReferenceStructure(list(zs), lattice, ref)
+    unit = (np.eye(3), np.ones((3, 3)))
+    for fn, fe in ((129, 8), (8, 129)):
+        model = PotGNN(small, 3.0, fn, fe, 1, 0.0, 5.0, *unit)
+        with pytest.raises(NotImplementedError, match="embedding sizes above 128 are not supported"):
+            model.calc_polarizabilities(ref[None])
+    lattice, ref, zs = rocksalt(4, 4, 2)
+    dense = PotGNN(ReferenceStructure(list(zs), lattice, ref), 7.9, 64, 64, 1, 0.0, 5.0, *unit)
+    assert dense.num_edges / dense.num_atoms > 149
+    with pytest.raises(NotImplementedError,
+                       match=r"outgoing edges; more than 149 per atom is unsupported for size_edge_embedding=64"):
+        dense.calc_polarizabilities(ref[None])
+    # the same graph is accepted at a width whose rows fit (590 per atom at Fe <= 16): creation then
+    # proceeds to the device probe, which is what fails on a machine without a GPU
+    import torch
+    if not torch.cuda.is_available():
+        from ramannoodle_amd.exceptions import DeviceError
+        ok = PotGNN(ReferenceStructure(list(zs), lattice, ref), 7.9, 8, 16, 1, 0.0, 5.0, *unit)
+        with pytest.raises(DeviceError, match="no usable HIP device"):
+            ok.calc_polarizabilities(ref[None])
+
+
 # ----------------------------------------------------------------------------- spectra
 def test_phonon_spectrum_matches_reference():
     g = load_golden("triclinic20")
