@@ -35,6 +35,20 @@
 namespace rn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Timing-only probe build (RN_BUILD_TAG=probe RN_EXTRA_FLAGS=-DRN_FUSED_PROBE=1; wrong results):
+// RN_FUSED_PROBE_MASK in the environment switches phases of the EdgeBlock kernel off at run time --
+// 1 triplet loop, 2 epilogue (LayerNorms, c2 gate, tanh), 4 Q' MFMA staging, 8 centring pass,
+// 16 per-round MFMA phase, 32 operand LDS-DMA.  The product build compiles none of it.
+#ifndef RN_FUSED_PROBE
+#define RN_FUSED_PROBE 0
+#endif
+#if RN_FUSED_PROBE
+#define RN_PROBE(bit) ((a.probe & (bit)) != 0)
+#else
+#define RN_PROBE(bit) false
+#endif
 
 struct EdgeFusedArgs {
   const float *edge_in;
@@ -45,10 +59,13 @@ struct EdgeFusedArgs {
   Graph g;
   Dims d;
   PassW<float> w;
+#if RN_FUSED_PROBE
+  int probe;
+#endif
 };
 
-#ifndef RN_FUSED_EXPERIMENT
-#define RN_FUSED_EXPERIMENT 0  // timing-only variant (wrong results): 1 no triplet loop
+#ifndef RN_FUSED_PK
+#define RN_FUSED_PK 1  // packed-f32 (two columns per instruction) arithmetic in the triplet loop
 #endif
 #ifndef RN_FUSED_PAIRWISE
 #define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
@@ -233,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   // LDS-DMA of the operand rows of round `r` of frame `s`: wave w brings rows 4w..4w+3 of
   // each of the three tiles; slot (row, piece p) receives global piece p ^ row.
   auto prefetch_round = [&](int s, int r) {
+    if (RN_PROBE(32)) return;
     const int row = 4 * wave + quad;
     const int i = min(r * NG + row, dcount - 1);
     const int piece = (l15 ^ row) & 15;
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     {
       WaveB<F16> bW5;
       bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad);
-      for (int mt = 0; mt * 16 < rows; ++mt) {
+      for (int mt = 0; mt * 16 < (RN_PROBE(4) ? 0 : rows); ++mt) {
         float af[KS];
         const float *src = a.edge_in + (erow0 + eo0 + min(mt * 16 + l15, rows - 1)) * FP + quad * KS;
 #pragma unroll
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     }
     __syncthreads();
     // ---- add Wi node[b_e], centre, record |q|^2 (padded columns forced to 0)
-    for (int r = grp; r < rows; r += NG) {
+    for (int r = grp; r < (RN_PROBE(8) ? 0 : rows); r += NG) {
       float *row = bufQ + r * LDQ;
       const float *np = a.np3 + (nrow0 + qb[r]) * (6 * FP) + c0;
       Vec4<float> f = load4<float>(row + c0), c = load4<float>(row + FP + c0);
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     }
     for (int r = 0; r < nrounds; ++r) {
       // ---- MFMA: P' and c2 pre-activations of 16 destinations from the DMA'd operand rows
-      {
+      if (!RN_PROBE(16)) {
         float af[KS];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         }
         sp = lg_sum<LG>(sp);
 
-        const int rb = d_rb[i], cnt = (RN_FUSED_EXPERIMENT == 1) ? 0 : d_cnt[i], rskip = d_skip[i];
+        const int rb = d_rb[i], cnt = RN_PROBE(1) ? 0 : d_cnt[i], rskip = d_skip[i];
         const int half = split ? (cnt + 1) / 2 : cnt;
         const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's triplets
         if constexpr (FASTG) {
@@ -422,6 +440,48 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             }
           }
           const float spe = sp * inv2n + 1e-5f;
+#if RN_FUSED_PK
+          // Two columns per instruction: v_pk_add_f32 / v_pk_fma_f32 carry the non-transcendental
+          // half of the loop at twice the columns per issue slot (the exp2 / rcp stay per column).
+          f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2], bf2[2], bc2[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            pf2[hh] = f32x2{pf[2 * hh], pf[2 * hh + 1]};
+            pc2[hh] = f32x2{pc[2 * hh], pc[2 * hh + 1]};
+            pdf2[hh] = f32x2{pdf[2 * hh], pdf[2 * hh + 1]};
+            pdc2[hh] = f32x2{pdc[2 * hh], pdc[2 * hh + 1]};
+            bf2[hh] = f32x2{b3f[2 * hh], b3f[2 * hh + 1]};
+            bc2[hh] = f32x2{b3c[2 * hh], b3c[2 * hh + 1]};
+          }
+          auto triplet = [&](int rq, float (&sumk)[4]) {
+            const float *qr = bufQ + rq * LDQ + c0;
+            const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
+            const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
+            f32x2 d2 = pdf2[0] * qf2[0];
+            f32x2 d3 = pdc2[0] * qc2[0];
+            d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
+            d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
+            d2 += d3;
+            const float dot = lg_sum<LG>(d2.x + d2.y);
+            float ve = dot + (spe + sq[rq]);
+            ve = ve > 1e-5f ? ve : 1e-5f;
+            const float rstd = fast_rsq(ve);
+            const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const f32x2 xf = __builtin_elementwise_fma(pf2[hh] + qf2[hh], rstd2, bf2[hh]);
+              const f32x2 xc = __builtin_elementwise_fma(pc2[hh] + qc2[hh], rstd2, bc2[hh]);
+              const f32x2 e1 = {fast_exp2(xf.x), fast_exp2(xf.y)}, e2 = {fast_exp2(xc.x), fast_exp2(xc.y)};
+              const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+              const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
+              const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
+              f32x2 sk = {sumk[2 * hh], sumk[2 * hh + 1]};
+              sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
+              sumk[2 * hh] = sk.x;
+              sumk[2 * hh + 1] = sk.y;
+            }
+          };
+#else
           auto triplet = [&](int rq, float (&sumk)[4]) {
             const float *qr = bufQ + rq * LDQ + c0;
             const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
@@ -443,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
               sumk[k] = fmaf(e2 - 1.0f, fast_rcp(fmaf(e1, t2, t2)), sumk[k]);
             }
           };
+#endif
 #if RN_FUSED_PAIRWISE
           // two independent triplets per iteration: at two waves per SIMD the second chain
           // fills the dependency stalls of the first (summation order: even/odd partial sums)
@@ -492,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           for (int k = 0; k < 4; ++k) acc[k] += other.v[k];
         }
       }
-      if (active && part == 0) {
+      if (RN_PROBE(2)) {
+        if (active && part == 0)
+          store4(a.edge_out + drow * FP + c0, Vec4<float>{{acc[0] + old.v[0], acc[1] + old.v[1], acc[2], acc[3]}});
+      } else if (active && part == 0) {
         const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
         const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
         // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
@@ -887,6 +951,9 @@ void launch_edge_fused(const float *edge_in, float *edge_out, const float *node,
                        int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
   EdgeFusedArgs a{edge_in, edge_out, node, np3, S, g, d, w};
+#if RN_FUSED_PROBE
+  a.probe = getenv("RN_FUSED_PROBE_MASK") ? atoi(getenv("RN_FUSED_PROBE_MASK")) : 0;
+#endif
   const size_t lds = edge_fused_lds_bytes(g);
   const bool pad = d.Fe != d.FeP;
   const bool fast = (w.c3_fast & 1) != 0;
