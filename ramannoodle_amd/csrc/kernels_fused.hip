@@ -109,10 +109,13 @@ __device__ __forceinline__ void dma16(const float *src, float *lds_wave_base) {
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// One wave's B operand of a [64 x N] weight matrix W (row-major, leading dimension ld): the 32
+// One wave's share of a [64 x N] weight matrix W (row-major, leading dimension ld): the 32
 // columns colbase .. colbase+31 as two 16-column MFMA tiles, resident in VGPRs.  `product`
-// accumulates  acc[t] += A * W[:, tile t]  for a 16-row A tile of which this lane (row l15, quad)
-// holds the 16 consecutive k = 16 quad .. 16 quad + 15 in `af`.
+// accumulates the TRANSPOSED tile  acc[t] += (X W[:, tile t])^T  for a 16-row X tile of which this
+// lane (row l15, quad) holds the 16 consecutive k = 16 quad .. 16 quad + 15 in `af`: the weights go
+// in as the MFMA's A operand, the rows as its B operand (the two fragment layouts are the same), so
+// a lane ends up with FOUR CONSECUTIVE COLUMNS 16 t + 4 quad .. + 3 of row l15 -- one 16-byte LDS
+// store per tile instead of four 4-byte ones.
 template <bool F16>
 struct WaveB;
 template <>
@@ -128,7 +131,7 @@ struct WaveB<false> {  // exact f32: v_mfma_f32_16x16x4_f32, k = 16 quad + step
 #pragma unroll
     for (int k = 0; k < KS; ++k)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], w[t][k], acc[t], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][k], af[k], acc[t], 0, 0, 0);
   }
 };
 template <>
@@ -149,12 +152,47 @@ struct WaveB<true> {  // split f16 (device_utils.hpp: mfma_split3), K = 32 slice
     f16x8 ah[2], al[2];
     split_f16x8(af, ah[0], al[0]);
     split_f16x8(af + 8, ah[1], al[1]);
+    product_split(ah, al, acc);
+  }
+  // the same with an A operand that is already split (slice s = k 16 quad + 8 s .. + 7)
+  __device__ __forceinline__ void product_split(const f16x8 (&ah)[2], const f16x8 (&al)[2], f32x4 (&acc)[2]) const {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t] = mfma_split3(ah[s], al[s], h[t][s], l[t][s], acc[t]);
+      for (int t = 0; t < 2; ++t) acc[t] = mfma_split3(h[t][s], l[t][s], ah[s], al[s], acc[t]);
   }
 };
+
+// One DMA slot (4 consecutive floats of an operand row) -> [hi x4 | lo x4] halves in the same 16 bytes.
+union SplitSlot {
+  float4 f;
+  struct {
+    f16x4 hi, lo;
+  } h;
+};
+__device__ __forceinline__ float4 split_slot(float4 x) {
+  SplitSlot u;
+  const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 hi = (_Float16)v[j];
+    u.h.hi[j] = hi;
+    u.h.lo[j] = (_Float16)(v[j] - (float)hi);
+  }
+  return u.f;
+}
+// A fragments of one operand tile whose slots were converted by split_slot: four 16-byte reads.
+__device__ __forceinline__ void load_split_a(const float *tile, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2]) {
+  SplitSlot u[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    u[j].f = *reinterpret_cast<const float4 *>(tile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
 }  // namespace
 
 template <bool PAD, bool FASTG, bool F16>
@@ -225,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   WaveB<F16> bW4, bWc;
   bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad);
   bWc.load(a.w.c2_WT, 2 * FP, colbase, l15, quad);
-  float c2bias[2];
+  f32x4 c2bias[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) c2bias[t] = a.w.c2_bias[colbase + 16 * t + l15];
+  for (int t = 0; t < 2; ++t) c2bias[t] = *reinterpret_cast<const f32x4 *>(a.w.c2_bias + colbase + 16 * t + 4 * quad);
 
   // ---- VALU-phase constants: lane q4 of group grp owns columns 4q4..4q4+3 (+FP)
   const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
@@ -260,6 +298,19 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     dma16(a.node + (nrow0 + j0 + d_bl[i]) * FP + 4 * piece, dst + NG * FP);
     dma16(a.node + (nrow0 + d_a[i]) * FP + 4 * piece, dst + 2 * NG * FP);
   };
+  // Split-f16 path: once its own DMA has landed (dma_wait), every lane turns the slots IT fetched
+  // into MFMA-ready halves in place -- the edge row, and node[b] * node[a] (the c2 operand) in the
+  // node[b] tile -- so the four waves read fragments instead of each splitting the whole tile.
+  auto split_landed_tiles = [&]() {
+    if constexpr (F16) {
+      float *slot = atile + wave * 256 + lane * 4;
+      const float4 e = *reinterpret_cast<const float4 *>(slot);
+      const float4 x = *reinterpret_cast<const float4 *>(slot + NG * FP);
+      const float4 y = *reinterpret_cast<const float4 *>(slot + 2 * NG * FP);
+      *reinterpret_cast<float4 *>(slot) = split_slot(e);
+      *reinterpret_cast<float4 *>(slot + NG * FP) = split_slot(float4{x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w});
+    }
+  };
   if (sg < a.S && dcount > 0) prefetch_round(sg, 0);
 
   for (int s = sg; s < a.S; s += nsg) {
@@ -270,8 +321,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + c));
     }
     // ================= source rows: W5 edge_e by MFMA -> bufQ (raw)
-    // (batching the operand loads of several 16-row tiles, or fetching the Wi node[b_e] terms
-    //  ahead of the barrier, measured no faster: the extra registers spill)
+    // (requesting the rows of the next 16-row tile before this tile's products, or the Wi node[b_e]
+    //  terms of the centring pass one row ahead, measured 3 % and 6 % SLOWER in round 2 although
+    //  nothing spills at 253 VGPRs: the kernel is issue-bound, not waiting on these loads)
     {
       WaveB<F16> bW5;
       bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad);
@@ -285,13 +337,10 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         bW5.product(af, acc);
+        if (const int r = mt * 16 + l15; r < rows) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int r = mt * 16 + 4 * quad + rr;
-          if (r < rows) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) bufQ[r * LDQ + colbase + 16 * t + l15] = acc[t][rr];
-          }
+          for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<f32x4 *>(bufQ + r * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
         }
       }
     }
@@ -331,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       if (q4 == 0) sq[r] = ss;
     }
     dma_wait();  // round 0's operand rows (issued before the frame loop / in the last round)
+    if (s == sg && !RN_PROBE(32)) split_landed_tiles();  // (later frames: split at the end of the previous frame)
     __syncthreads();
 
     // ================= destination edges, 16 per round (one per lane group)
@@ -350,31 +400,35 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     for (int r = 0; r < nrounds; ++r) {
       // ---- MFMA: P' and c2 pre-activations of 16 destinations from the DMA'd operand rows
       if (!RN_PROBE(16)) {
-        float af[KS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 v = *reinterpret_cast<const float4 *>(atile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
-          af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
-        }
         f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        bW4.product(af, accP);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int off = l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4;
-          const float4 x = *reinterpret_cast<const float4 *>(atile + NG * FP + off);
-          const float4 y = *reinterpret_cast<const float4 *>(atile + 2 * NG * FP + off);
-          af[4 * j] = x.x * y.x; af[4 * j + 1] = x.y * y.y; af[4 * j + 2] = x.z * y.z; af[4 * j + 3] = x.w * y.w;
-        }
         f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        bWc.product(af, accC);
+        if constexpr (F16) {
+          f16x8 ah[2], al[2];
+          load_split_a(atile, l15, quad, ah, al);
+          bW4.product_split(ah, al, accP);
+          load_split_a(atile + NG * FP, l15, quad, ah, al);
+          bWc.product_split(ah, al, accC);
+        } else {
+          float af[KS];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int i = 4 * quad + rr;  // row of the 16x16 output tile held in register rr
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            bufP[i * LDQ + colbase + 16 * t + l15] = accP[t][rr];
-            bufC[i * LDQ + colbase + 16 * t + l15] = accC[t][rr] + c2bias[t];
+          for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(atile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
+            af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
           }
+          bW4.product(af, accP);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int off = l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4;
+            const float4 x = *reinterpret_cast<const float4 *>(atile + NG * FP + off);
+            const float4 y = *reinterpret_cast<const float4 *>(atile + 2 * NG * FP + off);
+            af[4 * j] = x.x * y.x; af[4 * j + 1] = x.y * y.y; af[4 * j + 2] = x.z * y.z; af[4 * j + 3] = x.w * y.w;
+          }
+          bWc.product(af, accC);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {  // row l15, columns colbase + 16 t + 4 quad .. + 3
+          *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = accP[t];
+          *reinterpret_cast<f32x4 *>(bufC + l15 * LDQ + colbase + 16 * t + 4 * quad) = accC[t] + c2bias[t];
         }
       }
       __syncthreads();  // S1: bufP / bufC complete, operand tiles free
@@ -572,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         store4(a.edge_out + drow * FP + c0, out);
       }
       dma_wait();
+      if ((r + 1 < nrounds || s + nsg < a.S) && !RN_PROBE(32)) split_landed_tiles();
       __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten; next operand rows landed
     }
   }
@@ -666,6 +721,13 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
     const int piece = (l15 ^ row) & 15;
     dma16(a.edge + ((int64_t)s * g.E + d_edge[i]) * FP + 4 * piece, atile + wave * 256);
   };
+  // Split-f16 path: as in the EdgeBlock kernel, every lane splits the slot it fetched itself.
+  auto split_landed_tiles = [&]() {
+    if constexpr (F16) {
+      float *slot = atile + wave * 256 + lane * 4;
+      *reinterpret_cast<float4 *>(slot) = split_slot(*reinterpret_cast<const float4 *>(slot));
+    }
+  };
   if (sg < a.S && dcount > 0) prefetch_round(sg, 0);
 
   for (int s = sg; s < a.S; s += nsg) {
@@ -675,21 +737,26 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
       store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.npc1 + (nrow0 + j0 + n) * (2 * FP) + c));
     }
     dma_wait();
+    if (s == sg) split_landed_tiles();  // (later frames: split at the end of the previous frame)
     __syncthreads();  // the DMA'd operand rows of round 0 (every wave's share) have landed
     for (int r = 0; r < nrounds; ++r) {
       {
-        float af[KS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 v = *reinterpret_cast<const float4 *>(atile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
-          af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
-        }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        bW.product(af, acc);
+        if constexpr (F16) {
+          f16x8 ah[2], al[2];
+          load_split_a(atile, l15, quad, ah, al);
+          bW.product_split(ah, al, acc);
+        } else {
+          float af[KS];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+          for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(atile + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
+            af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
+          }
+          bW.product(af, acc);
+        }
 #pragma unroll
-          for (int t = 0; t < 2; ++t) bufP[(4 * quad + rr) * LDQ + colbase + 16 * t + l15] = acc[t][rr];
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
       }
       __syncthreads();  // S1: bufP complete, operand tile free
       if (r + 1 < nrounds) prefetch_round(s, r + 1);
@@ -709,6 +776,7 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
         store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
       }
       dma_wait();
+      if (r + 1 < nrounds || s + nsg < a.S) split_landed_tiles();
       __syncthreads();  // S2: bufP may be rewritten, next round's operand rows landed; after the last round: gated complete
     }
     // ---- per atom: sum over its in-edges (ascending, as the reference's scatter), LayerNorm, residual
