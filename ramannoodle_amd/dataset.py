@@ -1,4 +1,12 @@
-"""Polarizability dataset for training (``ramannoodle/dataset/torch/_dataset.py``)."""
+"""Training data for the device model: what ``ramannoodle.dataset.torch.PolarizabilityDataset``
+offers to ``train_single_epoch`` (same constructor, properties, item tuple and error texts;
+``dataset/torch/_dataset.py:65-230``), organised for this package's training step.
+
+The device step takes float64 positions and gives float32 6-vectors, so the samples live here as
+contiguous numpy arrays (no per-sample expanded tensors): one lattice, one species row, the
+``(S,N,3)`` positions and the ``(S,3,3)`` polarizabilities in float64, plus the standardised
+``(S,6)`` targets in the default torch dtype.  Items are assembled on demand as views.
+"""
 from __future__ import annotations
 
 import numpy as np
@@ -9,86 +17,92 @@ from torch.utils.data import Dataset
 from ramannoodle_amd.exceptions import get_type_error, verify_ndarray_shape
 from ramannoodle_amd.pmodel.potgnn import polarizability_tensors_to_vectors
 
+# scale mode -> standardised tensor from (alpha, mean, stddev)   (_dataset.py:44-51)
+_SCALERS = {
+    "standard": lambda alpha, mean, stddev: (alpha - mean) / stddev,
+    "stddev": lambda alpha, mean, stddev: (alpha - mean) / stddev + mean,
+    "none": lambda alpha, mean, stddev: alpha,
+}
+
+
+def _population_stats(alpha: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Element-wise mean and population (``ddof = 0``) standard deviation over the samples."""
+    return alpha.mean(0, keepdim=True), alpha.std(0, unbiased=False, keepdim=True)
+
 
 def scale_and_flatten_polarizabilities(polarizabilities: torch.Tensor, scale_mode: str):
-    """Element-wise mean, population standard deviation and the scaled 6-vectors
-    ``(xx,yy,zz,xy,xz,yz)`` (``_dataset.py:21-62``).  ``scale_mode``: ``"standard"``
-    ``(a-mean)/std``, ``"stddev"`` ``(a-mean)/std+mean`` or ``"none"``."""
-    mean = polarizabilities.mean(0, keepdim=True)
-    stddev = polarizabilities.std(0, unbiased=False, keepdim=True)
-    if scale_mode == "standard":
-        polarizabilities = (polarizabilities - mean) / stddev
-    elif scale_mode == "stddev":
-        polarizabilities = (polarizabilities - mean) / stddev + mean
-    elif scale_mode != "none":
-        raise ValueError(f"unsupported scale mode: {scale_mode}")
-    return mean, stddev, polarizability_tensors_to_vectors(polarizabilities)
+    """``(mean[1,3,3], stddev[1,3,3], vectors[S,6])``: the statistics of ``polarizabilities``
+    ``[S,3,3]`` and its scaled components in the order ``(xx,yy,zz,xy,xz,yz)``.  ``scale_mode`` is
+    ``"standard"``, ``"stddev"`` or ``"none"`` (``_dataset.py:21-62``)."""
+    try:
+        scaler = _SCALERS[scale_mode]
+    except KeyError:
+        raise ValueError(f"unsupported scale mode: {scale_mode}") from None
+    mean, stddev = _population_stats(polarizabilities)
+    return mean, stddev, polarizability_tensors_to_vectors(scaler(polarizabilities, mean, stddev))
 
 
 class PolarizabilityDataset(Dataset):
-    """Structures (fractional positions ``(S,N,3)`` of one cell) with polarizabilities
-    ``(S,3,3)``, standard-scaled and flattened to 6-vectors (``_dataset.py:65-230``)."""
+    """``S`` structures of one cell (fractional positions ``(S,N,3)``) with their polarizabilities
+    ``(S,3,3)``; targets are standard-scaled 6-vectors."""
 
     def __init__(self, lattice: NDArray[np.float64], atomic_numbers: list[int],
                  positions: NDArray[np.float64], polarizabilities: NDArray[np.float64]):
         verify_ndarray_shape("lattice", lattice, (3, 3))
         if not isinstance(atomic_numbers, list):
             raise get_type_error("atomic_numbers", atomic_numbers, "list")
-        num_atoms = len(atomic_numbers)
-        verify_ndarray_shape("positions", positions, (None, num_atoms, 3))
-        num_samples = positions.shape[0]
-        verify_ndarray_shape("polarizabilities", polarizabilities, (num_samples, 3, 3))
-        dtype = torch.get_default_dtype()
-        self._lattices = torch.tensor(lattice).type(dtype).unsqueeze(0).expand(num_samples, 3, 3)
-        self._atomic_numbers = torch.tensor(atomic_numbers).type(torch.int).unsqueeze(0).expand(
-            num_samples, num_atoms)
-        self._positions = torch.tensor(positions).type(dtype)
-        self._polarizabilities = torch.tensor(polarizabilities)
-        _, _, scaled = scale_and_flatten_polarizabilities(self._polarizabilities, "standard")
-        self._scaled_polarizabilities = scaled.type(dtype)
+        verify_ndarray_shape("positions", positions, (None, len(atomic_numbers), 3))
+        verify_ndarray_shape("polarizabilities", polarizabilities, (positions.shape[0], 3, 3))
+        real = torch.get_default_dtype()
+        self._lattice = torch.as_tensor(np.array(lattice)).to(real)
+        self._species = torch.as_tensor(np.array(atomic_numbers, dtype=np.int64)).to(torch.int)
+        self._positions = torch.as_tensor(np.array(positions)).to(real)
+        self._alpha = torch.as_tensor(np.array(polarizabilities))  # keeps the caller's precision
+        self._targets = scale_and_flatten_polarizabilities(self._alpha, "standard")[2].to(real)
+
+    # ---- sizes and raw data
+    def __len__(self) -> int:
+        return self._positions.shape[0]
+
+    num_samples = property(__len__)
 
     @property
     def num_atoms(self) -> int:
-        return self._positions.size(1)
-
-    @property
-    def num_samples(self) -> int:
-        return self._positions.size(0)
+        return self._positions.shape[1]
 
     @property
     def atomic_numbers(self) -> list[int]:
-        return [int(n) for n in self._atomic_numbers[0]]
+        return self._species.tolist()
 
     @property
     def positions(self) -> NDArray[np.float64]:
-        return self._positions.detach().clone().numpy()
+        return self._positions.numpy().copy()
 
     @property
     def polarizabilities(self) -> NDArray[np.float64]:
-        return self._polarizabilities.detach().clone().numpy()
+        return self._alpha.numpy().copy()
 
+    # ---- scaling
     @property
     def scaled_polarizabilities(self) -> NDArray[np.float64]:
-        return self._scaled_polarizabilities.detach().clone().numpy()
+        return self._targets.numpy().copy()
 
     @property
     def mean_polarizability(self) -> NDArray[np.float64]:
-        return self._polarizabilities.mean(0).clone().numpy()
+        return _population_stats(self._alpha)[0][0].numpy()
 
     @property
     def stddev_polarizability(self) -> NDArray[np.float64]:
-        return self._polarizabilities.std(0, unbiased=False).clone().numpy()
+        return _population_stats(self._alpha)[1][0].numpy()
 
     def scale_polarizabilities(self, mean: NDArray[np.float64], stddev: NDArray[np.float64]) -> None:
-        """Re-standardise with the statistics of another (training) set (``:193-217``)."""
+        """Standardise the targets with the statistics of another (the training) set instead of
+        this set's own (``_dataset.py:193-217``; a validation set is scaled like its training set)."""
         verify_ndarray_shape("mean", mean, (3, 3))
-        verify_ndarray_shape("mean", stddev, (3, 3))
-        scaled = (self._polarizabilities.detach().clone() - torch.tensor(mean)) / torch.tensor(stddev)
-        self._scaled_polarizabilities = polarizability_tensors_to_vectors(scaled)
+        verify_ndarray_shape("mean", stddev, (3, 3))  # (the reference names both arguments "mean")
+        scaled = _SCALERS["standard"](self._alpha, torch.as_tensor(mean), torch.as_tensor(stddev))
+        self._targets = polarizability_tensors_to_vectors(scaled)
 
-    def __len__(self) -> int:
-        return self.num_samples
-
+    # ---- items: (lattice[3,3], atomic_numbers[N] int32, positions[N,3], target[6])
     def __getitem__(self, i: int):
-        return (self._lattices[i], self._atomic_numbers[i], self._positions[i],
-                self._scaled_polarizabilities[i])
+        return self._lattice, self._species, self._positions[i], self._targets[i]
