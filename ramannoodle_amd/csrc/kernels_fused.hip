@@ -507,9 +507,16 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             bf2[hh] = f32x2{b3f[2 * hh], b3f[2 * hh + 1]};
             bc2[hh] = f32x2{b3c[2 * hh], b3c[2 * hh + 1]};
           }
-          auto triplet = [&](int rq, float (&sumk)[4]) {
+          struct QRow {
+            float4 f, c;  // columns c0..c0+3 of the filter and core halves of one source row
+            float s;      // its |q|^2 term
+          };
+          auto load_q = [&](int rq) {
             const float *qr = bufQ + rq * LDQ + c0;
-            const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
+            return QRow{*reinterpret_cast<const float4 *>(qr), *reinterpret_cast<const float4 *>(qr + FP), sq[rq]};
+          };
+          auto triplet_q = [&](const QRow &q, float (&sumk)[4]) {
+            const float4 qfv = q.f, qcv = q.c;
             const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
             f32x2 d2 = pdf2[0] * qf2[0];
             f32x2 d3 = pdc2[0] * qc2[0];
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
             d2 += d3;
             const float dot = lg_sum<LG>(d2.x + d2.y);
-            float ve = dot + (spe + sq[rq]);
+            float ve = dot + (spe + q.s);
             ve = ve > 1e-5f ? ve : 1e-5f;
             const float rstd = fast_rsq(ve);
             const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
@@ -535,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
               sumk[2 * hh + 1] = sk.y;
             }
           };
+          auto triplet = [&](int rq, float (&sumk)[4]) { triplet_q(load_q(rq), sumk); };
 #else
           auto triplet = [&](int rq, float (&sumk)[4]) {
             const float *qr = bufQ + rq * LDQ + c0;
@@ -563,13 +571,14 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           // fills the dependency stalls of the first (summation order: even/odd partial sums)
           float acc2[4] = {0.f, 0.f, 0.f, 0.f};
           int t = t0;
+          auto row_of = [&](int tt) { return rb + tt + ((rb + tt >= rskip) ? 1 : 0); };
+          // (requesting the next pair's first row early -- a rotated loop, with or without scheduling
+          //  barriers -- measured 1-3 % slower: the other wave of the SIMD already covers this latency)
           for (; t + 1 < t1; t += 2) {
-            const int r0 = rb + t + ((rb + t >= rskip) ? 1 : 0);
-            const int r1 = rb + t + 1 + ((rb + t + 1 >= rskip) ? 1 : 0);
-            triplet(r0, acc);
-            triplet(r1, acc2);
+            triplet(row_of(t), acc);
+            triplet(row_of(t + 1), acc2);
           }
-          if (t < t1) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
+          if (t < t1) triplet(row_of(t), acc);
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
 #else
