@@ -1972,12 +1972,9 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
                         w + L.scale0, w + L.shift0, st);
     HIP_TRY(hipGetLastError());
     // the triplet loop's folded-scale variant is chosen on the host from c3_norm_1: fetch those 4 P FeP floats
-    for (const auto &q : L.pass) {
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 2 * (size_t)h->d.FeP * sizeof(float),
+    for (const auto &q : L.pass)  // (scale then shift, adjacent in the packed layout: one copy per pass)
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 4 * (size_t)h->d.FeP * sizeof(float),
                              hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_b, w + q.c3n1_b, 2 * (size_t)h->d.FeP * sizeof(float),
-                             hipMemcpyDeviceToHost, st));
-    }
     HIP_TRY(hipStreamSynchronize(st));
     refresh_pass_flags<float>(h);
     h->host_stale = true;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Everything the round's committed measurements come from, in one GPU-box call (outputs under gpurun_out/).
+#   usage: bash tools/round_end_gpu.sh
+set -uo pipefail
+root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+cd "$root"
+mkdir -p gpurun_out/final
+python -m pytest tests -x -q -m gpu > gpurun_out/final/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee gpurun_out/final/pytest_rc.txt
+tail -n 3 gpurun_out/final/pytest_gpu.log
+bash tools/profile.sh final_perf > gpurun_out/final/profile_perf.log 2>&1; echo "profile perf rc=$?"
+bash tools/profile.sh final_parity --hparams parity > gpurun_out/final/profile_parity.log 2>&1; echo "profile parity rc=$?"
+export TMPDIR=/tmp
+RN_PROBE_STEPS=12 RN_PROBE_256=1 RN_PROBE_DEVICE=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/train_prof -o train -- \
+  python3 tools/train_probe.py perf 32 > gpurun_out/final/train_probe_device.log 2>&1; echo "train profile rc=$?"
+RN_PROBE_STEPS=12 RN_PROBE_256=1 python3 tools/train_probe.py perf 32 > gpurun_out/final/train_probe_host.log 2>&1
+python3 tools/run_configs.py > gpurun_out/final/other_configs.txt 2> gpurun_out/final/other_configs.err; echo "run_configs rc=$?"
+python3 tools/spectrum_bench.py > gpurun_out/final/spectrum_bench.txt 2>&1; echo "spectrum rc=$?"
+python3 bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo "bench rc=$?"
+tail -n 1 gpurun_out/final/bench_default.json
