@@ -417,8 +417,8 @@ def main():
             # each on the f16 MFMA) in fp32-equivalent FLOP/s over the 157.3 TFLOP/s fp32 peak
             "mfma_frac": (edge_block_mfma_flops(e, fn, fe) * mine * passes * args.steps / (agg_ms * 1e-3) / 157.3e12
                           if fused and not narrow and agg_ms > 0 else None),
-            "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): ~17 VALU instructions "
-                    "incl. 3 transcendentals per (triplet, feature pair); achieved/peak/frac are the HBM "
+            "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): about 13 VALU instructions, "
+                    "3 of them transcendental, per (triplet, feature pair); achieved/peak/frac are the HBM "
                     "figures the metric asks for, issue_frac (VALU-busy + MFMA-busy share of SIMD cycles, "
                     "from the committed SQ counter pass) says what actually bounds the kernel; "
                     "roofline_nodeblock is the pass's other scatter-aggregate, the one that streams",
