@@ -322,6 +322,20 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             lib.rn_potgnn_set_profiling(handle, self._profiling)
         return handle
 
+    # -- copies and pickles carry the host state only (copy.deepcopy(model), torch.save(model)): the
+    #    device handle, its optimiser state and the data-parallel hooks belong to this object
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_state_store"] = self._state  # (fetched from the device first when that copy is ahead)
+        for key in ("_handle", "_dp_group", "_dp_callback", "_dp_installed_on"):
+            state.pop(key, None)
+        state.update(_device_ahead=False, _device_training=False, _uploaded_version=None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._handle = None
+
     def _release(self) -> None:
         if getattr(self, "_handle", None) is not None:
             _lib.load().rn_potgnn_destroy(self._handle)

@@ -177,6 +177,34 @@ def test_create_rejects_bad_arguments_without_touching_the_gpu():
     assert rc == _lib.RN_ERR_INVALID_ARGUMENT
 
 
+def test_model_copies_and_pickles_carry_host_state_only():
+    """``copy.deepcopy(model)`` / ``torch.save(model)`` (both appear around the reference's training
+    loop) work on the device model: parameters are copied, the device handle is not."""
+    import copy
+    import io
+    import torch
+    from bench import rocksalt
+    from ramannoodle_amd.pmodel import PotGNN
+    from ramannoodle_amd.structure import ReferenceStructure
+    lattice, ref, zs = rocksalt(1, 1, 1)
+    model = PotGNN(ReferenceStructure(list(zs), lattice, ref), 3.0, 5, 14, 2, 0.0, 5.0, np.eye(3), np.ones((3, 3)))
+    model._handle = ctypes.c_void_p(1234)  # what a live handle looks like to copy / pickle
+    try:
+        twin = copy.deepcopy(model)
+        buffer = io.BytesIO()
+        torch.save(model, buffer)
+    finally:
+        model._handle = None
+    buffer.seek(0)
+    loaded = torch.load(buffer, weights_only=False)
+    for other in (twin, loaded):
+        assert other._handle is None and other.num_edges == model.num_edges
+        for (ka, va), (kb, vb) in zip(model.state_dict().items(), other.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb)
+        assert other.parameters()[0] is not model.parameters()[0]
+        assert isinstance(other.parameters()[0], torch.nn.Parameter)
+
+
 def test_documented_size_limits_raise_not_implemented():
     """The two limits of the device model (DESIGN.md "Limits"): embedding sizes above 128, and
     more outgoing edges per atom than one LDS tile holds (149 at Fe = 64; the reference's
