@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 RN_PROBE_STEPS=12 RN_PROBE_256=1 RN_PROBE_DEVICE=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/train_prof -o train -- \
   python3 tools/train_probe.py perf 32 > gpurun_out/final/train_probe_device.log 2>&1; echo "train profile rc=$?"
 RN_PROBE_STEPS=12 RN_PROBE_256=1 python3 tools/train_probe.py perf 32 > gpurun_out/final/train_probe_host.log 2>&1
-python3 tools/run_configs.py > gpurun_out/final/other_configs.txt 2> gpurun_out/final/other_configs.err; echo "run_configs rc=$?"
+RN_CONFIG5_FULL=1 python3 tools/run_configs.py > gpurun_out/final/other_configs.txt 2> gpurun_out/final/other_configs.err; echo "run_configs rc=$?"
 python3 tools/spectrum_bench.py > gpurun_out/final/spectrum_bench.txt 2>&1; echo "spectrum rc=$?"
 python3 bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo "bench rc=$?"
 tail -n 1 gpurun_out/final/bench_default.json
