@@ -166,6 +166,7 @@ struct rn_potgnn {
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
   int train_prec = 4;  // sizeof of the precision it ran in
+  bool tape_fused = true;
   // device-resident optimisation (rn_potgnn_adam_step): gradients stay in f32.grad, Adam moments and
   // the trainable mask live next to the weights; the host copy `packed` is refreshed on demand
   bool device_training = false;  // BatchNorm running statistics are updated on the device
@@ -712,7 +713,7 @@ struct ChunkRun {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
         if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, h->g, h->d, w, st());
-        else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, S, h->g, h->d, w, h->mfma_f16, st());
+        else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
         launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
@@ -762,7 +763,9 @@ struct ChunkRun {
     }
     HIP_TRY(hipGetLastError());
   }
-  bool fused() const { return sizeof(T) == 4 && h->use_fused && !prec<T>(h).tape_on; }
+  // (the fused kernels also serve taped float32 runs: the EdgeBlock kernel records the one extra
+  //  array the reverse pass needs; RN_POTGNN_TAPE_FUSED=0 keeps those runs on the unfused kernels)
+  bool fused() const { return sizeof(T) == 4 && h->use_fused && (!prec<T>(h).tape_on || h->tape_fused); }
   bool narrow() const { return sizeof(T) == 4 && h->use_narrow && !prec<T>(h).tape_on; }
   T *tape_agg(int p) {  // where the EdgeBlock's pre-LayerNorm sums are recorded (taped runs only)
     Precision<T> &P = prec<T>(h);
@@ -1423,6 +1426,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   if (const char *e = getenv("RN_POTGNN_INTERLEAVE")) h->interleave = atoi(e) != 0;
   if (const char *e = getenv("RN_POTGNN_LANES")) h->num_lanes = std::max(1, std::min(2, atoi(e)));
   if (const char *e = getenv("RN_POTGNN_MFMA")) h->mfma_f16 = !(e[0] == 'f' && e[1] == '3');
+  if (const char *e = getenv("RN_POTGNN_TAPE_FUSED")) h->tape_fused = atoi(e) != 0;
 
   // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets
   h->edge_a.assign(edge_a, edge_a + E);

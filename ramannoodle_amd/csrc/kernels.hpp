@@ -179,8 +179,10 @@ void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w
                           hipStream_t st);
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
+// `agg_out` (taped runs, else null): the pre-LayerNorm triplet sums per destination edge
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
-                       int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
+                       float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
+                       hipStream_t st);
 
 // Device-resident optimisation step (kernels_train.hip); offsets index the packed weight blob.
 struct DerivedOp {

@@ -55,6 +55,7 @@ struct EdgeFusedArgs {
   float *edge_out;
   const float *node;  // updated node embedding [S*N, FP]
   const float *np3;   // [S*N, 6FP] = node * (Wi | Wj(+bias) | Wk)
+  float *agg_out;     // taped runs: the pre-LayerNorm triplet sums [S*E, FP] (what the reverse pass needs); else null
   int S;
   Graph g;
   Dims d;
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         if (active && part == 0)
           store4(a.edge_out + drow * FP + c0, Vec4<float>{{acc[0] + old.v[0], acc[1] + old.v[1], acc[2], acc[3]}});
       } else if (active && part == 0) {
+        if (a.agg_out) store4(a.agg_out + drow * FP + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
         const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
         const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
         // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
@@ -1025,9 +1027,10 @@ static void launch_cfg(const EdgeFusedArgs &a, size_t lds, hipStream_t st) {
 }
 
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
-                       int S, const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
+                       float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
+                       hipStream_t st) {
   if (S == 0 || g.E == 0) return;
-  EdgeFusedArgs a{edge_in, edge_out, node, np3, S, g, d, w};
+  EdgeFusedArgs a{edge_in, edge_out, node, np3, agg_out, S, g, d, w};
 #if RN_FUSED_PROBE
   a.probe = getenv("RN_FUSED_PROBE_MASK") ? atoi(getenv("RN_FUSED_PROBE_MASK")) : 0;
 #endif
