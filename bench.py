@@ -448,6 +448,11 @@ def main():
                 "parallelism": (f"frames sharded x{world} in contiguous blocks "
                                 f"({'strong' if strong else 'weak'} scaling), one RCCL all-gather of alpha per step"
                                 if world > 1 else "single GPU"),
+                # how the fp32 matrix products of the pass are evaluated
+                "matrix_products": ("fp32 operands split exactly into two f16 halves (22 significant bits), three "
+                                    "f16 MFMA products with fp32 accumulation; measured error vs float64 6e-7, as "
+                                    "exact-fp32 MFMA (RN_POTGNN_MFMA=f32)" if flags["split_f16_mfma"] and fused
+                                    else "fp32 scalar FMA" if narrow else "exact fp32 MFMA"),
             },
             "roofline": roofline,
             "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused, narrow),
