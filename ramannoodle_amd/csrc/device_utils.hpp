@@ -214,8 +214,16 @@ __device__ __forceinline__ void split_f16x8(const float *x, f16x8 &hi, f16x8 &lo
 // 60 000 frames repeat bit for bit (profiles/r02/determinism.txt).  The matrix pipe is a few percent
 // of these kernels' time either way.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifndef RN_MFMA_K32
+#define RN_MFMA_K32 0
+#endif
 __device__ __forceinline__ f32x4_t mfma_split3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh,
                                                const f16x8 &bl, f32x4_t acc) {
+#if RN_MFMA_K32  // experiment only (see above): one K = 32 instruction per product
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+#endif
   const f16x4 ah0 = ah.lo, ah1 = ah.hi, al0 = al.lo, al1 = al.hi;
   const f16x4 bh0 = bh.lo, bh1 = bh.hi, bl0 = bl.lo, bl1 = bl.hi;
   acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al0, bh0, acc, 0, 0, 0);
