@@ -22,11 +22,15 @@
 // Structure of one frame (S1/S2 = workgroup barriers):
 //   stage:  Q' tile by MFMA -> LDS; centre rows, |q|^2                      (2 barriers)
 //   round r (16 destination edges, one per 16-lane group):
-//     MFMA   A operands (edge row, node[b], node[a] rows of the 16 destinations) are read
+//     MFMA   A fragments of the 16 destinations' operands (edge row; node[b] * node[a]) are read
 //            from LDS tiles that the PREVIOUS round filled by LDS-DMA (global_load_lds,
-//            XOR-swizzled through the per-lane source address); P' and c2 -> LDS     S1
+//            XOR-swizzled through the per-lane source address) and that the fetching lanes
+//            turned into [hi x4 | lo x4] halves in place; the MFMAs take the weights as their
+//            A operand, so a lane ends with four consecutive columns of one row and
+//            P' and c2 -> LDS as 16-byte stores                                      S1
 //     DMA    issue the next round's (or next frame's first round's) operand rows
-//     VALU   triplet loop of the unfused kernel on LDS operands, epilogue, store     S2
+//     VALU   triplet loop (two-column packed arithmetic) on LDS operands, epilogue, store;
+//            then each lane splits the operand slots it fetched itself               S2
 // The tile topology lives in LDS for the whole launch (the graph is the same in every
 // frame), so no load inside the frame loop has a dependent address.
 #include "device_utils.hpp"
