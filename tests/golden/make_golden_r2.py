@@ -129,6 +129,45 @@ def triclinic_r2():
     np.savez_compressed(os.path.join(HERE, "triclinic20_r2.npz"), **data)
 
 
+def triclinic_randn():
+    """The reference's own batch test draws positions from N(0,1) -- far outside the unit cell
+    (``test/tests/torch/test_gnn.py:83-113``): ``forward`` of the triclinic20 model on such positions,
+    batch sizes 1..3 in one array, float32 and float64."""
+    old = np.load(os.path.join(HERE, "triclinic20.npz"))
+    rng = np.random.default_rng(404)
+    lattice, positions, zs = R1.triclinic(rng)
+    hp = dict(cutoff=3.0, fn=8, fe=12, passes=2, g0=0.0, g1=4.0)
+    rng = np.random.default_rng(404)
+    sym = rng.normal(size=(3, 3))
+    mean = (sym + sym.T) * 2.0 + np.diag([40.0, 41.0, 39.0])
+    std = np.abs(rng.normal(size=(3, 3)))
+    std = (std + std.T) * 0.5 + 0.2
+    ref, model = R1.build(lattice, positions, zs, hp, mean, std, 404, "soft", torch.float32)
+    for k, v in model.state_dict().items():
+        assert np.array_equal(v.numpy(), old["sd/" + k]), k
+    model64 = to_f64(model, lattice, positions, zs, hp, mean, std, 404, "soft")
+    torch.manual_seed(2024)
+    pos = torch.randn(6, len(zs), 3)
+    lat = torch.tensor(lattice, dtype=torch.float32).expand(6, 3, 3)
+    zz = torch.tensor(zs, dtype=torch.int).unsqueeze(0).expand(6, -1)
+    model.eval()
+    with torch.no_grad():
+        whole = model.forward(lat, zz, pos)
+        single = torch.cat([model.forward(lat[i:i + 1], zz[i:i + 1], pos[i:i + 1]) for i in range(6)])
+    assert torch.allclose(whole, single, atol=1e-5)  # the reference's own assertion
+    torch.set_default_dtype(torch.float64)
+    model64.eval()
+    with torch.no_grad():
+        whole64 = model64.forward(lat.double(), zz, pos.double())
+    torch.set_default_dtype(torch.float32)
+    assert np.isfinite(whole.numpy()).all()
+    np.savez_compressed(os.path.join(HERE, "triclinic20_randn.npz"), positions=pos.numpy(),
+                        forward=whole.numpy(), forward64=whole64.numpy(),
+                        calc=model.calc_polarizabilities(pos.numpy().astype(np.float64)))
+    print(f"triclinic20_randn: |x| up to {pos.abs().max():.2f}, f32 vs f64 "
+          f"{np.abs(whole.numpy() - whole64.numpy()).max():.2e}")
+
+
 class LinearModel(PolarizabilityModel):
     """alpha(x) = alpha0 + sum_k c_k (x - x0)_k  -- a seeded linear map, symmetric tensors."""
 
@@ -195,6 +234,10 @@ def perf256():
 
 
 if __name__ == "__main__":
-    triclinic_r2()
-    config1()
-    perf256()
+    if sys.argv[1:] == ["randn"]:  # (added after the others: leaves their files untouched)
+        triclinic_randn()
+    else:
+        triclinic_r2()
+        config1()
+        perf256()
+        triclinic_randn()

@@ -136,6 +136,27 @@ def test_forward_with_per_sample_lattices():
         model.forward(torch.tensor(r["lat/lattices"]), zs, torch.tensor(r["lat/positions"]))
 
 
+def test_forward_on_positions_far_outside_the_unit_cell():
+    """Positions drawn from N(0,1), as in the reference's own batch test
+    (``test/tests/torch/test_gnn.py:83-113``): fractional coordinates up to +-3.  Against the
+    reference's float32 and float64 outputs, whole batch and one structure at a time."""
+    g, r = load_golden("triclinic20"), load_golden("triclinic20_randn")
+    model = product_model_from_golden(g).eval()
+    s = r["positions"].shape[0]
+    lat = torch.tensor(g["lattice"], dtype=torch.float32).expand(s, 3, 3)
+    zs = torch.tensor(g["atomic_numbers"]).expand(s, -1)
+    pos = torch.tensor(r["positions"])
+    out = model.forward(lat, zs, pos).numpy()
+    scale = np.abs(r["forward64"]).max()
+    assert np.abs(out - r["forward"]).max() < REL * scale
+    assert np.abs(out - r["forward64"]).max() < REL * scale
+    for i in range(s):
+        one = model.forward(lat[i:i + 1], zs[i:i + 1], pos[i:i + 1]).numpy()
+        np.testing.assert_array_equal(one[0], out[i])
+    alpha = model.calc_polarizabilities(r["positions"].astype(np.float64))
+    assert _rel_err(alpha, r["calc"]) < REL
+
+
 def test_device_resident_entry_point():
     g = load_golden("rocksalt64_parity")
     model = product_model_from_golden(g)

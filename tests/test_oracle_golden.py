@@ -85,3 +85,21 @@ def test_forward_with_per_sample_lattices_matches_reference():
     # sample 0 carries the reference lattice: same as the plain call
     plain = O.forward(m, r["lat/positions"][:1], faithful=True).numpy()
     np.testing.assert_array_equal(plain[0], r["lat/forward"][0])
+
+
+def test_forward_on_positions_far_outside_the_unit_cell():
+    """The reference's own batch test feeds ``forward`` positions drawn from N(0,1)
+    (``test/tests/torch/test_gnn.py:83-113``): fractional coordinates up to +-3, negative ones
+    included.  Fixture: the reference's float32 and float64 outputs for such a batch
+    (tests/golden/make_golden_r2.py ``randn``)."""
+    from tests.conftest import load_golden
+    g, r = load_golden("triclinic20"), load_golden("triclinic20_randn")
+    assert np.abs(r["positions"]).max() > 2.5 and r["positions"].min() < -2.0
+    m = O.model_from_arrays(g)
+    pos = r["positions"].astype(np.float64)
+    np.testing.assert_array_equal(O.forward(m, pos, faithful=True).numpy(), r["forward"])
+    np.testing.assert_allclose(O.forward(m, pos, faithful=False).numpy(), r["forward"], rtol=0, atol=3e-7)
+    for i in range(pos.shape[0]):  # batch-size independence, the property the reference's test asserts
+        np.testing.assert_allclose(O.forward(m, pos[i:i + 1], faithful=True).numpy()[0], r["forward"][i],
+                                   rtol=0, atol=1e-5)
+
