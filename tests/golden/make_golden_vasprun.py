@@ -77,6 +77,10 @@ ROWS3 = [["0.1 0.2 0.3", "0.25 +0.5 1e-1", ".75 5. -0.125"]] * 2
 CASES = {
     "tio2_md": ("file", "/root/reference/test/data/TiO2/md_run_vasprun.xml", 6),
     "sto": ("file", "/root/reference/test/data/STO/vasprun.xml", None),
+    # the two inputs of the reference's own exception test (test/tests/test_vasprun.py:154-200):
+    # an empty <modeling> root, and a POSCAR handed over as a vasprun.xml
+    "ref_malformed": ("file", "/root/reference/test/data/malformed/vasprun.xml", None),
+    "ref_poscar_as_xml": ("file", "/root/reference/test/data/TiO2/POSCAR", None),
     "small": good,
     "number_forms": small(2, rows=[["1_0.5 inf -Infinity", "nan 1E2 2e-3", "1 2 3"], ["1 2 3", "4 5 6", "7 8 9"]]),
     "comments_cdata_entities": small(2, rows=[["0.1 <!-- c --> 0.2 0.3", "<![CDATA[0.4 0.5]]> 0.6", "&#48;.7 0.8 0.9"],
