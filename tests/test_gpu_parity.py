@@ -157,6 +157,24 @@ def test_forward_on_positions_far_outside_the_unit_cell():
     assert _rel_err(alpha, r["calc"]) < REL
 
 
+@pytest.mark.parametrize("batch_size", [50, 100, 180])
+def test_forward_and_calc_polarizabilities_agree(batch_size):
+    """The property the reference's own ``test_calc_polarizabilities`` asserts
+    (``test/tests/torch/test_gnn.py:170-193``): with mean 0 and stddev 1, ``forward`` (standardised
+    6-vectors -> tensors) and ``calc_polarizabilities`` give the same numbers on N(0,1) positions,
+    for batch sizes below, at and above the reference's 100-structure sub-batch."""
+    from ramannoodle_amd.pmodel import polarizability_vectors_to_tensors
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g, mean=np.zeros((3, 3)), stddev=np.ones((3, 3))).eval()
+    torch.manual_seed(batch_size)
+    pos = torch.randn(batch_size, model.num_atoms, 3)
+    lat = torch.tensor(g["lattice"], dtype=torch.float32).expand(batch_size, 3, 3)
+    zs = torch.tensor(g["atomic_numbers"]).expand(batch_size, -1)
+    forward = polarizability_vectors_to_tensors(model.forward(lat, zs, pos).detach().clone()).numpy()
+    calc = model.calc_polarizabilities(pos.detach().clone().numpy())
+    assert np.allclose(forward, calc, atol=1e-6)
+
+
 def test_device_resident_entry_point():
     g = load_golden("rocksalt64_parity")
     model = product_model_from_golden(g)
@@ -762,7 +780,8 @@ def test_device_adam_matches_torch_adam():
     np.testing.assert_array_equal(again, a_dev)
 
 
-def test_device_adam_through_train_single_epoch():
+@pytest.mark.parametrize("batch_size", [1, 4])  # (1: the batch size of the reference's own test_train_single_epoch)
+def test_device_adam_through_train_single_epoch(batch_size):
     """``train_single_epoch`` (``_train.py:20-91``) with the device-resident optimiser."""
     from ramannoodle_amd.pmodel import DeviceAdam, train_single_epoch
     g, host, lat, zs, pos = _load_train_case()
@@ -770,10 +789,11 @@ def test_device_adam_through_train_single_epoch():
     targets = torch.tensor(g["train/target"])
     data = torch.utils.data.TensorDataset(lat, zs, pos, targets)
     torch.manual_seed(3)
-    ref = train_single_epoch(host, data, data, 4, torch.optim.Adam(host.parameters(), lr=1e-3),
+    ref = train_single_epoch(host, data, data, batch_size, torch.optim.Adam(host.parameters(), lr=1e-3),
                              torch.nn.MSELoss())
     torch.manual_seed(3)
-    got = train_single_epoch(device, data, data, 4, DeviceAdam(device, lr=1e-3), torch.nn.MSELoss())
+    got = train_single_epoch(device, data, data, batch_size, DeviceAdam(device, lr=1e-3), torch.nn.MSELoss())
+    assert np.isfinite(ref[0]) and np.isfinite(ref[1])
     assert got[0] == pytest.approx(ref[0], rel=1e-4) and got[1] == pytest.approx(ref[1], rel=1e-4)
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-3, atol=1e-7)
 

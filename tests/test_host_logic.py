@@ -287,6 +287,57 @@ def test_corrections_and_convolution_errors():
     assert ow.shape == oi.shape == (7,)
 
 
+def test_convolve_spectrum_against_the_reference_tests_known_answers():
+    """The known-answer vectors of the reference's own ``test_convolve_intensities``
+    (``test/tests/test_phonon_spectrum.py:404-447``, data under tests/golden/ref_spectrum), with
+    that test's tolerance (``np.allclose``)."""
+    base = os.path.join(os.path.dirname(__file__), "golden", "ref_spectrum")
+    known = np.load(os.path.join(base, "known_spectrum.npz"))
+    for function in ("gaussian", "lorentzian"):
+        expected = np.load(os.path.join(base, f"known_{function}_spectrum.npz"))
+        w, i = convolve_spectrum(known["wavenumbers"], known["intensities"], function)
+        assert np.allclose(w, expected["wavenumbers"])
+        assert np.allclose(i, expected["intensities"])
+        np.testing.assert_allclose(i, expected["intensities"], rtol=1e-9, atol=1e-12 * np.abs(expected["intensities"]).max())
+
+
+@pytest.mark.parametrize("wavenumbers,intensities,function,width,out_wavenumbers,exception_type,in_reason", [
+    # the table of the reference's test_convolve_intensities_exception (test_phonon_spectrum.py:450-541)
+    (np.array([1, 2, 3]), [0, 3, 0], "gaussian", 5, None, TypeError, "intensities should have type ndarray, not list"),
+    ([1, 2, 3], np.array([0, 3, 0]), "gaussian", 5, None, TypeError, "wavenumbers should have type ndarray, not list"),
+    (np.array([1, 2, 3, 4]), np.array([0, 3, 0]), "gaussian", 5, None, ValueError,
+     "intensities has wrong shape: (3,) != (4,)"),
+    (np.array([[1, 2, 3, 5], [2, 3, 4, 5]]), np.array([0, 3, 0, 4]), "gaussian", 5, None, ValueError,
+     "wavenumbers has wrong shape: (2,4) != (_,)"),
+    (np.array([1, 2, 3]), np.array([0, 3, 0]), "smoother", 5, None, ValueError, "unsupported convolution type: smoother"),
+    (np.array([1, 2, 3]), np.array([0, 3, 0]), "gaussian", -4, None, ValueError, "invalid width: -4 <= 0"),
+    (np.array([1, 2, 3]), np.array([0, 3, 0]), "gaussian", "not_a_int", None, TypeError,
+     "width should have type float, not str"),
+    (np.array([1, 2, 3]), np.array([0, 3, 0]), "gaussian", 5.0, np.array(([1, 2], [1, 2])), ValueError,
+     "out_wavenumbers has wrong shape: (2,2) != (_,)"),
+])
+def test_convolve_spectrum_exceptions_as_the_reference(wavenumbers, intensities, function, width, out_wavenumbers,
+                                                       exception_type, in_reason):
+    import re
+    with pytest.raises(exception_type, match=re.escape(in_reason)):
+        convolve_spectrum(wavenumbers, intensities, function, width, out_wavenumbers)
+
+
+@pytest.mark.parametrize("function,argument,exception_type,in_reason", [
+    # test_get_bose_einstein_correction_exception / test_get_laser_correction (test_phonon_spectrum.py:544-618)
+    (get_bose_einstein_correction, 300, TypeError, "wavenumbers should have type ndarray, not list"),
+    (get_bose_einstein_correction, -300, ValueError, "invalid temperature: -300 <= 0"),
+    (get_bose_einstein_correction, "string temperature", TypeError, "temperature should have type float, not str"),
+    (get_laser_correction, 600, TypeError, "wavenumbers should have type ndarray, not list"),
+    (get_laser_correction, -600, ValueError, "invalid laser_wavenumber: -600 <= 0"),
+    (get_laser_correction, "string wavelength", TypeError, "laser_wavenumber should have type float, not str"),
+])
+def test_correction_exceptions_as_the_reference(function, argument, exception_type, in_reason):
+    import re
+    with pytest.raises(exception_type, match=re.escape(in_reason)):
+        function([1, 2, 3], argument)
+
+
 # ----------------------------------------------------------------------------- dynamics
 class _Raises:
     def calc_polarizabilities(self, positions_batch):
