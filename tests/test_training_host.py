@@ -43,6 +43,10 @@ def test_dataset_matches_reference():
 
 
 def test_dataset_errors_and_scale_modes():
+    # the case of the reference's test_polarizability_dataset_exception (test/tests/torch/test_dataset.py:46-71)
+    import re
+    with pytest.raises(ValueError, match=re.escape("polarizabilities has wrong shape: (2,3,3) != (3,3,3)")):
+        PolarizabilityDataset(np.zeros((3, 3)), [1, 2], np.random.random((3, 2, 3)), np.random.random((2, 3, 3)))
     with pytest.raises(ValueError, match="positions has wrong shape"):
         PolarizabilityDataset(np.eye(3), [1, 2], np.zeros((3, 5, 3)), np.zeros((3, 3, 3)))
     with pytest.raises(TypeError, match="atomic_numbers should have type list"):
