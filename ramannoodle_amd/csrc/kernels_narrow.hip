@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void readout_narrow_kernel(ReadoutNarrowArgs a
 
 // ============================================================================ launchers
 // Instantiated (Fn, Fe) pairs: the documented set first; the others are what the parity fixtures use.
-#define RN_NARROW_PAIRS(X) X(5, 14) X(6, 10) X(8, 12) X(8, 16) X(16, 16) X(3, 2)
+#define RN_NARROW_PAIRS(X) X(5, 14) X(5, 5) X(6, 10) X(8, 12) X(8, 16) X(16, 16) X(3, 2)
 
 bool narrow_supported(Dims d) {
   if (d.FnP != 16 || d.FeP != 16) return false;

@@ -9,7 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["tio2_notebook", "rocksalt64_parity", "rocksalt64_perf", "triclinic20", "rocksalt64_s205"]
+CASES = ["tio2_notebook", "rocksalt64_parity", "rocksalt64_perf", "triclinic20", "rocksalt64_s205", "tio2_gnn_test"]
 
 
 def pytest_configure(config):

@@ -168,6 +168,18 @@ def triclinic_randn():
           f"{np.abs(whole.numpy() - whole64.numpy()).max():.2e}")
 
 
+def tio2_gnn_test():
+    """The configuration of the reference's own PotGNN tests (``test/tests/torch/test_gnn.py:170-193``:
+    ``PotGNN(ref_structure, 2, 5, 5, 5, 0, 5, ...)`` on test/data/TiO2/POSCAR -- cutoff 2 A,
+    Fn = Fe = 5, five message passes), captured like the round-1 cases (same file layout)."""
+    import ramannoodle as rn
+    ref = rn.io.vasp.poscar.read_ref_structure("/root/reference/test/data/TiO2/POSCAR")
+    hp = dict(cutoff=2.0, fn=5, fe=5, passes=5, g0=0.0, g1=5.0)
+    stages = ["unit", "dist", "node0", "edge0"] + [f"{k}{p}" for p in range(1, 6) for k in ("node", "edge")] + ["pol_emb"]
+    R1.make_case("tio2_gnn_test", ref.lattice, ref.positions, ref.atomic_numbers, hp, seed=606, style="notebook",
+                 s=3, keep=stages)
+
+
 class LinearModel(PolarizabilityModel):
     """alpha(x) = alpha0 + sum_k c_k (x - x0)_k  -- a seeded linear map, symmetric tensors."""
 
@@ -236,8 +248,11 @@ def perf256():
 if __name__ == "__main__":
     if sys.argv[1:] == ["randn"]:  # (added after the others: leaves their files untouched)
         triclinic_randn()
+    elif sys.argv[1:] == ["tio2_gnn_test"]:
+        tio2_gnn_test()
     else:
         triclinic_r2()
         config1()
         perf256()
         triclinic_randn()
+        tio2_gnn_test()
