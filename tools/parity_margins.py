@@ -19,4 +19,5 @@ for case in CASES:
         rel_std = np.abs((got - want) / std).max() / np.abs((want - mean) / std).max()
         line += f"   vs reference {ref[:3]}: {rel:.1e} (standardised {rel_std:.1e})"
     flags = model.config_flags()
-    print(line + f"   fused={int(flags['fused_edge_block'])} folded_gate={int(flags['folded_gate_scale'])}")
+    print(line + f"   fused={int(flags['fused_edge_block'])} folded_gate={int(flags['folded_gate_scale'])}"
+                 f" split_f16={int(flags['split_f16_mfma'])} narrow={int(flags['narrow_kernels'])}")
