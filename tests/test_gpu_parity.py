@@ -625,7 +625,7 @@ def test_training_step_gradients_match_reference():
     assert out.requires_grad
     np.testing.assert_allclose(out.detach().numpy(), g["train/out"], rtol=0, atol=1e-5)
     loss = torch.nn.MSELoss()(out, torch.tensor(g["train/target"]))
-    assert float(loss) == pytest.approx(float(g["train/loss"]), rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(float(g["train/loss"]), rel=1e-5)
     loss.backward()
     for name, p in model.named_parameters():
         ref = g["train/grad/" + name]
