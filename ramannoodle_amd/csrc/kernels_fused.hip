@@ -72,6 +72,9 @@ struct EdgeFusedArgs {
 #ifndef RN_FUSED_PK
 #define RN_FUSED_PK 1  // packed-f32 (two columns per instruction) arithmetic in the triplet loop
 #endif
+#ifndef RN_FUSED_PRIO
+#define RN_FUSED_PRIO 3  // s_setprio level of every phase but the triplet loop (0: off); +2 % (profiles/r02/edge_phase_probe.txt)
+#endif
 #ifndef RN_FUSED_PAIRWISE
 #define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
 #endif
@@ -223,6 +226,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, quad = lane >> 4;
   const int colbase = wave * 32;  // this wave's 32 of the 128 pre-activation columns
+#if RN_FUSED_PRIO
+  __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+#endif
 
   // Workgroups of one frame group share node / np3 rows: keep them on one XCD (its L2).
   // Dispatch is round-robin over the 8 XCDs, so consecutive logical ids = same XCD.
@@ -482,6 +488,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         sp = lg_sum<LG>(sp);
 
         const int rb = d_rb[i], cnt = RN_PROBE(1) ? 0 : d_cnt[i], rskip = d_skip[i];
+#if RN_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);  // the triplet loop is always ready to issue: let the other wave's sparse phases go first
+#endif
         const int half = split ? (cnt + 1) / 2 : cnt;
         const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's triplets
         if constexpr (FASTG) {
@@ -611,6 +620,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           }
         }
       }
+#if RN_FUSED_PRIO
+      __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+#endif
       if (split) {  // second halves reach their partner through the unused rows 8..15 of bufP
         float *xch = bufP + (NG / 2 + slot) * LDQ + c0;
         if (active && part == 1) store4(xch, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});

@@ -333,6 +333,83 @@ static void run_store(const char *name, const _Float16 *frag, float *out, int bl
          store_bad<16, K32, CONSUMER>(frag, out, blocks, iters, ref));
 }
 
+// The measured MFMA issued right behind PRE other MFMAs (a backed-up matrix pipe, as in the real kernels'
+// product chains), then N wait states, then a VALU read of its result.
+template <int PAD, int K32, int PRE>
+__global__ __launch_bounds__(256) void queued(const _Float16 *frag, float *out, int iters) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f16x8 *src = reinterpret_cast<const f16x8 *>(frag) + (size_t)(blockIdx.x % 64) * 4096;
+  f16x8 a = src[(wave * 8 + 0) * 64 + lane], b = src[2048 + (wave * 8) * 64 + lane];
+  float sum = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    float r;
+#define NOPS "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+#define GAP(n) "s_nop " #n "\n\t"
+#define PRE32 "v_mfma_f32_16x16x32_f16 v[208:211], %1, %2, 0\n\tv_mfma_f32_16x16x32_f16 v[212:215], %1, %2, 0\n\t" \
+              "v_mfma_f32_16x16x32_f16 v[216:219], %1, %2, 0\n\tv_mfma_f32_16x16x32_f16 v[220:223], %1, %2, 0\n\t"
+#define PRE16 "v_mfma_f32_16x16x16_f16 v[208:211], %1, %2, 0\n\tv_mfma_f32_16x16x16_f16 v[212:215], %1, %2, 0\n\t" \
+              "v_mfma_f32_16x16x16_f16 v[216:219], %1, %2, 0\n\tv_mfma_f32_16x16x16_f16 v[220:223], %1, %2, 0\n\t"
+#define Q(PREFIX, MFMA, A, B, G)                                                                              \
+  asm volatile(NOPS PREFIX MFMA " v[204:207], %1, %2, 0\n\t" G "v_add_f32 %0, v207, %3\n\t" NOPS                \
+               : "=&v"(r) : "v"(A), "v"(B), "v"(1.0f)                                                          \
+               : "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214",      \
+                 "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223")
+#define LADDER(PREFIX, MFMA, A, B)                                   \
+  if (PAD == 7) Q(PREFIX, MFMA, A, B, GAP(6));                       \
+  else if (PAD == 8) Q(PREFIX, MFMA, A, B, GAP(7));                  \
+  else if (PAD == 9) Q(PREFIX, MFMA, A, B, GAP(8));                  \
+  else if (PAD == 10) Q(PREFIX, MFMA, A, B, GAP(9));                 \
+  else if (PAD == 12) Q(PREFIX, MFMA, A, B, GAP(11));                \
+  else if (PAD == 16) Q(PREFIX, MFMA, A, B, GAP(15));                \
+  else if (PAD == 24) Q(PREFIX, MFMA, A, B, GAP(15) GAP(7));         \
+  else if (PAD == 32) Q(PREFIX, MFMA, A, B, GAP(15) GAP(15));        \
+  else Q(PREFIX, MFMA, A, B, NOPS NOPS)
+    const f16x4 alo = a.lo, blo = b.lo;
+    if (K32) {
+      if (PRE == 0) { LADDER("", "v_mfma_f32_16x16x32_f16", a, b); }
+      else if (PRE == 4) { LADDER(PRE32, "v_mfma_f32_16x16x32_f16", a, b); }
+      else { LADDER(PRE32 PRE32, "v_mfma_f32_16x16x32_f16", a, b); }
+    } else {
+      if (PRE == 0) { LADDER("", "v_mfma_f32_16x16x16_f16", alo, blo); }
+      else if (PRE == 4) { LADDER(PRE16, "v_mfma_f32_16x16x16_f16", alo, blo); }
+      else { LADDER(PRE16 PRE16, "v_mfma_f32_16x16x16_f16", alo, blo); }
+    }
+#undef LADDER
+#undef Q
+#undef PRE16
+#undef PRE32
+#undef GAP
+#undef NOPS
+    sum += r;
+    a[it & 7] += (_Float16)0.001f;
+  }
+  out[(size_t)blockIdx.x * 256 + tid] = sum;
+}
+template <int PAD, int K32, int PRE>
+static long queued_bad(const _Float16 *frag, float *out, const std::vector<float> &ref) {
+  const size_t n = (size_t)1024 * 256;
+  std::vector<float> cur(n);
+  queued<PAD, K32, PRE><<<1024, 256>>>(frag, out, 300);
+  hipDeviceSynchronize();
+  hipMemcpy(cur.data(), out, n * sizeof(float), hipMemcpyDeviceToHost);
+  long bad = 0;
+  for (size_t i = 0; i < n; ++i) bad += std::memcmp(&ref[i], &cur[i], 4) != 0;
+  return bad;
+}
+template <int K32, int PRE>
+static void run_queued(const char *name, const _Float16 *frag, float *out) {
+  const size_t n = (size_t)1024 * 256;
+  std::vector<float> ref(n);
+  queued<200, K32, PRE><<<1024, 256>>>(frag, out, 300);
+  hipDeviceSynchronize();
+  hipMemcpy(ref.data(), out, n * sizeof(float), hipMemcpyDeviceToHost);
+  printf("  %s, %d MFMAs issued right before it -> v_add_f32 after N wait states  N=7: %ld  8: %ld  9: %ld  10: %ld  12: %ld  16: %ld  24: %ld  32: %ld\n",
+         name, PRE, queued_bad<7, K32, PRE>(frag, out, ref), queued_bad<8, K32, PRE>(frag, out, ref),
+         queued_bad<9, K32, PRE>(frag, out, ref), queued_bad<10, K32, PRE>(frag, out, ref),
+         queued_bad<12, K32, PRE>(frag, out, ref), queued_bad<16, K32, PRE>(frag, out, ref),
+         queued_bad<24, K32, PRE>(frag, out, ref), queued_bad<32, K32, PRE>(frag, out, ref));
+}
+
 // WAR: the MFMA reads v[204:207] as SrcC (or v[200:203] as SrcA); N wait states later a VALU move
 // overwrites those registers.  The MFMA result must not change.
 template <int PAD, int K32, int WHICH>
@@ -527,6 +604,12 @@ int main() {
   run_pattern<1>("K=32 compiler pattern, inline asm", frag, out, 1024, 500);
   run_movfeed(frag, out, 1024, 500);
   printf("MFMA result consumed by an LDS store; lanes (of 262144) that differ from the 64-wait-state build:\n");
+  run_queued<0, 0>("16x16x16_f16", frag, out);
+  run_queued<0, 4>("16x16x16_f16", frag, out);
+  run_queued<0, 8>("16x16x16_f16", frag, out);
+  run_queued<1, 0>("16x16x32_f16", frag, out);
+  run_queued<1, 4>("16x16x32_f16", frag, out);
+  run_queued<1, 8>("16x16x32_f16", frag, out);
   run_war<0>("16x16x16_f16", frag, out, 1024, 300);
   run_war<1>("16x16x32_f16", frag, out, 1024, 300);
   {  // the same consumers while a second wave per SIMD keeps the matrix pipe busy (N = wait states given)
