@@ -75,6 +75,12 @@ struct EdgeFusedArgs {
 #ifndef RN_FUSED_PRIO
 #define RN_FUSED_PRIO 3  // s_setprio level of every phase but the triplet loop (0: off); +2 % (profiles/r02/edge_phase_probe.txt)
 #endif
+#ifndef RN_FUSED_PRIO_LATE
+#define RN_FUSED_PRIO_LATE 0  // 1: the epilogue stays at the loop's priority (measured 0.8 % slower)
+#endif
+#ifndef RN_NODE_PRIO
+#define RN_NODE_PRIO 3  // NodeBlock kernel: priority of the MFMA phase over the gate phase (-2.7 % of its time)
+#endif
 #ifndef RN_FUSED_PAIRWISE
 #define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
 #endif
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           }
         }
       }
-#if RN_FUSED_PRIO
+#if RN_FUSED_PRIO && !RN_FUSED_PRIO_LATE
       __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
 #endif
       if (split) {  // second halves reach their partner through the unused rows 8..15 of bufP
@@ -652,6 +658,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2.v[k] + c3.v[k]);
         store4(a.edge_out + drow * FP + c0, out);
       }
+#if RN_FUSED_PRIO && RN_FUSED_PRIO_LATE
+      __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+#endif
       dma_wait();
       if ((r + 1 < nrounds || s + nsg < a.S) && !RN_PROBE(32)) split_landed_tiles();
       __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten; next operand rows landed
@@ -788,6 +797,9 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
       __syncthreads();  // S1: bufP complete, operand tile free
       if (r + 1 < nrounds) prefetch_round(s, r + 1);
       else if (s + nsg < a.S) prefetch_round(s + nsg, 0);
+#if RN_NODE_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       const int i = r * NG + grp;
       if (i < dcount) {
         const float *njr = nj + (size_t)d_bl[i] * 2 * FP + c0;
@@ -802,6 +814,9 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
         const LnParams<float> pc{load4<float>(s_c1g + FP + c0), load4<float>(s_c1b + FP + c0)};
         store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
       }
+#if RN_NODE_PRIO
+      __builtin_amdgcn_s_setprio(RN_NODE_PRIO);
+#endif
       dma_wait();
       if (r + 1 < nrounds || s + nsg < a.S) split_landed_tiles();
       __syncthreads();  // S2: bufP may be rewritten, next round's operand rows landed; after the last round: gated complete
