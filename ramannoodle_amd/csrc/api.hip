@@ -1453,8 +1453,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   // serves its tile's destination edges G at a time (G lane groups), so the budget is chosen
   // to waste as few lane groups in the last round as possible (18 in-edges per atom and
   // G = 16: 4 atoms per tile idle 10 % of the groups, 6 atoms 4 %).
-  const size_t row_bytes = (size_t)2 * d.FeP * sizeof(float);
-  const size_t cap_rows = max_out_degree(d.FeP);
+  const size_t row_bytes = (size_t)2 * d.FeP * sizeof(float);  // (the out-degree cap was checked before the device probe)
   auto build_tiles = [&](size_t budget_rows, std::vector<int> &tb) {
     tb.assign(1, 0);
     int rows = 0, max_rows = 0;

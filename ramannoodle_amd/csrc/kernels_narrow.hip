@@ -24,7 +24,6 @@ namespace rn {
 
 namespace {
 
-constexpr float kLog2e = 1.4426950408889634f;
 
 // Weights and LayerNorm parameters are read through the CONSTANT address space: they do not change
 // while a kernel runs, every index is wave-uniform, and loads from that address space are scalar
