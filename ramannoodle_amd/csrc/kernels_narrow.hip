@@ -251,6 +251,9 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
   for (int s = sg; s < a.S; s += nsg) {
     const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
     // ================= source rows Q'_e = W5 edge_e + Wi node[b_e], centred, (x gamma), |q|^2
+#if RN_NARROW_PRIO
+    __builtin_amdgcn_s_setprio(RN_NARROW_PRIO);  // the short source-row stage goes ahead of other waves' triplet loops
+#endif
     for (int r = tid; r < rows; r += 256) {
       float x[FE], nb[FN];
       load_row<FE>(a.edge_in + (erow0 + eo0 + r) * FeP, x);
@@ -285,6 +288,9 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
     __syncthreads();
 
     // ================= destination edges: one lane each
+#if RN_NARROW_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     for (int i = tid; i < dcount; i += 256) {
       const int dst = d_edge[i];
       const float *xrow = a.edge_in + (erow0 + dst) * FeP;
