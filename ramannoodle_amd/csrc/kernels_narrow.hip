@@ -93,8 +93,8 @@ __device__ __forceinline__ void ln_gate_row(const float (&x)[2 * F], cptr g, cpt
   const float rstd = fast_rsq(q * (1.0f / (2 * F)) + 1e-5f);
 #pragma unroll
   for (int k = 0; k < F; ++k) {
-    const float yf = d[k] * rstd * g[k] + b[k];
-    const float yc = d[F + k] * rstd * g[HP + k] + b[HP + k];
+    const float yf = fmaf(d[k], rstd * g[k], b[k]);  // (one scalar operand per instruction)
+    const float yc = fmaf(d[F + k], rstd * g[HP + k], b[HP + k]);
     out[k] = gate(yf, yc);
   }
 }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void ln_row1(const float (&x)[F], cptr g, cptr b, flo
   }
   const float rstd = fast_rsq(q * (1.0f / F) + 1e-5f);
 #pragma unroll
-  for (int c = 0; c < F; ++c) out[c] = d[c] * rstd * g[c] + b[c];
+  for (int c = 0; c < F; ++c) out[c] = fmaf(d[c], rstd * g[c], b[c]);
 }
 
 }  // namespace
@@ -382,8 +382,10 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
           const float rstd = fast_rsq(var + 1e-5f);
 #pragma unroll
           for (int k = 0; k < FE; ++k) {
-            const float yf = ((p[k] + q[k]) * rstd) * g3(k) + b3(k);
-            float yc = ((p[FE + k] + q[FE + k]) * rstd) * g3(FE + k) + b3(FE + k);
+            // (one scalar operand per instruction: rstd * gamma first, then an fma with beta -- the
+            //  form ((p+q) rstd) gamma + beta needs two scalars in one fma, i.e. an extra v_mov each)
+            const float yf = fmaf(p[k] + q[k], rstd * g3(k), b3(k));
+            float yc = fmaf(p[FE + k] + q[FE + k], rstd * g3(FE + k), b3(FE + k));
             yc = fminf(fmaxf(yc, -43.28f), 43.28f);
             const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
             const float t2 = 1.0f + e2;
