@@ -561,7 +561,9 @@ void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node
   const size_t lds = edge_narrow_lds_bytes(d.Fe, g.max_tile_out_rows, g.max_tile_in_rows);
   // The folded-scale triplet loop (FASTG, kernels_fused.hip) keeps 2 Fe more values per lane alive;
   // here that costs a wave per SIMD (132 vs 100 VGPRs at Fe = 14) and measured 5 % slower than the
-  // general loop (4.23 vs 4.03 us per 256-atom structure), so the general loop is always used.
+  // general loop (4.23 vs 4.03 us per 256-atom structure); forced down to 128 VGPRs (four workgroups per
+  // CU again, 16 bytes of scratch) it ties with the general loop (217 k vs 219 k structures/s) although
+  // it issues 209 instead of 257 instructions per triplet.  So the general loop is always used.
 #define X(FN, FE)                                        \
   if (d.Fn == FN && d.Fe == FE) {                        \
     launch_edge_cfg<FN, FE, false>(a, lds, st);          \
