@@ -380,6 +380,32 @@ def main():
         model.calc_polarizabilities(sample)
         host_rate = len(sample) / (time.perf_counter() - t1)
 
+    # informational (N = 1): the same step with the matrix products on the exact-fp32 MFMA instead of the
+    # split-f16 products, and how far the two outputs are apart -- so that the headline can be read
+    # against a run that makes no use of f16 at all
+    exact = None
+    if world == 1 and mine and model.config_flags()["split_f16_mfma"] and model.config_flags()["fused_edge_block"] \
+            and "RN_POTGNN_MFMA" not in os.environ:
+        os.environ["RN_POTGNN_MFMA"] = "f32"
+        try:
+            model32 = wl["model"](device=local, max_chunk_structures=args.chunk)
+            out32 = torch.zeros_like(out)
+            model32.calc_polarizabilities_device(pos, out32[:mine])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                model32.calc_polarizabilities_device(pos, out32[:mine])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+            model.calc_polarizabilities_device(pos, out[:mine])
+            torch.cuda.synchronize()
+            diff = float((out[:mine] - out32[:mine]).abs().max() / out32[:mine].abs().max())
+            exact = {"structures_per_s": mine / dt, "max_rel_diff_of_alpha": diff,
+                     "note": "RN_POTGNN_MFMA=f32: v_mfma_f32_16x16x4_f32 everywhere, no f16 operands"}
+            del model32
+        finally:
+            del os.environ["RN_POTGNN_MFMA"]
+
     if rank == 0:
         agg_ms, agg_launches = times.get("edge_agg", (0.0, 0))
         flags = model.config_flags()
@@ -458,6 +484,7 @@ def main():
             "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused, narrow),
             "roofline_projection": projection_roofline(times, e, fn, fe, mine, passes, args.steps),
             "host_buffers_structures_per_s": host_rate,
+            "exact_fp32_mfma": exact,
         }
         if args.profile_all:
             result["kernel_ms"] = {k: round(v[0], 3) for k, v in times.items()}
