@@ -935,6 +935,33 @@ def test_bench_two_ranks_contract(tmp_path):
     assert "128 atoms" in result["config"]["workload"]
 
 
+def test_bench_single_gpu_line_contract():
+    """``python bench.py`` at N = 1 (a short trajectory and a 4-frame CPU sample instead of the defaults):
+    one JSON line with every key of the bench contract, the roofline object (algorithmic figure,
+    committed traffic / issue records only when they match the workload) and the CPU baseline."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "60",
+           "--cpu-sample", "4", "--cpu-reps", "1"]
+    result = _bench_line(cmd, dict(os.environ), root)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in result, key
+    assert result["n_gpus"] == 1 and result["steps"] == 2 and result["warmup"] == 1 and result["higher_is_better"]
+    assert result["vs_baseline"] is None and result["dtype"] == "f32" and result["data"] == "synthetic"
+    assert result["value"] == pytest.approx(60 * 2 / (result["ms_per_step"] * 2e-3), rel=1e-6)
+    assert "256 atoms" in result["config"]["workload"] and result["config"]["total_frames"] == 60
+    roof = result["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0 < roof["frac"] < 1
+    assert roof["algorithmic_bytes_per_structure_pass"] == 4 * (256 * 64 + 2 * 4608 * 64)  # B_EB, SURVEY 8d
+    assert roof["traffic"] is not None and roof["issue_frac"] is not None   # committed records of this shape
+    cpu = result["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "structures/s"
+    exact = result["exact_fp32_mfma"]
+    assert exact["structures_per_s"] > 0 and exact["max_rel_diff_of_alpha"] < 1e-5
+
+
 def test_bench_starts_its_own_ranks():
     """``python bench.py --gpus 2`` with no launcher: the process starts the two ranks itself
     (before touching the GPU) and rank 0 prints the one JSON line.  Default workload = BASELINE
