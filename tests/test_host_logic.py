@@ -177,6 +177,27 @@ def test_create_rejects_bad_arguments_without_touching_the_gpu():
     assert rc == _lib.RN_ERR_INVALID_ARGUMENT
 
 
+def test_bench_refuses_to_run_without_gpus():
+    """bench.py on a machine without a GPU: no CPU fallback, and ``--gpus N`` checks the device count
+    before it starts any rank."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a GPU-less machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu"], capture_output=True, text=True,
+                         timeout=300)
+    assert one.returncode != 0 and "needs a GPU" in one.stderr
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu"],
+                         capture_output=True, text=True, timeout=300)
+    assert two.returncode != 0 and "only 0 GPU(s) visible" in two.stderr
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    clash = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--no-cpu"], env=env,
+                           capture_output=True, text=True, timeout=300)
+    assert clash.returncode != 0 and "does not match WORLD_SIZE=2" in clash.stderr
+
+
 def test_model_copies_and_pickles_carry_host_state_only():
     """``copy.deepcopy(model)`` / ``torch.save(model)`` (both appear around the reference's training
     loop) work on the device model: parameters are copied, the device handle is not."""
