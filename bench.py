@@ -281,8 +281,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
                     help="BASELINE.json workload: 3 = 256 atoms, 10k frames sharded over the GPUs "
                          "(default); 2 = 128 atoms, 1000 frames per GPU")
