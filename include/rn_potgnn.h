@@ -103,6 +103,17 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
                                     double *alpha);
 
 /*
+ * The same evaluation with every kernel instantiated for float64 -- what the reference computes
+ * when torch's default dtype is float64 (calc_polarizabilities casts lattice and positions to
+ * torch.get_default_dtype(), _gnn.py:705-710, and the modules were built in that dtype).  The
+ * float32 master weights are widened exactly; geometry, projections, LayerNorms, gates and the
+ * readout run in double.  Roughly 8x slower than the float32 path (no matrix cores, half the
+ * frames per launch); meant for validation and for callers that need more than float32 carries.
+ */
+int rn_potgnn_calc_polarizabilities_f64(rn_potgnn *h, const double *positions, int64_t S,
+                                        double *alpha);
+
+/*
  * Pipelined host entry for streamed trajectories: the call enqueues the
  * host-to-device copy of `positions` on the handle's copy stream, the evaluation behind it and the
  * device-to-host copy of the result, and returns without waiting, so that the copy of block k+1
@@ -146,6 +157,19 @@ int rn_potgnn_forward(rn_potgnn *h, const double *positions, int64_t S, float *v
  */
 int rn_potgnn_forward_lattices(rn_potgnn *h, const double *lattices, const double *positions,
                                int64_t S, float *vec6);
+
+/*
+ * PotGNN.forward(lattice[S,3,3], atomic_numbers[S,N], positions[S,N,3]) with BOTH per-sample
+ * inputs (_gnn.py:617-665): `lattices` host f64[S*9] or NULL (the reference structure's lattice
+ * for every sample); `atom_types` host int32[S*N] or NULL (the reference structure's species) --
+ * the atom TYPE of every (sample, atom), i.e. PotGNN._atom_type_map[atomic_numbers]
+ * (_convert_to_atom_type, _gnn.py:541-557), which selects the row of the node-embedding table
+ * (_gnn.py:642-643).  Types outside [0, num_atom_types) are refused (RN_ERR_INVALID_ARGUMENT): the
+ * reference's Embedding raises for them.  Graph topology stays the reference structure's.
+ * host f64 positions -> host f32[S*6] standardised 6-vectors, eval mode.
+ */
+int rn_potgnn_forward_samples(rn_potgnn *h, const double *lattices, const int32_t *atom_types,
+                              const double *positions, int64_t S, float *vec6);
 
 /*
  * Replaces the finite-difference loop of Phonons.get_raman_spectrum
@@ -275,7 +299,10 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * 64); bit 1 = every pass takes the folded-LayerNorm-scale triplet loop; bit 2 = the fused
  * kernels' matrix products run as split-f16 MFMA (default; RN_POTGNN_MFMA=f32 at create time
  * selects the exact-f32 MFMA); bit 3 = the narrow-width kernels (one lane per row; Fn, Fe <= 16 in
- * an instantiated pair, e.g. the documented Fn = 5, Fe = 14) are in use. */
+ * an instantiated pair, e.g. the documented Fn = 5, Fe = 14) are in use; bit 4 = split-f16 was
+ * requested but the range guard refused it (a non-finite weight, or readout hidden activations
+ * that the weights allow beyond 3e4): the exact-f32 MFMA instantiations run instead.  Weight
+ * matrices of any finite scale are fine: each is prescaled by a power of two into f16's range. */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

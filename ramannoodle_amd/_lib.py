@@ -49,6 +49,7 @@ SIGNATURES = {
                                    C.POINTER(_P)]),
     "rn_potgnn_destroy": (None, [_P]),
     "rn_potgnn_calc_polarizabilities": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "rn_potgnn_calc_polarizabilities_f64": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int]),
     "rn_potgnn_calc_polarizabilities_async": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_wait": (C.c_int, [_P]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rn_host_buffer_free": (None, [_P]),
     "rn_potgnn_forward": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_lattices": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "rn_potgnn_forward_samples": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
     "rn_potgnn_raman_tensors": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, _P]),
     "rn_potgnn_alpha_jacobian": (C.c_int, [_P, _P, C.c_int, _P]),
     "rn_potgnn_raman_tensors_analytic": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

@@ -85,10 +85,12 @@ struct PackedLayout {
     size_t c2_WT, c2_bias, c2n1_g, c2n1_b, c2n2_g, c2n2_b;
     size_t c3_WnT, c3_nshift, c3_WeT, c3n1_g, c3n1_b, c3n2_g, c3n2_b;
     size_t c3n1_gs, c3n1_bs;  // c3_norm_1 with the gate's exp2 scale folded in (-log2e | 2 log2e): narrow kernels
+    size_t mfma_scale;        // [8] split-f16 prescales (s, 1/s): c1_WeT | W4 | W5 | c2_WT (kernels.hpp: mfma_prescale)
     size_t t_c3We, t_c3Wn, t_c2W, t_c1We, t_c1Wn;  // transposed copies [N][K] (reverse pass)
   };
   std::vector<Pass> pass;
   size_t W0T, W3T, b3, W5T, b5, ones, b0p, t_W0, t_W3, t_W5;
+  size_t ro_mfma_scale;  // [8] split-f16 prescales (s, 1/s): W0T | W3T | W5T
   // device-computed
   size_t node_table, scale0, shift0;
   size_t total = 0;
@@ -144,7 +146,9 @@ struct rn_potgnn {
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
-  bool mfma_f16 = true;  // fused kernels: split-f16 MFMA products (RN_POTGNN_MFMA=f32: exact-f32 MFMA)
+  bool mfma_f16 = true;  // fused kernels: split-f16 MFMA products are in use (requested and inside the safe range)
+  bool mfma_f16_requested = true;   // RN_POTGNN_MFMA=f32 at create time: exact-f32 MFMA everywhere
+  bool mfma_range_fallback = false; // split-f16 was requested but the range guard (mfma_f16_range_ok) refused it
   Graph g{};
   DeviceBuf g_ints;
   double lattice[9], mean[9], stdv[9];
@@ -154,7 +158,7 @@ struct rn_potgnn {
   Precision<float> f32;
   Precision<double> f64;
   // cached I/O staging for the host entry points
-  DeviceBuf io_pos, io_alpha, io_vec6, io_lat;
+  DeviceBuf io_pos, io_alpha, io_vec6, io_lat, io_types;
   // pipelined host entry (rn_potgnn_calc_polarizabilities_async): two staging slots
   struct Slot {
     DeviceBuf pos, alpha;
@@ -210,6 +214,28 @@ inline int gated_col(int r, int F, int FP) { return r < F ? r : FP + (r - F); }
 // values (+ an index) each, have to fit a 150 KB LDS tile.  590 for FeP = 16, 149 for 64, 74 for 128.
 inline size_t max_out_degree(int FeP) { return (size_t)150 * 1024 / ((size_t)2 * FeP * sizeof(double) + 4); }
 
+// The weight blocks that enter a split-f16 matrix product and where their (s, 1/s) pair lives.
+struct MfmaScaleOp {
+  size_t src;
+  int K, N, ld;
+  size_t dst;
+};
+std::vector<MfmaScaleOp> mfma_scale_ops(const rn_potgnn *h) {
+  const PackedLayout &L = h->lay;
+  const int FnP = h->d.FnP, FeP = h->d.FeP, HP = std::max(FeP, 32);
+  std::vector<MfmaScaleOp> ops;
+  for (const auto &q : L.pass) {
+    ops.push_back({q.c1_WeT, FeP, 2 * FnP, 2 * FnP, q.mfma_scale});
+    ops.push_back({q.c3_WeT, FeP, 2 * FeP, 4 * FeP, q.mfma_scale + 2});            // W4: destination-edge part
+    ops.push_back({q.c3_WeT + 2 * FeP, FeP, 2 * FeP, 4 * FeP, q.mfma_scale + 4});  // W5: source-edge part
+    ops.push_back({q.c2_WT, FnP, 2 * FeP, 2 * FeP, q.mfma_scale + 6});
+  }
+  ops.push_back({L.W0T, FeP, HP, HP, L.ro_mfma_scale});
+  ops.push_back({L.W3T, HP, HP, HP, L.ro_mfma_scale + 2});
+  ops.push_back({L.W5T, HP, 32, 32, L.ro_mfma_scale + 4});
+  return ops;
+}
+
 void pack_weights(rn_potgnn *h, const float *w) {
   const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP,
             FeP = h->d.FeP, P = h->cfg.num_message_passes;
@@ -245,6 +271,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3n2_b = L.take(FeP);
     p.c3n1_gs = L.take(2 * FeP);
     p.c3n1_bs = L.take(2 * FeP);
+    p.mfma_scale = L.take(8);
     p.t_c3We = L.take((size_t)4 * FeP * FeP);
     p.t_c3Wn = L.take((size_t)6 * FeP * FnP);
     p.t_c2W = L.take((size_t)2 * FeP * FnP);
@@ -267,6 +294,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
   L.t_W0 = L.take((size_t)HP * FeP);
   L.t_W3 = L.take((size_t)HP * HP);
   L.t_W5 = L.take((size_t)32 * HP);
+  L.ro_mfma_scale = L.take(8);
   L.node_table = L.take((size_t)K * FnP);
   L.scale0 = L.take(HP);
   L.shift0 = L.take(HP);
@@ -371,6 +399,14 @@ void pack_weights(rn_potgnn *h, const float *w) {
     copy(L.b5, 12);
   }
   for (int i = 0; i < HP; ++i) o[L.ones + i] = 1.0f;
+  for (const MfmaScaleOp &m : mfma_scale_ops(h)) {  // power-of-two prescales of the split-f16 products
+    float mx = 0.0f;
+    for (int k = 0; k < m.K; ++k)
+      for (int n = 0; n < m.N; ++n) mx = std::max(mx, std::fabs(o[m.src + (size_t)k * m.ld + n]));
+    const float sc = mfma_prescale(mx);
+    o[m.dst] = sc;
+    o[m.dst + 1] = 1.0f / sc;
+  }
   // transposed copies: src [K][N] (row stride N) -> dst [N][K]
   auto transpose = [&](size_t src, int Kd, int Nd, size_t dst) {
     for (int k = 0; k < Kd; ++k)
@@ -418,6 +454,44 @@ size_t per_structure_elems(const rn_potgnn *h) {
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
   const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
   return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA + E * 4 * FeP;
+}
+
+// May the fused kernels run their matrix products as split-f16 MFMAs (device_utils.hpp)?
+// Weights: always -- each block is prescaled by a power of two into f16's normal range (mfma_prescale),
+// so only a non-finite weight refuses.  Activations are split unscaled, which is exact to 22 bits while
+// they stay well inside f16's range: edge rows (Gaussian basis, then tanh outputs), updated node rows
+// and their products are bounded by 1 by construction; the two hidden layers of the readout MLP
+// (shifted softplus, unbounded above) are bounded here from the weights, for |edge| <= 1:
+//   |h1_n| <= |scale0_n| sum_k |W0[n][k]| + |shift0_n|,   |h2_n| <= B1 sum_k |W3[n][k]| + |b3_n|.
+// Beyond 3e4 (f16 overflows at 65504) the handle falls back to the exact-f32 MFMA instantiations.
+bool mfma_f16_range_ok(const rn_potgnn *h) {
+  const PackedLayout &L = h->lay;
+  const float *o = h->packed.data();
+  const int Fe = h->d.Fe, HP = std::max(h->d.FeP, 32);
+  for (const MfmaScaleOp &m : mfma_scale_ops(h))
+    for (int k = 0; k < m.K; ++k)
+      for (int n = 0; n < m.N; ++n)
+        if (!std::isfinite(o[m.src + (size_t)k * m.ld + n])) return false;
+  const double ln2 = 0.6931471805599453;
+  double b1 = ln2, b2 = ln2;
+  for (int n = 0; n < Fe; ++n) {  // BatchNorm(eval) folded as setup_kernel does
+    const double sc = (double)o[L.bn_w + n] / std::sqrt((double)o[L.bn_rv + n] + 1e-5);
+    const double sh = ((double)o[L.b0 + n] - (double)o[L.bn_rm + n]) * sc + (double)o[L.bn_b + n];
+    double sum = 0;
+    for (int k = 0; k < Fe; ++k) sum += std::fabs((double)o[L.W0T + (size_t)k * HP + n]);
+    b1 = std::max(b1, std::fabs(sc) * sum + std::fabs(sh));
+  }
+  for (int n = 0; n < Fe; ++n) {
+    double sum = 0;
+    for (int k = 0; k < Fe; ++k) sum += std::fabs((double)o[L.W3T + (size_t)k * HP + n]);
+    b2 = std::max(b2, sum * b1 + std::fabs((double)o[L.b3 + n]));
+  }
+  return std::isfinite(b1) && std::isfinite(b2) && b1 <= 3.0e4 && b2 <= 3.0e4;
+}
+void refresh_mfma_mode(rn_potgnn *h) {
+  const bool ok = mfma_f16_range_ok(h);
+  h->mfma_f16 = h->mfma_f16_requested && ok;
+  h->mfma_range_fallback = h->mfma_f16_requested && !ok;
 }
 
 // Per pass: may the EdgeBlock's triplet loop fold c3_norm_1's scale into its operands and
@@ -497,9 +571,10 @@ void ensure_precision(rn_potgnn *h) {
     o.c3_norm_1 = {w + q.c3n1_g, w + q.c3n1_b};
     o.c3_norm_2 = {w + q.c3n2_g, w + q.c3n2_b};
     o.c3_norm_1s = {w + q.c3n1_gs, w + q.c3n1_bs};
+    o.mfma_scale = w + q.mfma_scale;
   }
   refresh_pass_flags<T>(h);
-  P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5};
+  P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5, w + L.ro_mfma_scale};
   P.offsets = w + L.offsets;
   P.node_table = w + L.node_table;
   P.ones = w + L.ones;
@@ -593,6 +668,7 @@ struct ChunkRun {
   float *d_vec6;
   double *d_alpha_raw;
   const T *d_lat = nullptr;  // per-frame lattices [S][9] of this chunk, or null: the reference structure's
+  const int *d_types = nullptr;  // per-frame atom types [S][N] of this chunk, or null: the reference structure's
   int cur = 0;
   T *node[2], *edge[2], *unit4, *npc1, *np3, *bufA, *bufB;
   int64_t MN, ME;
@@ -641,7 +717,7 @@ struct ChunkRun {
     }
     {
       Timer t(h, st(), K_NODE_INIT);
-      launch_node_init<T>(P.node_table, S, h->g, h->d, node[0], st());
+      launch_node_init<T>(P.node_table, S, h->g, h->d, node[0], d_types, st());
     }
     cur = 0;
     snapshot(0);
@@ -775,9 +851,10 @@ struct ChunkRun {
 
 template <typename T>
 void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_alpha,
-               float *d_vec6, double *d_alpha_raw, const T *d_lat) {
+               float *d_vec6, double *d_alpha_raw, const T *d_lat, const int *d_types) {
   ChunkRun<T> c(h, ln, d_pos, S, d_alpha, d_vec6, d_alpha_raw);
   c.d_lat = d_lat;
+  c.d_types = d_types;
   c.begin();
   for (int p = 0; p < h->cfg.num_message_passes; ++p) {
     c.stage_project(p);
@@ -813,7 +890,8 @@ void run_pair(rn_potgnn *h, ChunkRun<T> &a, ChunkRun<T> &b) {
 
 template <typename T>
 void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alpha, float *d_vec6,
-                    double *d_alpha_raw, hipStream_t user, bool sync, const T *d_lat = nullptr) {
+                    double *d_alpha_raw, hipStream_t user, bool sync, const T *d_lat = nullptr,
+                    const int *d_types = nullptr) {
   ensure_precision<T>(h);
   Precision<T> &P = prec<T>(h);
   const int N = h->cfg.num_atoms;
@@ -825,6 +903,7 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
                   d_alpha ? d_alpha + first * 9 : nullptr, d_vec6 ? d_vec6 + first * 6 : nullptr,
                   d_alpha_raw ? d_alpha_raw + first * 9 : nullptr);
     c.d_lat = d_lat ? d_lat + first * 9 : nullptr;
+    c.d_types = d_types ? d_types + first * N : nullptr;
     return c;
   };
   int64_t done = 0;
@@ -844,7 +923,7 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
       const int s = (int)std::min<int64_t>(chunk, left);
       run_chunk<T>(h, P.lanes[0], d_pos + done * N * 3, s, d_alpha ? d_alpha + done * 9 : nullptr,
                    d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr,
-                   d_lat ? d_lat + done * 9 : nullptr);
+                   d_lat ? d_lat + done * 9 : nullptr, d_types ? d_types + done * N : nullptr);
       h->last_chunk_structs = s;
       done += s;
     }
@@ -1092,6 +1171,7 @@ std::vector<DerivedOp> derived_ops(const rn_potgnn *h) {
   transpose(L.W3T, HP, HP, L.t_W3);
   transpose(L.W5T, HP, 32, L.t_W5);
   scaled(L.b0p, Fe, 1.0f, L.b0);  // the bias of readout Linear 0 lives twice (eval fold / training forward)
+  for (const MfmaScaleOp &m : mfma_scale_ops(h)) ops.push_back({2, m.K, m.N, (float)m.ld, m.src, m.dst});
   return ops;
 }
 
@@ -1107,7 +1187,8 @@ std::vector<unsigned char> trainable_mask(rn_potgnn *h) {
   const PackedLayout &L = h->lay;
   const int HP = std::max(h->d.FeP, 32);
   auto clear = [&](size_t o, size_t n) { std::fill(mask.begin() + o, mask.begin() + o + n, (unsigned char)0); };
-  for (const DerivedOp &op : derived_ops(h)) clear(op.dst, (size_t)op.K * (op.kind == 0 ? op.N : 1));
+  for (const DerivedOp &op : derived_ops(h))
+    clear(op.dst, op.kind == 2 ? 2 : (size_t)op.K * (op.kind == 0 ? op.N : 1));
   clear(L.ones, HP);
   clear(L.offsets, h->d.FeP);  // buffers of the state dict: Gaussian offsets, BatchNorm running statistics
   clear(L.bn_rm, h->d.Fe);
@@ -1425,7 +1506,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   h->debug_sync = getenv("RN_POTGNN_DEBUG_SYNC") && atoi(getenv("RN_POTGNN_DEBUG_SYNC")) != 0;
   if (const char *e = getenv("RN_POTGNN_INTERLEAVE")) h->interleave = atoi(e) != 0;
   if (const char *e = getenv("RN_POTGNN_LANES")) h->num_lanes = std::max(1, std::min(2, atoi(e)));
-  if (const char *e = getenv("RN_POTGNN_MFMA")) h->mfma_f16 = !(e[0] == 'f' && e[1] == '3');
+  if (const char *e = getenv("RN_POTGNN_MFMA")) h->mfma_f16_requested = !(e[0] == 'f' && e[1] == '3');
+  h->mfma_f16 = h->mfma_f16_requested;
   if (const char *e = getenv("RN_POTGNN_TAPE_FUSED")) h->tape_fused = atoi(e) != 0;
 
   // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets
@@ -1579,6 +1661,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     HIP_TRY(hipMemcpy(hp->d_mean_std.p, ms, sizeof(ms), hipMemcpyHostToDevice));
 
     pack_weights(hp, weights);
+    refresh_mfma_mode(hp);
     // The fused kernels (kernels_fused.hip) are the default where they apply (float32, Fn and
     // Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
     hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
@@ -1666,6 +1749,24 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
     HIP_TRY(hipMemcpy(h->io_pos.p, positions, pb, hipMemcpyHostToDevice));
     forward_device<float>(h, h->io_pos.as<double>(), S, h->io_alpha.as<double>(), nullptr, nullptr,
                           nullptr, true);
+    HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
+  });
+}
+
+int rn_potgnn_calc_polarizabilities_f64(rn_potgnn *h, const double *positions, int64_t S, double *alpha) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !alpha))) {
+    set_error(h, "invalid positions / alpha / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    sync_host(h);  // the float64 copy of the weights is made from the host master copy
+    const size_t pb = (size_t)S * h->cfg.num_atoms * 3 * sizeof(double);
+    h->io_pos.ensure(pb);
+    h->io_alpha.ensure((size_t)S * 9 * sizeof(double));
+    HIP_TRY(hipMemcpy(h->io_pos.p, positions, pb, hipMemcpyHostToDevice));
+    forward_device<double>(h, h->io_pos.as<double>(), S, h->io_alpha.as<double>(), nullptr, nullptr, nullptr, true);
     HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
   });
 }
@@ -1775,6 +1876,42 @@ int rn_potgnn_forward_lattices(rn_potgnn *h, const double *lattices, const doubl
   });
 }
 
+int rn_potgnn_forward_samples(rn_potgnn *h, const double *lattices, const int32_t *atom_types,
+                              const double *positions, int64_t S, float *vec6) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !vec6))) {
+    set_error(h, "invalid positions / vec6 / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  const size_t SN = (size_t)S * h->cfg.num_atoms;
+  if (atom_types)
+    for (size_t i = 0; i < SN; ++i)
+      if (atom_types[i] < 0 || atom_types[i] >= h->cfg.num_atom_types) {
+        set_error(h, "atom type %d of sample %zu, atom %zu is outside [0,%d)", atom_types[i],
+                  i / h->cfg.num_atoms, i % h->cfg.num_atoms, h->cfg.num_atom_types);
+        return RN_ERR_INVALID_ARGUMENT;
+      }
+  return guarded(h, [&]() {
+    h->io_pos.ensure(SN * 3 * sizeof(double));
+    h->io_vec6.ensure((size_t)S * 6 * sizeof(float));
+    HIP_TRY(hipMemcpy(h->io_pos.p, positions, SN * 3 * sizeof(double), hipMemcpyHostToDevice));
+    if (lattices) {
+      std::vector<float> lat32((size_t)S * 9);  // the reference's forward computes in float32
+      for (size_t i = 0; i < lat32.size(); ++i) lat32[i] = (float)lattices[i];
+      h->io_lat.ensure(lat32.size() * sizeof(float));
+      HIP_TRY(hipMemcpy(h->io_lat.p, lat32.data(), lat32.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (atom_types) {
+      h->io_types.ensure(SN * sizeof(int32_t));
+      HIP_TRY(hipMemcpy(h->io_types.p, atom_types, SN * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    forward_device<float>(h, h->io_pos.as<double>(), S, nullptr, h->io_vec6.as<float>(), nullptr, nullptr, true,
+                          lattices ? h->io_lat.as<float>() : nullptr, atom_types ? h->io_types.as<int>() : nullptr);
+    HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
 int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions, const double *displacements,
                             int64_t M, double delta, double *raman) {
   if (!h) return RN_ERR_INVALID_ARGUMENT;
@@ -1859,6 +1996,7 @@ int rn_potgnn_set_weights(rn_potgnn *h, const float *weights, size_t num_weights
   return guarded(h, [&]() {
     HIP_TRY(hipDeviceSynchronize());
     pack_weights(h, weights);
+    refresh_mfma_mode(h);
     h->host_stale = false;
     h->grads_on_device = false;
     if (h->f32.ready) upload_weights<float>(h);
@@ -1978,8 +2116,13 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
     for (const auto &q : L.pass)  // (scale then shift, adjacent in the packed layout: one copy per pass)
       HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 4 * (size_t)h->d.FeP * sizeof(float),
                              hipMemcpyDeviceToHost, st));
+    {  // ... and the split-f16 range guard reads the readout block (W0T .. b5, contiguous in the layout)
+      const size_t lo = L.W0T, hi = L.b5 + 32;
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + lo, w + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     refresh_pass_flags<float>(h);
+    refresh_mfma_mode(h);
     h->host_stale = true;
     h->grads_on_device = false;
   });
@@ -2048,7 +2191,8 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
-  int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0);
+  int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
+              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0);
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);

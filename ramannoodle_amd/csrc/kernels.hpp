@@ -51,6 +51,7 @@ struct PassW {
   Ln<T> c3_norm_1;   // [2FeP]
   Ln<T> c3_norm_2;   // [FeP]
   Ln<T> c3_norm_1s;  // [2FeP] c3_norm_1 times the gate's exp2 scales (-log2e on the filter half, 2 log2e on the core half)
+  const T *mfma_scale;  // [8] split-f16 prescales (s, 1/s) of c1_WeT | c3_WeT[:, W4] | c3_WeT[:, W5] | c2_WT (mfma_prescale)
   int c3_fast;       // host-side decision: c3_norm_1 admits the folded-scale triplet loop
                      // (bit 0: in the fused EdgeBlock kernel, bit 1: in edge_agg_kernel)
 };
@@ -64,7 +65,26 @@ struct ReadoutW {
   const T *b3;   // [HP]
   const T *W5T;  // [HP][32]  (12 real columns)
   const T *b5;   // [32]
+  const T *mfma_scale;  // [8] split-f16 prescales (s, 1/s) of W0T | W3T | W5T (mfma_prescale)
 };
+
+// Power-of-two prescale of a weight matrix for the split-f16 matrix products (device_utils.hpp):
+// s = 2^(12 - floor(log2 m)) for m = max |w|, so that s w lies in [2^12, 2^13) -- inside f16's
+// normal range whatever the scale of the weights, with every entry down to 2^-15 of the largest
+// one keeping its full 22 bits.  Exact (a power of two); the inverse is applied to the float32
+// accumulator.  Same bit arithmetic on the host (pack_weights) and on the device (kernels_train.hip).
+__host__ __device__ inline float mfma_prescale(float m) {
+  union { float f; unsigned u; } b;
+  b.f = m;
+  const unsigned ex = (b.u >> 23) & 0xffu;
+  if (!(m > 0.0f) || ex == 0xffu) return 1.0f;  // zero, negative, NaN, inf: leave unscaled
+  int e = (int)ex - 127;
+  if (e < -126) e = -126;
+  int se = 12 - e;
+  se = se < -126 ? -126 : (se > 126 ? 126 : se);
+  b.u = (unsigned)(se + 127) << 23;
+  return b.f;
+}
 
 struct Dims {
   int Fn, Fe, FnP, FeP;  // logical and padded (pow2 >= 16) embedding widths
@@ -82,7 +102,8 @@ void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
                      const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st);
 
 template <typename T>
-void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node, hipStream_t st);
+void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node,
+                      const int *types /* [S*N] atom type per (sample, atom), or null: g.atom_type */, hipStream_t st);
 
 // Y[M, NOUT] = act(X[M, KP] * WT[KP, NOUT] * scale + shift)
 //   amode 0: X rows are read from `X` (row stride KP)
@@ -186,7 +207,8 @@ void launch_edge_fused(const float *edge_in, float *edge_out, const float *node,
 
 // Device-resident optimisation step (kernels_train.hip); offsets index the packed weight blob.
 struct DerivedOp {
-  int kind;        // 0: transposed copy of a [K][N] block, 1: scaled copy of K values
+  int kind;        // 0: transposed copy of a [K][N] block, 1: scaled copy of K values,
+                   // 2: dst[0..1] = (s, 1/s), s = mfma_prescale(max |src[k * ld + n]|), ld = (int)scale
   int K, N;
   float scale;
   size_t src, dst;

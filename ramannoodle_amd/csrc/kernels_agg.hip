@@ -164,7 +164,7 @@ template void launch_geom_rbf<double>(const double *, int, const Graph &, const 
 // ============================================================================ node init
 template <typename T>
 __global__ void node_init_kernel(const T *__restrict__ table, int S, Graph g, Dims d,
-                                 T *__restrict__ node) {
+                                 T *__restrict__ node, const int *__restrict__ types) {
   const int c4n = d.FnP / 4;
   const int64_t total = (int64_t)S * g.N * c4n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -172,19 +172,22 @@ __global__ void node_init_kernel(const T *__restrict__ table, int S, Graph g, Di
     const int q = (int)(i % c4n);
     const int64_t rown = i / c4n;
     const int n = (int)(rown % g.N);
-    store4(node + rown * d.FnP + 4 * q, load4<T>(table + g.atom_type[n] * d.FnP + 4 * q));
+    // atom type per (sample, atom) when the caller's atomic_numbers differ between samples
+    // (_gnn.py:541-557, 642-643), else the reference structure's
+    const int ty = types ? types[rown] : g.atom_type[n];
+    store4(node + rown * d.FnP + 4 * q, load4<T>(table + ty * d.FnP + 4 * q));
   }
 }
 template <typename T>
-void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node, hipStream_t st) {
+void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node, const int *types, hipStream_t st) {
   const int64_t total = (int64_t)S * g.N * (d.FnP / 4);
   if (total == 0) return;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  node_init_kernel<T><<<blocks, 256, 0, st>>>(table, S, g, d, node);
+  node_init_kernel<T><<<blocks, 256, 0, st>>>(table, S, g, d, node, types);
 }
-template void launch_node_init<float>(const float *, int, const Graph &, Dims, float *, hipStream_t);
-template void launch_node_init<double>(const double *, int, const Graph &, Dims, double *,
+template void launch_node_init<float>(const float *, int, const Graph &, Dims, float *, const int *, hipStream_t);
+template void launch_node_init<double>(const double *, int, const Graph &, Dims, double *, const int *,
                                        hipStream_t);
 
 // ============================================================================ node block

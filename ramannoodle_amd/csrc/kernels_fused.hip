@@ -81,6 +81,9 @@ struct EdgeFusedArgs {
 #ifndef RN_NODE_PRIO
 #define RN_NODE_PRIO 3  // NodeBlock kernel: priority of the MFMA phase over the gate phase (-2.7 % of its time)
 #endif
+#ifndef RN_FUSED_NK_SAMEROUND
+#define RN_FUSED_NK_SAMEROUND 0
+#endif
 #ifndef RN_FUSED_PAIRWISE
 #define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
 #endif
@@ -135,7 +138,7 @@ struct WaveB;
 template <>
 struct WaveB<false> {  // exact f32: v_mfma_f32_16x16x4_f32, k = 16 quad + step
   float w[2][KS];
-  __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad) {
+  __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad, float /*prescale: exact f32 needs none*/) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -151,14 +154,16 @@ struct WaveB<false> {  // exact f32: v_mfma_f32_16x16x4_f32, k = 16 quad + step
 template <>
 struct WaveB<true> {  // split f16 (device_utils.hpp: mfma_split3), K = 32 slice s covers k = 16 quad + 8 s + j
   f16x8 h[2][2], l[2][2];
-  __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad) {
+  // `prescale`: the block's power-of-two mfma_prescale (kernels.hpp) -- the halves then sit in f16's
+  // normal range whatever the scale of the weights; the caller multiplies the accumulator by 1/prescale
+  __device__ __forceinline__ void load(const float *W, int ld, int colbase, int l15, int quad, float prescale) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         float tmp[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tmp[j] = W[(size_t)(quad * KS + 8 * s + j) * ld + colbase + 16 * t + l15];
+        for (int j = 0; j < 8; ++j) tmp[j] = prescale * W[(size_t)(quad * KS + 8 * s + j) * ld + colbase + 16 * t + l15];
         split_f16x8(tmp, h[t][s], l[t][s]);
       }
   }
@@ -277,9 +282,14 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 
   // ---- B fragments resident for the whole kernel: lane (n = l15, quad) holds
   //      W[k = 16 quad ..+15][colbase + 16 t + n]
+  // split-f16 products run on power-of-two prescaled weights (kernels.hpp: mfma_prescale); the inverse
+  // scales are folded into the first float32 operation on each accumulator
+  const float s4 = F16 ? a.w.mfma_scale[2] : 1.0f, inv4 = F16 ? a.w.mfma_scale[3] : 1.0f;
+  const float s5 = F16 ? a.w.mfma_scale[4] : 1.0f, inv5 = F16 ? a.w.mfma_scale[5] : 1.0f;
+  const float sc2 = F16 ? a.w.mfma_scale[6] : 1.0f, invc2 = F16 ? a.w.mfma_scale[7] : 1.0f;
   WaveB<F16> bW4, bWc;
-  bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad);
-  bWc.load(a.w.c2_WT, 2 * FP, colbase, l15, quad);
+  bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad, s4);
+  bWc.load(a.w.c2_WT, 2 * FP, colbase, l15, quad, sc2);
   f32x4 c2bias[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) c2bias[t] = *reinterpret_cast<const f32x4 *>(a.w.c2_bias + colbase + 16 * t + 4 * quad);
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
     //  nothing spills at 253 VGPRs: the kernel is issue-bound, not waiting on these loads)
     {
       WaveB<F16> bW5;
-      bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad);
+      bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad, s5);
       for (int mt = 0; mt * 16 < (RN_PROBE(4) ? 0 : rows); ++mt) {
         float af[KS];
         const float *src = a.edge_in + (erow0 + eo0 + min(mt * 16 + l15, rows - 1)) * FP + quad * KS;
@@ -371,8 +381,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f.v[i] += nf.v[i];
-        c.v[i] += nc.v[i];
+        f.v[i] = fmaf(f.v[i], inv5, nf.v[i]);
+        c.v[i] = fmaf(c.v[i], inv5, nc.v[i]);
         sum += f.v[i] + c.v[i];
       }
       const float mean = lg_sum<LG>(sum) * inv2n;
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {  // row l15, columns colbase + 16 t + 4 quad .. + 3
           *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = accP[t];
-          *reinterpret_cast<f32x4 *>(bufC + l15 * LDQ + colbase + 16 * t + 4 * quad) = accC[t] + c2bias[t];
+          *reinterpret_cast<f32x4 *>(bufC + l15 * LDQ + colbase + 16 * t + 4 * quad) = accC[t] * invc2 + c2bias[t];
         }
       }
       __syncthreads();  // S1: bufP / bufC complete, operand tiles free
@@ -466,16 +476,27 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         if (part == 0) old = load4<float>(a.edge_in + drow * FP + c0);
         float pf[4], pc[4];
         {
+#if RN_FUSED_NK_SAMEROUND
+          {
+            const float *nk = a.np3 + (nrow0 + d_a[i]) * (6 * FP) + 4 * FP + c0;
+            nkf = load4<float>(nk);
+            nkc = load4<float>(nk + FP);
+          }
+#endif
           const Vec4<float> xf = load4<float>(bufP + slot * LDQ + c0), xc = load4<float>(bufP + slot * LDQ + FP + c0);
           const Vec4<float> jf = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + c0);
           const Vec4<float> jc = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + FP + c0);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            pf[k] = xf.v[k] + nkf.v[k] + jf.v[k];
-            pc[k] = xc.v[k] + nkc.v[k] + jc.v[k];
+            pf[k] = fmaf(xf.v[k], inv4, nkf.v[k]) + jf.v[k];
+            pc[k] = fmaf(xc.v[k], inv4, nkc.v[k]) + jc.v[k];
           }
         }
+#if RN_FUSED_NK_SAMEROUND  // experiment (profiles/r03/determinism.txt): nothing per-destination crosses the MFMA phase in registers
+        if (const int inext = -1; inext >= 0) {
+#else
         if (const int inext = (r + 1 < nrounds) ? dest_index(r + 1) : -1; inext >= 0) {  // next round's Wk node[a_d]
+#endif
           const float *nk = a.np3 + (nrow0 + d_a[inext]) * (6 * FP) + 4 * FP + c0;
           nkf = load4<float>(nk);
           nkc = load4<float>(nk + FP);
@@ -743,8 +764,9 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
     d_edge[i] = e;
     d_bl[i] = g.edge_b[e] - j0;
   }
-  WaveB<F16> bW;  // B fragments of the edge part of c1_linear, resident
-  bW.load(a.w.c1_WeT, 2 * FP, colbase, l15, quad);
+  WaveB<F16> bW;  // B fragments of the edge part of c1_linear, resident (prescaled: see the EdgeBlock kernel)
+  const float s1 = F16 ? a.w.mfma_scale[0] : 1.0f, inv1 = F16 ? a.w.mfma_scale[1] : 1.0f;
+  bW.load(a.w.c1_WeT, 2 * FP, colbase, l15, quad, s1);
 
   const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
   const int nvalid = min(max(a.d.Fn - c0, 0), 4);
@@ -807,8 +829,8 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
         const Vec4<float> af = load4<float>(njr), ac = load4<float>(njr + FP);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          xf.v[k] += af.v[k];
-          xc.v[k] += ac.v[k];
+          xf.v[k] = fmaf(xf.v[k], inv1, af.v[k]);
+          xc.v[k] = fmaf(xc.v[k], inv1, ac.v[k]);
         }
         const LnParams<float> pf{load4<float>(s_c1g + c0), load4<float>(s_c1b + c0)};
         const LnParams<float> pc{load4<float>(s_c1g + FP + c0), load4<float>(s_c1b + FP + c0)};
@@ -870,6 +892,635 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
   kern<<<(unsigned)nsg * (unsigned)g.num_tiles, 256, lds, st>>>(a);
 }
 
+// ============================================================================ EdgeBlock, frame-pipelined form
+// The kernel above spends 60 % of its time outside the triplet loop, most of it waiting: per frame it
+// re-loads and re-splits W5, fetches the tile's source rows 16 at a time with the global-memory latency
+// exposed each time (as does the centring pass with its Wi node[b] rows), and only then starts its rounds
+// (profiles/r02/edge_phase_probe.txt).  This form removes every such wait from the frame:
+//   * Q' of the NEXT frame is staged while the current frame's rounds run: 16 source rows per round ride
+//     through the round's MFMA phase next to the 16 destinations' P' (W5 resident in VGPRs beside W4),
+//     are centred in the round's VALU phase and land in the other half of a double-buffered bufQ, so a
+//     frame is nothing but rounds, and every round is the same;
+//   * everything a round reads from global memory -- destination edge rows, source edge rows, the
+//     Wi node[b] rows of the centring pass, the Wk node[a] rows of P', Wj node[j] -- arrives by LDS-DMA,
+//     requested one round ahead; the VALU phase itself issues two loads (old row, c2 row) it needs only
+//     after the triplet loop;
+//   * the c2 branch (Linear -> LayerNorm -> gate -> LayerNorm of node[b] * node[a], _gnn.py:223-228)
+//     moves to edge_c2_kernel below: it is a per-edge quantity with no triplet structure, and its
+//     weight fragments are what made room for a resident W5.
+// The double buffer halves the tile (2 x rows of Q'), so the last round of a frame is usually a short one:
+// destinations are then split over 2, 4, 8 or 16 lane groups (partial sums added in a fixed order).
+struct Edge2Args {
+  const float *edge_in;
+  float *edge_out;
+  const float *np3;  // [S*N, 6FP] = node * (Wi | Wj(+bias) | Wk)
+  const float *c2;   // [S*E, FP]  the finished c2 embedding of every edge (edge_c2_kernel)
+  float *agg_out;    // taped runs: the pre-LayerNorm triplet sums [S*E, FP]; else null
+  int S;
+  Graph g;
+  Dims d;
+  PassW<float> w;
+};
+
+namespace {
+struct Edge2Lds {
+  size_t bufQ, sq, bufP, atile, npI, npK, nj, lnp, ints, total;
+};
+__host__ __device__ inline Edge2Lds edge2_lds(int maxR, int maxD, int maxN) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  Edge2Lds L;
+  size_t off = 0;
+  L.bufQ = off; off += 2 * up((size_t)maxR * LDQ * 4);   // [2][maxR][LDQ] centred source rows: this frame | next frame
+  L.sq = off; off += 2 * up((size_t)maxR * 4);           // [2][maxR] |q|^2
+  L.bufP = off; off += up((size_t)NG * LDQ * 4);         // [16][LDQ] W4 edge_d of a round
+  L.atile = off; off += 2 * (size_t)NG * FP * 4;         // 2 x [16][64] swizzled operand rows: destinations | staged sources
+  L.npI = off; off += (size_t)NG * 2 * FP * 4;           // [16][2FP] Wi node[b_e] of the staged rows
+  L.npK = off; off += (size_t)NG * 2 * FP * 4;           // [16][2FP] Wk node[a_d] of the destinations
+  L.nj = off; off += 2 * up((size_t)maxN * 2 * FP * 4);  // [2][maxN][2FP] Wj node[j] + bias: this frame | next frame
+  L.lnp = off; off += (size_t)6 * FP * 4;
+  L.ints = off; off += up(((size_t)maxR + 6 * (size_t)maxD) * 4);
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+template <bool PAD, bool FASTG, bool F16>
+__global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Graph &g = a.g;
+  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
+  const Edge2Lds L = edge2_lds(maxR, maxD, maxN);
+  float *bufQ0 = reinterpret_cast<float *>(smem_raw + L.bufQ);
+  float *sq0 = reinterpret_cast<float *>(smem_raw + L.sq);
+  const int bufQ_stride = (int)((((size_t)maxR * LDQ * 4 + 15) & ~size_t(15)) / 4);
+  const int sq_stride = (int)((((size_t)maxR * 4 + 15) & ~size_t(15)) / 4);
+  const int nj_stride = (int)((((size_t)maxN * 2 * FP * 4 + 15) & ~size_t(15)) / 4);
+  float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);
+  float *atile = reinterpret_cast<float *>(smem_raw + L.atile);
+  float *npI = reinterpret_cast<float *>(smem_raw + L.npI);
+  float *npK = reinterpret_cast<float *>(smem_raw + L.npK);
+  float *nj0 = reinterpret_cast<float *>(smem_raw + L.nj);
+  float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
+  float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_g3 = lnp + 2 * FP, *s_ig3 = lnp + 4 * FP;
+  int *qb = reinterpret_cast<int *>(smem_raw + L.ints);
+  int *d_edge = qb + maxR, *d_a = d_edge + maxD, *d_bl = d_a + maxD, *d_rb = d_bl + maxD, *d_cnt = d_rb + maxD,
+      *d_skip = d_cnt + maxD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int colbase = wave * 32;
+#if RN_FUSED_PRIO
+  __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+#endif
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.num_tiles;
+  const int sg = logical / g.num_tiles, nsg = gridDim.x / g.num_tiles;
+  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  const int nrD = (dcount + NG - 1) / NG, nrS = (rows + NG - 1) / NG;
+  const int nrounds = max(max(nrD, nrS), 1);
+
+  // ---- once per launch: LayerNorm parameters and the tile topology -> LDS
+  for (int c = tid; c < 2 * FP; c += 256) {
+    const float gam = a.w.c3_norm_1.g[c] * (c < FP ? -kLog2e : 2.0f * kLog2e);
+    s_g3[c] = gam;
+    s_ig3[c] = ((c % FP) < a.d.Fe) ? 1.0f / gam : 0.0f;
+    if (c < FP) {
+      s_c3n2g[c] = a.w.c3_norm_2.g[c];
+      s_c3n2b[c] = a.w.c3_norm_2.b[c];
+    }
+  }
+  for (int r = tid; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
+  for (int i = tid; i < dcount; i += 256) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_bl[i] = bd - j0;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+  }
+
+  // ---- weight fragments resident for the whole launch (prescaled: kernels.hpp mfma_prescale)
+  const float s4 = F16 ? a.w.mfma_scale[2] : 1.0f, inv4 = F16 ? a.w.mfma_scale[3] : 1.0f;
+  const float s5 = F16 ? a.w.mfma_scale[4] : 1.0f, inv5 = F16 ? a.w.mfma_scale[5] : 1.0f;
+  WaveB<F16> bW4, bW5;
+  bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad, s4);
+  bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad, s5);
+
+  // ---- VALU-phase constants: lane q4 of group grp owns columns 4q4..4q4+3 (+FP)
+  const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
+  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
+  const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
+  float b3f[4], b3c[4], g3f[4], g3c[4];  // c3_norm_1 with the exp2 scale of the gate folded in
+  {
+    const Vec4<float> gf = load4<float>(a.w.c3_norm_1.g + c0), bf = load4<float>(a.w.c3_norm_1.b + c0);
+    const Vec4<float> gc = load4<float>(a.w.c3_norm_1.g + FP + c0), bc = load4<float>(a.w.c3_norm_1.b + FP + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g3f[i] = -kLog2e * gf.v[i];
+      b3f[i] = -kLog2e * bf.v[i];
+      g3c[i] = 2.0f * kLog2e * gc.v[i];
+      b3c[i] = 2.0f * kLog2e * bc.v[i];
+    }
+  }
+  __syncthreads();
+
+  // ---- LDS-DMA requests.  A frame index outside [0, S) or a round beyond what the tile has: nothing is
+  //      requested (the consumers test the same conditions).  All conditions are workgroup-uniform.
+  // operand rows of the MFMA phase of round r: destinations of frame sd, staged source rows of frame ss;
+  // wave w brings rows 4w..4w+3 of each tile, slot (row, piece p) receives global piece p ^ row
+  auto request_tiles = [&](int sd, int ss, int r) {
+    const int row = 4 * wave + quad;
+    const int piece = (l15 ^ row) & 15;
+    if (sd >= 0 && sd < a.S && r < nrD) {
+      const int i = min(r * NG + row, dcount - 1);
+      dma16(a.edge_in + ((int64_t)sd * g.E + d_edge[i]) * FP + 4 * piece, atile + wave * 256);
+    }
+    if (ss < a.S && r < nrS) {
+      const int rr = min(r * NG + row, rows - 1);
+      dma16(a.edge_in + ((int64_t)ss * g.E + eo0 + rr) * FP + 4 * piece, atile + NG * FP + wave * 256);
+    }
+  };
+  // the 2FP-wide rows of np3 a round's VALU phase adds: wave w brings rows 4w..4w+3 (two per request), which
+  // are the rows its own four lane groups read -- except in rounds whose destinations are split over groups
+  auto request_npI = [&](int ss, int r) {  // Wi node[b_e] of the staged rows (np3 columns 0 .. 2FP)
+    if (!(ss < a.S && r < nrS)) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 4 * wave + 2 * j + (lane >> 5);
+      const int rr = min(r * NG + row, rows - 1);
+      dma16(a.np3 + ((int64_t)ss * g.N + qb[rr]) * (6 * FP) + 4 * (lane & 31), npI + (4 * wave + 2 * j) * 2 * FP);
+    }
+  };
+  auto request_npK = [&](int sd, int r) {  // Wk node[a_d] of the destinations (np3 columns 4FP .. 6FP)
+    if (!(sd >= 0 && sd < a.S && r < nrD)) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 4 * wave + 2 * j + (lane >> 5);
+      const int i = min(r * NG + row, dcount - 1);
+      dma16(a.np3 + ((int64_t)sd * g.N + d_a[i]) * (6 * FP) + 4 * FP + 4 * (lane & 31), npK + (4 * wave + 2 * j) * 2 * FP);
+    }
+  };
+  auto request_nj = [&](int sd, float *dst) {  // Wj node[j] + bias of the tile's atoms (np3 columns 2FP .. 4FP)
+    if (!(sd >= 0 && sd < a.S)) return;
+    for (int n0 = 2 * wave; n0 < j1 - j0; n0 += 8) {  // two atoms per request
+      const int n = min(n0 + (lane >> 5), j1 - j0 - 1);
+      dma16(a.np3 + ((int64_t)sd * g.N + j0 + n) * (6 * FP) + 2 * FP + 4 * (lane & 31), dst + n0 * 2 * FP);
+    }
+  };
+  // every lane turns the 16-byte operand slots IT fetched into [hi x4 | lo x4] in place (split-f16 path)
+  auto split_landed_tiles = [&](bool dests, bool stage) {
+    if constexpr (F16) {
+      float *slot = atile + wave * 256 + lane * 4;
+      if (dests) *reinterpret_cast<float4 *>(slot) = split_slot(*reinterpret_cast<const float4 *>(slot));
+      if (stage)
+        *reinterpret_cast<float4 *>(slot + NG * FP) = split_slot(*reinterpret_cast<const float4 *>(slot + NG * FP));
+    }
+  };
+  // A fragments of one operand tile -> this wave's 32 columns of the transposed product (see WaveB)
+  auto tile_product = [&](const float *tl, const WaveB<F16> &bw, f32x4 (&acc)[2]) {
+    if constexpr (F16) {
+      f16x8 ah[2], al[2];
+      load_split_a(tl, l15, quad, ah, al);
+      bw.product_split(ah, al, acc);
+    } else {
+      float af[KS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4 *>(tl + l15 * FP + (((4 * quad + j) ^ l15) & 15) * 4);
+        af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
+      }
+      bw.product(af, acc);
+    }
+  };
+
+  // The frame loop starts one frame early: frame sg - nsg has no destinations, its rounds only stage Q' of
+  // frame sg.  par: which half of bufQ / sq / nj holds the frame whose destinations are being served.
+  int par = 0;
+  request_tiles(-1, sg, 0);
+  request_npI(sg, 0);
+  dma_wait();
+  split_landed_tiles(false, true);
+  __syncthreads();
+
+  for (int s = sg - nsg; s < a.S; s += nsg, par ^= 1) {
+    const bool have_cur = s >= 0, have_nxt = s + nsg < a.S;
+    const int64_t erow0 = (int64_t)s * g.E;
+    float *bufQ = bufQ0 + par * bufQ_stride, *bufQn = bufQ0 + (par ^ 1) * bufQ_stride;
+    float *sq = sq0 + par * sq_stride, *sqn = sq0 + (par ^ 1) * sq_stride;
+    const float *nj = nj0 + par * nj_stride;
+
+    for (int r = 0; r < nrounds; ++r) {
+      const bool do_dest = have_cur && r < nrD, do_stage = have_nxt && r < nrS;
+      // ================= MFMA phase: P' of 16 destinations, Q' of 16 source rows of the next frame
+      if (do_dest) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        tile_product(atile, bW4, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
+      }
+      if (do_stage) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        tile_product(atile + NG * FP, bW5, acc);
+        if (const int rr = r * NG + l15; rr < rows) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<f32x4 *>(bufQn + rr * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
+        }
+      }
+      __syncthreads();  // S1: bufP and the raw Q' rows complete, operand tiles free; npI / npK of this round landed (S2 below)
+
+      // ---- what the NEXT round needs (next round of this frame pair, or round 0 of the next pair)
+      const bool wrap = r + 1 == nrounds;
+      const int sd_n = wrap ? s + nsg : s, ss_n = wrap ? s + 2 * nsg : s + nsg, r_n = wrap ? 0 : r + 1;
+      request_tiles(sd_n, ss_n, r_n);
+      if (wrap) request_nj(sd_n, nj0 + (par ^ 1) * nj_stride);
+
+      // ================= VALU phase
+      // ---- centring of the staged row of this group: add Wi node[b_e], centre, fold the gate scale, |q|^2
+      if (const int rr = r * NG + grp; do_stage && rr < rows) {
+        float *row = bufQn + rr * LDQ;
+        const float *np = npI + grp * 2 * FP + c0;
+        Vec4<float> f = load4<float>(row + c0), c = load4<float>(row + FP + c0);
+        const Vec4<float> nf = load4<float>(np), nc = load4<float>(np + FP);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f.v[i] = fmaf(f.v[i], inv5, nf.v[i]);
+          c.v[i] = fmaf(c.v[i], inv5, nc.v[i]);
+          sum += f.v[i] + c.v[i];
+        }
+        const float mean = lg_sum<LG>(sum) * inv2n;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f.v[i] = (!PAD || i < nvalid) ? f.v[i] - mean : 0.f;
+          c.v[i] = (!PAD || i < nvalid) ? c.v[i] - mean : 0.f;
+          ss += f.v[i] * f.v[i] + c.v[i] * c.v[i];
+        }
+        ss = lg_sum<LG>(ss);
+        if (FASTG) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f.v[i] *= g3f[i];
+            c.v[i] *= g3c[i];
+          }
+          ss *= inv2n;
+        }
+        store4(row + c0, f);
+        store4(row + FP + c0, c);
+        if (q4 == 0) sqn[rr] = ss;
+      }
+      // this wave's groups have consumed their npI rows: the next round's may land (wave-private rows)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      request_npI(ss_n, r_n);
+
+      // ---- destinations of this round: `parts` lane groups share one when at most 8 / 4 / 2 / 1 are left
+      const int rem = do_dest ? dcount - r * NG : 0;
+      const int parts = rem > 8 ? 1 : (rem > 4 ? 2 : (rem > 2 ? 4 : (rem > 1 ? 8 : 16)));  // uniform over the workgroup
+      const int nslots = NG / parts;
+      const int slot = grp & (nslots - 1), part = grp / nslots;
+      const bool active = slot < rem;
+      const int i = r * NG + slot;
+      const int64_t drow = active ? erow0 + d_edge[i] : 0;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      float pf[4], pc[4], sp = 0.f;
+      Vec4<float> old, c2v;
+      if (active) {
+        if (part == 0) {
+          old = load4<float>(a.edge_in + drow * FP + c0);
+          c2v = load4<float>(a.c2 + drow * FP + c0);
+        }
+        const Vec4<float> xf = load4<float>(bufP + slot * LDQ + c0), xc = load4<float>(bufP + slot * LDQ + FP + c0);
+        const Vec4<float> kf = load4<float>(npK + slot * 2 * FP + c0), kc = load4<float>(npK + slot * 2 * FP + FP + c0);
+        const Vec4<float> jf = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + c0);
+        const Vec4<float> jc = load4<float>(nj + (size_t)d_bl[i] * 2 * FP + FP + c0);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf[k] = fmaf(xf.v[k], inv4, kf.v[k]) + jf.v[k];
+          pc[k] = fmaf(xc.v[k], inv4, kc.v[k]) + jc.v[k];
+          sum += pf[k] + pc[k];
+        }
+        const float mean = lg_sum<LG>(sum) * inv2n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf[k] = (!PAD || k < nvalid) ? pf[k] - mean : 0.f;
+          pc[k] = (!PAD || k < nvalid) ? pc[k] - mean : 0.f;
+          sp += pf[k] * pf[k] + pc[k] * pc[k];
+        }
+        sp = lg_sum<LG>(sp);
+      }
+      // npK rows are wave-private unless the round is split over groups (then: after the exchange barrier below)
+      if (parts == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        request_npK(sd_n, r_n);
+      }
+      if (active) {
+        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+#if RN_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);  // the triplet loop is always ready to issue: let the other wave's sparse phases go first
+#endif
+        const int t0 = (cnt * part) / parts, t1 = (cnt * (part + 1)) / parts;  // this group's triplets
+        auto row_of = [&](int tt) { return rb + tt + ((rb + tt >= rskip) ? 1 : 0); };
+        if constexpr (FASTG) {
+          // pd = p/gamma * (2/2Fe), pg = p*gamma; var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
+          float pdf[4], pdc[4];
+          {
+            const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);
+            const float two_inv = 2.0f * inv2n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              pdf[k] = pf[k] * igf.v[k] * two_inv;
+              pdc[k] = pc[k] * igc.v[k] * two_inv;
+              pf[k] *= g3f[k];
+              pc[k] *= g3c[k];
+            }
+          }
+          const float spe = sp * inv2n + 1e-5f;
+          // two columns per instruction (v_pk_add_f32 / v_pk_fma_f32); the exp2 / rcp stay per column
+          f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2], bf2[2], bc2[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            pf2[hh] = f32x2{pf[2 * hh], pf[2 * hh + 1]};
+            pc2[hh] = f32x2{pc[2 * hh], pc[2 * hh + 1]};
+            pdf2[hh] = f32x2{pdf[2 * hh], pdf[2 * hh + 1]};
+            pdc2[hh] = f32x2{pdc[2 * hh], pdc[2 * hh + 1]};
+            bf2[hh] = f32x2{b3f[2 * hh], b3f[2 * hh + 1]};
+            bc2[hh] = f32x2{b3c[2 * hh], b3c[2 * hh + 1]};
+          }
+          auto triplet = [&](int rq, float (&sumk)[4]) {
+            const float *qr = bufQ + rq * LDQ + c0;
+            const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
+            const float qs = sq[rq];
+            const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
+            f32x2 d2 = pdf2[0] * qf2[0];
+            f32x2 d3 = pdc2[0] * qc2[0];
+            d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
+            d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
+            d2 += d3;
+            const float dot = lg_sum<LG>(d2.x + d2.y);
+            float ve = dot + (spe + qs);
+            ve = ve > 1e-5f ? ve : 1e-5f;
+            const float rstd = fast_rsq(ve);
+            const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const f32x2 xf2 = __builtin_elementwise_fma(pf2[hh] + qf2[hh], rstd2, bf2[hh]);
+              const f32x2 xc2 = __builtin_elementwise_fma(pc2[hh] + qc2[hh], rstd2, bc2[hh]);
+              const f32x2 e1 = {fast_exp2(xf2.x), fast_exp2(xf2.y)}, e2 = {fast_exp2(xc2.x), fast_exp2(xc2.y)};
+              const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+              const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
+              const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
+              f32x2 sk = {sumk[2 * hh], sumk[2 * hh + 1]};
+              sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
+              sumk[2 * hh] = sk.x;
+              sumk[2 * hh + 1] = sk.y;
+            }
+          };
+          // two independent triplets per iteration (summation order: even / odd partial sums)
+          float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+          int t = t0;
+          for (; t + 1 < t1; t += 2) {
+            triplet(row_of(t), acc);
+            triplet(row_of(t + 1), acc2);
+          }
+          if (t < t1) triplet(row_of(t), acc);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
+        } else {
+          for (int t = t0; t < t1; ++t) {
+            const int rq = row_of(t);
+            const float *qr = bufQ + rq * LDQ + c0;
+            const Vec4<float> qf = load4<float>(qr), qc = load4<float>(qr + FP);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot += pf[k] * qf.v[k] + pc[k] * qc.v[k];
+            dot = lg_sum<LG>(dot);
+            const float var = fmaxf((sp + sq[rq] + 2.0f * dot) * inv2n, 0.0f);
+            const float rstd = fast_rsq(var + 1e-5f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float yf = ((pf[k] + qf.v[k]) * rstd) * g3f[k] + b3f[k];
+              float yc = ((pc[k] + qc.v[k]) * rstd) * g3c[k] + b3c[k];
+              yc = fminf(fmaxf(yc, -43.28f), 43.28f);
+              const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
+              acc[k] += (e2 - 1.0f) * fast_rcp((1.0f + e1) * (1.0f + e2));
+            }
+          }
+        }
+      }
+#if RN_FUSED_PRIO
+      __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+#endif
+      if (parts > 1) {  // the other parts reach part 0 through rows nslots .. 15 of bufP (read by no one in a split round)
+        if (active && part > 0)
+          store4(bufP + (part * nslots + slot) * LDQ + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
+        __syncthreads();
+        request_npK(sd_n, r_n);  // every group has read its npK row before the barrier
+        if (active && part == 0) {
+          for (int p = 1; p < parts; ++p) {
+            const Vec4<float> other = load4<float>(bufP + (p * nslots + slot) * LDQ + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += other.v[k];
+          }
+        }
+      }
+      if (active && part == 0) {
+        if (a.agg_out) store4(a.agg_out + drow * FP + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
+        const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
+        const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+        Vec4<float> out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2v.v[k] + c3.v[k]);
+        store4(a.edge_out + drow * FP + c0, out);
+      }
+      dma_wait();
+      split_landed_tiles(sd_n >= 0 && sd_n < a.S && r_n < nrD, ss_n < a.S && r_n < nrS);
+      __syncthreads();  // S2: bufP may be rewritten; the next round's operand tiles and np rows have landed
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- c2 of every edge
+// _EdgeBlock._get_c2_embedding (_gnn.py:200-228):  LayerNorm_Fe(gate(LayerNorm_2Fe(c2_linear(node[b] * node[a]))))
+// for all S*E edges, with the UPDATED node embedding.  One wave per 16-row tile: the operand rows (products
+// of two gathered node rows) are split in registers, all 128 output columns of the tile come from one wave
+// (W fragments of the whole matrix resident: 128 VGPRs), pass through a wave-private LDS slab (a wave's LDS
+// operations complete in order: no barrier) into the row-per-lane-group layout, and leave as finished rows.
+struct EdgeC2Args {
+  const float *node;  // [S*N, FP] updated node embedding
+  float *c2;          // [S*E, FP]
+  int64_t M;          // S * E
+  Graph g;
+  Dims d;
+  PassW<float> w;
+};
+
+template <bool PAD, bool F16>
+__global__ __launch_bounds__(256, 2) void edge_c2_kernel(EdgeC2Args a, int tiles_per_wave) {
+  __shared__ __attribute__((aligned(16))) float slab_all[4 * NG * LDQ];
+  __shared__ __attribute__((aligned(16))) float s_ln[6 * FP];  // c2_norm_1 g | b (2FP each), c2_norm_2 g | b
+  __shared__ __attribute__((aligned(16))) float s_bias[2 * FP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  for (int c = tid; c < 2 * FP; c += 256) {
+    s_ln[c] = a.w.c2_norm_1.g[c];
+    s_ln[2 * FP + c] = a.w.c2_norm_1.b[c];
+    s_bias[c] = a.w.c2_bias[c];
+    if (c < FP) {
+      s_ln[4 * FP + c] = a.w.c2_norm_2.g[c];
+      s_ln[5 * FP + c] = a.w.c2_norm_2.b[c];
+    }
+  }
+  const float sc = F16 ? a.w.mfma_scale[6] : 1.0f, inv = F16 ? a.w.mfma_scale[7] : 1.0f;
+  WaveB<F16> bw[4];  // columns 32 j .. 32 j + 31
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bw[j].load(a.w.c2_WT, 2 * FP, 32 * j, l15, quad, sc);
+  __syncthreads();
+  float *slab = slab_all + wave * NG * LDQ;
+  const int q4 = lane & 15, c0 = 4 * q4;
+  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
+  const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
+  const LnParams<float> p1f{load4<float>(s_ln + c0), load4<float>(s_ln + 2 * FP + c0)};
+  const LnParams<float> p1c{load4<float>(s_ln + FP + c0), load4<float>(s_ln + 3 * FP + c0)};
+  const LnParams<float> p2{load4<float>(s_ln + 4 * FP + c0), load4<float>(s_ln + 5 * FP + c0)};
+  const Graph &g = a.g;
+  const int64_t num_tiles = (a.M + 15) / 16;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+
+  float nb[KS], na[KS];  // next tile's operand rows: this lane's 16 k of node[b] and node[a]
+  auto fetch = [&](int64_t tl) {
+    int64_t row = tl * 16 + l15;
+    if (row >= a.M) row = a.M - 1;
+    const int64_t s = row / g.E;
+    const int e = (int)(row - s * g.E);
+    const float *pb = a.node + (s * g.N + g.edge_b[e]) * FP + quad * KS;
+    const float *pa = a.node + (s * g.N + g.edge_a[e]) * FP + quad * KS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 x = *reinterpret_cast<const float4 *>(pb + 4 * j), y = *reinterpret_cast<const float4 *>(pa + 4 * j);
+      nb[4 * j] = x.x; nb[4 * j + 1] = x.y; nb[4 * j + 2] = x.z; nb[4 * j + 3] = x.w;
+      na[4 * j] = y.x; na[4 * j + 1] = y.y; na[4 * j + 2] = y.z; na[4 * j + 3] = y.w;
+    }
+  };
+  if (first < num_tiles) fetch(first);
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int64_t tl = first + it;
+    if (tl >= num_tiles) break;
+    float af[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) af[k] = nb[k] * na[k];
+    if (it + 1 < tiles_per_wave && tl + 1 < num_tiles) fetch(tl + 1);
+    if constexpr (F16) {
+      f16x8 ah[2], al[2];
+      split_f16x8(af, ah[0], al[0]);
+      split_f16x8(af + 8, ah[1], al[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        bw[j].product_split(ah, al, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(slab + l15 * LDQ + 32 * j + 16 * t + 4 * quad) = acc[t];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        bw[j].product(af, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(slab + l15 * LDQ + 32 * j + 16 * t + 4 * quad) = acc[t];
+      }
+    }
+    // four rows per step: lane group `quad` takes row 4 st + quad of the tile
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int rl = 4 * st + quad;
+      const float *rp = slab + rl * LDQ;
+      Vec4<float> xf = load4<float>(rp + c0), xc = load4<float>(rp + FP + c0);
+      const Vec4<float> bf = load4<float>(s_bias + c0), bc = load4<float>(s_bias + FP + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xf.v[k] = fmaf(xf.v[k], inv, bf.v[k]);
+        xc.v[k] = fmaf(xc.v[k], inv, bc.v[k]);
+      }
+      const Vec4<float> g2 = ln_gate<LG, PAD>(xf, xc, p1f, p1c, inv2n, nvalid);
+      const Vec4<float> out = ln_row<LG, PAD>(g2, p2, invn, nvalid);
+      const int64_t row = tl * 16 + rl;
+      if (row < a.M) store4(a.c2 + row * FP + c0, out);
+    }
+  }
+}
+
+size_t edge2_lds_bytes(int rows, int in_rows, int nodes) { return edge2_lds(rows, in_rows, nodes).total; }
+size_t edge2_lds_bytes(const Graph &g) { return edge2_lds_bytes(g.max_tile_out_rows, g.max_tile_in_rows, g.max_tile_nodes); }
+bool edge2_supported(const Graph &g, Dims d) {
+  return d.FnP == 64 && d.FeP == 64 && g.E > 0 && edge2_lds_bytes(g) <= kFusedLdsBudget;
+}
+
+void launch_edge_c2(const float *node, float *c2, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
+                    hipStream_t st) {
+  if (S == 0 || g.E == 0) return;
+  EdgeC2Args a{node, c2, (int64_t)S * g.E, g, d, w};
+  const int64_t tiles = (a.M + 15) / 16;
+  const int tpw = 8;
+  const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
+  const bool pad = d.Fe != d.FeP;
+  if (f16) {
+    if (pad) edge_c2_kernel<true, true><<<blocks, 256, 0, st>>>(a, tpw);
+    else edge_c2_kernel<false, true><<<blocks, 256, 0, st>>>(a, tpw);
+  } else {
+    if (pad) edge_c2_kernel<true, false><<<blocks, 256, 0, st>>>(a, tpw);
+    else edge_c2_kernel<false, false><<<blocks, 256, 0, st>>>(a, tpw);
+  }
+}
+
+template <bool PAD, bool FASTG, bool F16>
+static void launch_cfg2(const Edge2Args &a, size_t lds, hipStream_t st) {
+  auto kern = &edge_block2_kernel<PAD, FASTG, F16>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, 2);
+  int nsg = per_cu * cus / a.g.num_tiles;
+  nsg = nsg < 1 ? 1 : (nsg > a.S ? a.S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)a.g.num_tiles, 256, lds, st>>>(a);
+}
+
+void launch_edge2(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
+                  const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
+  if (S == 0 || g.E == 0) return;
+  Edge2Args a{edge_in, edge_out, np3, c2, agg_out, S, g, d, w};
+  const size_t lds = edge2_lds_bytes(g);
+  const bool pad = d.Fe != d.FeP;
+  const bool fast = (w.c3_fast & 1) != 0;
+  if (f16) {
+    if (pad) fast ? launch_cfg2<true, true, true>(a, lds, st) : launch_cfg2<true, false, true>(a, lds, st);
+    else fast ? launch_cfg2<false, true, true>(a, lds, st) : launch_cfg2<false, false, true>(a, lds, st);
+  } else {
+    if (pad) fast ? launch_cfg2<true, true, false>(a, lds, st) : launch_cfg2<true, false, false>(a, lds, st);
+    else fast ? launch_cfg2<false, true, false>(a, lds, st) : launch_cfg2<false, false, false>(a, lds, st);
+  }
+}
+
 // ============================================================================ readout MLP
 // _to_polarizability_embedding (_gnn.py:532-539) in one launch: Linear -> BatchNorm(eval, folded)
 // -> ssp -> Linear -> ssp -> Linear(12) per edge row.  The three weight matrices sit in LDS
@@ -905,17 +1556,21 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
       reinterpret_cast<float *>(raw)[n * LDW + k] = v;
     }
   };
+  // split-f16: power-of-two prescaled weights (kernels.hpp: mfma_prescale), inverse folded into the epilogues
+  const float ps0 = F16 ? a.w.mfma_scale[0] : 1.0f, inv0 = F16 ? a.w.mfma_scale[1] : 1.0f;
+  const float ps3 = F16 ? a.w.mfma_scale[2] : 1.0f, inv3 = F16 ? a.w.mfma_scale[3] : 1.0f;
+  const float ps5 = F16 ? a.w.mfma_scale[4] : 1.0f, inv5 = F16 ? a.w.mfma_scale[5] : 1.0f;
   for (int i = tid; i < FP * FP; i += 256) {
     const int k = i / FP, n = i % FP;  // W?T is [K][N] row-major
-    put(w0_raw, FP, n, k, a.w.W0T[i]);
-    put(w3_raw, FP, n, k, a.w.W3T[i]);
+    put(w0_raw, FP, n, k, ps0 * a.w.W0T[i]);
+    put(w3_raw, FP, n, k, ps3 * a.w.W3T[i]);
   }
   for (int i = tid; i < FP * 16; i += 256) {
     const int k = i / 16, n = i % 16;
-    put(w5_raw, 16, n, k, a.w.W5T[k * 32 + n]);
+    put(w5_raw, 16, n, k, ps5 * a.w.W5T[k * 32 + n]);
   }
   if (tid < FP) {
-    s_scale0[tid] = a.w.scale0[tid];
+    s_scale0[tid] = a.w.scale0[tid] * inv0;
     s_shift0[tid] = a.w.shift0[tid];
     s_b3[tid] = a.w.b3[tid];
     if (tid < 16) s_b5[tid] = a.w.b5[tid];
@@ -1000,7 +1655,7 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
       product(af, w3_raw, FP, nt, acc);
       const int col = nt * 16 + l15;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) slab[(4 * quad + rr) * LDW + col] = ssp_fast(acc[rr] + s_b3[col]);
+      for (int rr = 0; rr < 4; ++rr) slab[(4 * quad + rr) * LDW + col] = ssp_fast(fmaf(acc[rr], inv3, s_b3[col]));
     }
     load_slab(af);
     // pol = h2 W5^T + b5
@@ -1009,7 +1664,7 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int64_t row = tile * 16 + 4 * quad + rr;
-      if (row < a.M) a.pol[row * 32 + l15] = acc[rr] + s_b5[l15];
+      if (row < a.M) a.pol[row * 32 + l15] = fmaf(acc[rr], inv5, s_b5[l15]);
     }
   }
 }
@@ -1038,6 +1693,10 @@ bool edge_fused_supported(const Graph &g, Dims d) {
 template <bool PAD, bool FASTG, bool F16>
 static void launch_cfg(const EdgeFusedArgs &a, size_t lds, hipStream_t st) {
   auto kern = &edge_block_fused_kernel<PAD, FASTG, F16>;
+  // experiment knob (profiles/r03/determinism.txt): a dynamic-LDS request of at least this many KiB,
+  // e.g. 96 leaves room for ONE workgroup per CU, so no SIMD hosts waves of two workgroups
+  static const size_t min_lds = getenv("RN_POTGNN_FUSED_MIN_LDS_KB") ? (size_t)atoi(getenv("RN_POTGNN_FUSED_MIN_LDS_KB")) * 1024 : 0;
+  if (lds < min_lds) lds = min_lds;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);

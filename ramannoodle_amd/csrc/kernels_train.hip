@@ -43,9 +43,31 @@ void launch_adam(float *w, const float *g, float *m, float *v, const unsigned ch
 // one entry per derived range of the packed blob
 //   kind 0: dst[n*K + k] = src[k*N + n]   (transposed copy, src is [K][N])
 //   kind 1: dst[i] = src[i] * scale       (count = K: copies with scale 1, folded LayerNorm halves)
+//   kind 2: dst[0..1] = (s, 1/s), s = mfma_prescale(max |src[k * ld + n]|, k < K, n < N), ld = (int)scale:
+//           the power-of-two prescale of a weight block for the split-f16 matrix products
 __global__ void refresh_derived_kernel(float *__restrict__ w, const DerivedOp *__restrict__ ops, int num_ops) {
+  __shared__ float s_max[256];
   for (int o = blockIdx.x; o < num_ops; o += gridDim.x) {
     const DerivedOp op = ops[o];
+    if (op.kind == 2) {  // (uniform over the block)
+      const int ld = (int)op.scale;
+      float mx = 0.0f;
+      for (size_t i = threadIdx.x; i < (size_t)op.K * op.N; i += blockDim.x)
+        mx = fmaxf(mx, fabsf(w[op.src + (i / op.N) * ld + i % op.N]));
+      s_max[threadIdx.x] = mx;
+      __syncthreads();
+      for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + st]);
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        const float sc = mfma_prescale(s_max[0]);
+        w[op.dst] = sc;
+        w[op.dst + 1] = 1.0f / sc;
+      }
+      __syncthreads();
+      continue;
+    }
     const size_t total = (size_t)op.K * (op.kind == 0 ? op.N : 1);
     for (size_t i = threadIdx.x; i < total; i += blockDim.x) {
       if (op.kind == 0) {

@@ -53,10 +53,15 @@ def stream_polarizabilities(model, reader, chunk_frames: int = 2000) -> np.ndarr
     pinned = []
     if pipelined:
         device = model.device_index
-        pinned = [PinnedArray((chunk_frames, atoms, 3), device) for _ in range(3)]
+        # FOUR input buffers: while block k is submitted, the worker parses block k+1 into the buffer
+        # block k-3 used.  calc_polarizabilities_async(k-1) returned only after the staging slot it
+        # shares with block k-3 (two slots, alternating) had finished -- copy-in included -- so that
+        # buffer is free by construction; with three buffers the worker would write block k-2's
+        # buffer before anything had waited for block k-2's host-to-device copy.
+        pinned = [PinnedArray((chunk_frames, atoms, 3), device) for _ in range(4)]
         out_pin = PinnedArray((total, 3, 3), device)
         pinned.append(out_pin)
-        buffers, result = [p.array for p in pinned[:3]], out_pin.array
+        buffers, result = [p.array for p in pinned[:4]], out_pin.array
     else:
         buffers = [np.empty((chunk_frames, atoms, 3), dtype=np.float64) for _ in range(2)]
         result = np.empty((total, 3, 3), dtype=np.float64)
@@ -79,8 +84,8 @@ def stream_polarizabilities(model, reader, chunk_frames: int = 2000) -> np.ndarr
                 raise errors[0]
             worker = None
             if k + 1 < len(bounds):
-                # (three input buffers when pipelined: block k-1 may still be in flight on the device
-                #  while block k is submitted and block k+1 is parsed)
+                # (pipelined: blocks k-1 and k-2 may still be in flight on the device while block k is
+                #  submitted and block k+1 is parsed -- see the buffer count above)
                 worker = threading.Thread(target=parse, args=(k + 1,))
                 worker.start()
             block = buffers[k % len(buffers)][: hi - lo]

@@ -39,6 +39,17 @@ def polarizability_tensors_to_vectors(tensors):
     return tensors[:, [0, 1, 2, 0, 0, 1], [0, 1, 2, 1, 2, 2]]
 
 
+def _wants_float64(dtype) -> bool:
+    """Evaluation dtype selector: ``None`` = torch's default dtype (``_gnn.py:705``)."""
+    if dtype is None:
+        dtype = torch.get_default_dtype()
+    if dtype in (torch.float64, np.float64, float, "float64", "f64"):
+        return True
+    if dtype in (torch.float32, np.float32, "float32", "f32"):
+        return False
+    raise ValueError(f"unsupported evaluation dtype: {dtype}")
+
+
 _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
 
 
@@ -352,13 +363,22 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         verify_ndarray_shape("positions_batch", positions_batch, (None, self.num_atoms, 3))
         return np.ascontiguousarray(positions_batch, dtype=np.float64)
 
-    def calc_polarizabilities(self, positions_batch: NDArray[np.float64]) -> NDArray[np.float64]:
+    def calc_polarizabilities(self, positions_batch: NDArray[np.float64], dtype=None) -> NDArray[np.float64]:
         """Polarizabilities ``(S,3,3)`` for fractional positions ``(S,N,3)``
-        (``_gnn.py:667-721``): host arrays in, host arrays out."""
+        (``_gnn.py:667-721``): host arrays in, host arrays out.
+
+        ``dtype`` is the arithmetic the model is evaluated in.  ``None`` follows
+        ``torch.get_default_dtype()`` as the reference does (``_gnn.py:705-710``): float32 unless the
+        caller ran ``torch.set_default_dtype(torch.float64)``; ``torch.float64`` / ``numpy.float64``
+        selects the kernels instantiated for ``double`` (``rn_potgnn_calc_polarizabilities_f64``)."""
         pos = self._check_positions(positions_batch)
         self.eval()  # as the reference does (_gnn.py:686)
         out = np.empty((pos.shape[0], 3, 3), dtype=np.float64)
         handle = self._ensure_handle()
+        if _wants_float64(dtype):
+            rc = _lib.load().rn_potgnn_calc_polarizabilities_f64(handle, _ptr(pos), pos.shape[0], _ptr(out))
+            _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities_f64")
+            return out
         rc = _lib.load().rn_potgnn_calc_polarizabilities(handle, _ptr(pos), pos.shape[0], _ptr(out))
         _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities")
         return out
@@ -414,37 +434,47 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
 
     def forward(self, lattice, atomic_numbers, positions) -> torch.Tensor:
         """Standardised 6-vectors ``[S,6]`` (``_gnn.py:617-665``).  ``lattice`` ``[S,3,3]`` is
-        used per sample in the geometry, as the reference does (``_gnn.py:603-611``); the graph
-        topology is the reference structure's.  ``atomic_numbers`` ``[S,N]`` must repeat the
-        reference structure's species (the frozen graph and the per-type embedding table of the
-        device model are built from them)."""
+        used per sample in the geometry, as the reference does (``_gnn.py:603-611``), and
+        ``atomic_numbers`` ``[S,N]`` per sample for the node embedding
+        (``_convert_to_atom_type``, ``_gnn.py:541-557,642-643``); the graph topology is the
+        reference structure's.  An atomic number the model has no atom type for raises
+        ``IndexError``, as the reference's ``Embedding`` does."""
         pos = np.ascontiguousarray(torch.as_tensor(positions).detach().cpu().numpy(), dtype=np.float64)
         verify_ndarray_shape("positions", pos, (None, self.num_atoms, 3))
         lat = np.ascontiguousarray(torch.as_tensor(lattice).detach().cpu().numpy(), dtype=np.float64)
         zs = torch.as_tensor(atomic_numbers).detach().cpu().numpy()
         if lat.shape != (pos.shape[0], 3, 3) or zs.shape != (pos.shape[0], self.num_atoms):
             raise ValueError("lattice / atomic_numbers do not match positions")
-        if pos.shape[0] and not np.array_equal(zs, np.broadcast_to(
-                np.asarray(self._ref_structure.atomic_numbers), zs.shape)):
-            raise NotImplementedError("atomic_numbers that differ from the reference structure's "
-                                      "are not supported")
+        same_species = (not pos.shape[0]) or np.array_equal(zs, np.broadcast_to(
+            np.asarray(self._ref_structure.atomic_numbers), zs.shape))
         same_lattice = (not pos.shape[0]) or np.allclose(lat, self._ref_structure.lattice[None],
                                                          rtol=1e-6, atol=1e-9)
         if self.training:
-            if not same_lattice:
-                raise NotImplementedError("training mode supports only the reference structure's "
-                                          "lattice (PolarizabilityDataset holds a single lattice)")
+            if not same_lattice or not same_species:
+                raise NotImplementedError("training mode supports only the reference structure's lattice "
+                                          "and species (PolarizabilityDataset holds a single structure)")
             if self._device_training:  # gradients stay in HBM: nothing for autograd to route
                 return _TrainStep.apply(self, pos, self._device_anchor)
             return _TrainStep.apply(self, pos, *self.parameters())
         out = np.empty((pos.shape[0], 6), dtype=np.float32)
         handle = self._ensure_handle()
-        if same_lattice:
+        if same_lattice and same_species:
             rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), pos.shape[0], _ptr(out))
             _lib.check(rc, handle, "rn_potgnn_forward")
         else:
-            rc = _lib.load().rn_potgnn_forward_lattices(handle, _ptr(lat), _ptr(pos), pos.shape[0], _ptr(out))
-            _lib.check(rc, handle, "rn_potgnn_forward_lattices")
+            types = None
+            if not same_species:
+                zi = zs.astype(np.int64)
+                if zi.min() < -self._atom_type_map.size or zi.max() >= self._atom_type_map.size:
+                    raise IndexError("atomic number outside the atom type map")
+                types = np.ascontiguousarray(self._atom_type_map[zi], dtype=np.int32)
+                if types.min() < 0:
+                    raise IndexError("index out of range in self: atomic_numbers holds a species the "
+                                     "model has no atom type for")
+            rc = _lib.load().rn_potgnn_forward_samples(
+                handle, None if same_lattice else _ptr(lat), None if types is None else _ptr(types),
+                _ptr(pos), pos.shape[0], _ptr(out))
+            _lib.check(rc, handle, "rn_potgnn_forward_samples")
         return torch.from_numpy(out)
 
     # -- training step pieces used by _TrainStep ------------------------------------------
@@ -685,7 +715,8 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         """Which kernel variants the handle selected (``rn_potgnn_config_flags``)."""
         flags = _lib.load().rn_potgnn_config_flags(self._ensure_handle())
         return {"fused_edge_block": bool(flags & 1), "folded_gate_scale": bool(flags & 2),
-                "split_f16_mfma": bool(flags & 4), "narrow_kernels": bool(flags & 8)}
+                "split_f16_mfma": bool(flags & 4), "narrow_kernels": bool(flags & 8),
+                "mfma_range_fallback": bool(flags & 16)}
 
     def set_profiling(self, mode: int) -> None:
         """0 = off, 1 = HIP-event timing of every kernel launch, 100+k = kernel k only."""

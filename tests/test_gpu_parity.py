@@ -127,13 +127,64 @@ def test_forward_with_per_sample_lattices():
     same = model.forward(torch.tensor(g["lattice"]).expand(s, 3, 3), zs, torch.tensor(r["lat/positions"])).numpy()
     np.testing.assert_array_equal(same[0], out[0])          # sample 0 carries the reference lattice
     assert np.abs(same[1:] - out[1:]).max() > 1e3 * REL * scale  # the others really differ
-    other = zs.clone()
-    other[0, 0] = 8 if int(other[0, 0]) != 8 else 22
-    with pytest.raises(NotImplementedError, match="atomic_numbers that differ"):
-        model.forward(torch.tensor(r["lat/lattices"]), other, torch.tensor(r["lat/positions"]))
     model.train()
     with pytest.raises(NotImplementedError, match="training mode supports only"):
         model.forward(torch.tensor(r["lat/lattices"]), zs, torch.tensor(r["lat/positions"]))
+
+
+def test_forward_with_per_sample_atomic_numbers():
+    """``forward(lattice, atomic_numbers[S,N], positions)`` with species that differ between samples
+    (``_convert_to_atom_type`` + node embedding per (sample, atom), ``_gnn.py:541-557,642-643``)
+    against the reference's float32 and float64 outputs: pairs of atoms swapped, one species
+    replaced, half of the samples on a strained lattice as well."""
+    g, r = load_golden("triclinic20"), load_golden("triclinic20_r3")
+    model = product_model_from_golden(g).eval()
+    zs, lat, pos = r["zs/atomic_numbers"], r["zs/lattices"], r["zs/positions"]
+    out = model.forward(torch.tensor(lat), torch.tensor(zs), torch.tensor(pos)).numpy()
+    scale = np.abs(r["zs/forward64"]).max()
+    assert np.abs(out - r["zs/forward"]).max() < REL * scale
+    assert np.abs(out - r["zs/forward64"]).max() < REL * scale
+    ref_zs = np.broadcast_to(g["atomic_numbers"], zs.shape)
+    plain = model.forward(torch.tensor(lat), torch.tensor(ref_zs.copy()), torch.tensor(pos)).numpy()
+    np.testing.assert_array_equal(plain[0], out[0])               # sample 0 carries the reference species
+    assert np.abs(plain[1:] - out[1:]).max() > 1e3 * REL * scale  # the others really differ
+    for i in range(len(zs)):  # sample by sample = the batch (test_gnn.py:76-113)
+        one = model.forward(torch.tensor(lat[i:i + 1]), torch.tensor(zs[i:i + 1]), torch.tensor(pos[i:i + 1])).numpy()
+        np.testing.assert_array_equal(one[0], out[i])
+    unknown = zs.copy()
+    unknown[2, 5] = 79  # the model has no atom type for gold: the reference's Embedding raises IndexError
+    with pytest.raises(IndexError):
+        model.forward(torch.tensor(lat), torch.tensor(unknown), torch.tensor(pos))
+    model.train()
+    with pytest.raises(NotImplementedError, match="training mode supports only"):
+        model.forward(torch.tensor(g["lattice"]).expand(len(zs), 3, 3), torch.tensor(zs), torch.tensor(pos))
+
+
+def test_calc_polarizabilities_in_float64(golden):
+    """``calc_polarizabilities`` evaluates in ``torch.get_default_dtype()`` (``_gnn.py:705-710``):
+    under a float64 default (or ``dtype=torch.float64``) the kernels instantiated for ``double`` run
+    and reproduce the reference's float64 results far below float32 round-off."""
+    name, g = golden
+    if "f64/alpha" not in g.files:
+        pytest.skip("fixture has no float64 run")
+    model = product_model_from_golden(g)
+    pos = g["pos_batch"]
+    a64 = model.calc_polarizabilities(pos, dtype=torch.float64)
+    # (5e-8, not 1e-12: the fixture's float64 reference model was BUILT under a float64 default, so its
+    #  Gaussian coefficient -0.5 / (mu_1 - mu_0)^2 comes from a float64 linspace, while its offsets --
+    #  like every weight -- are the float32 state widened; here the coefficient is derived from those
+    #  float32 offsets.  Measured 5.9e-9 on tio2_notebook, whose 5/13 spacing is inexact in float32.)
+    assert _rel_err(a64, g["f64/alpha"]) < 5e-8, name
+    a32 = model.calc_polarizabilities(pos)
+    assert _rel_err(a32, g["f64/alpha"]) < REL and np.abs(a32 - a64).max() > 0
+    torch.set_default_dtype(torch.float64)
+    try:
+        np.testing.assert_array_equal(model.calc_polarizabilities(pos), a64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos), a32)  # and back
+    with pytest.raises(ValueError, match="unsupported evaluation dtype"):
+        model.calc_polarizabilities(pos, dtype=torch.float16)
 
 
 def test_forward_on_positions_far_outside_the_unit_cell():
@@ -487,6 +538,63 @@ def test_split_f16_mfma_matches_exact_f32_mfma(monkeypatch):
     assert e16 < REL / 2 and e32 < REL / 2 and _rel_err(std(a16), std(a32)) < REL / 2
 
 
+@pytest.mark.parametrize("scale", [2.0 ** -12, 2.0 ** -6, 2.0 ** 8, "outlier"])
+def test_split_f16_mfma_is_scale_invariant(scale):
+    """The split-f16 products must not care about the scale of a weight matrix: every Linear that
+    feeds a LayerNorm (c1, c2, c3 of each pass) is multiplied as a whole by 2^-12, 2^-6 or 2^8 -- the
+    LayerNorm makes that scale a free parameter of the model, and an unscaled f16 split would carry
+    2^-25 ABSOLUTE error per weight -- or gets one entry of 7e4 (beyond f16's largest finite value).
+    The fused path on prescaled weights (kernels.hpp: mfma_prescale) must stay as close to the float64
+    oracle as in test_split_f16_mfma_matches_exact_f32_mfma and must not fall back to float32."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("rocksalt64_parity")
+    model, oracle = _random_model(g, 3.2, 64, 64, 2, seed=64064)
+    state = model.state_dict()
+    rng = np.random.default_rng(9)
+    for key, value in state.items():
+        if key.endswith(("c1_linear.weight", "c2_linear.weight", "c3_linear.weight")):
+            if scale == "outlier":
+                value[int(rng.integers(value.shape[0])), int(rng.integers(value.shape[1]))] = 7.0e4
+            else:
+                value.mul_(scale)
+        elif key.endswith(("c1_linear.bias", "c2_linear.bias", "c3_linear.bias")) and scale != "outlier":
+            value.mul_(scale)
+    model.load_state_dict(state)
+    oracle.sd = {k: v.clone() for k, v in state.items()}
+    oracle = oracle.to(torch.float64)
+    rng = np.random.default_rng(5)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=5)] + rng.normal(scale=2e-3, size=(5,) + base.shape[1:])
+    got = model.calc_polarizabilities(pos)
+    flags = model.config_flags()
+    assert flags["fused_edge_block"] and flags["split_f16_mfma"] and not flags["mfma_range_fallback"]
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    err = _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std)
+    print(f"scale {scale}: standardised alpha vs float64 oracle {err:.2e}")
+    assert err < REL / 2
+
+
+def test_split_f16_range_guard_falls_back_to_float32():
+    """What the prescale cannot cover -- readout hidden activations that the weights allow beyond
+    f16's range, or a non-finite weight -- makes the handle run the exact-f32 MFMA instantiations and
+    say so (``config_flags()["mfma_range_fallback"]``); results then still match the oracle."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("rocksalt64_parity")
+    model, oracle = _random_model(g, 3.2, 64, 64, 1, seed=64164)
+    assert model.config_flags()["split_f16_mfma"] and not model.config_flags()["mfma_range_fallback"]
+    state = model.state_dict()
+    state["_to_polarizability_embedding.0.weight"].mul_(3.0e3)   # |h1| may now reach ~1e5
+    model.load_state_dict(state)
+    oracle.sd = {k: v.clone() for k, v in state.items()}
+    oracle = oracle.to(torch.float64)
+    pos = g["pos_batch"][:3]
+    got = model.calc_polarizabilities(pos)
+    flags = model.config_flags()
+    assert flags["fused_edge_block"] and flags["mfma_range_fallback"] and not flags["split_f16_mfma"]
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    assert _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL
+
+
 def _random_model(g, cutoff, fn, fe, passes, seed):
     """Product model + oracle with identical random weights on a fixture's geometry."""
     from oracle import potgnn_oracle as O
@@ -718,7 +826,7 @@ def test_training_step_at_config5_shape():
             continue
         worst = max(worst, np.abs(p.grad.numpy() - grads64[name]).max() / scale)
     print(f"config-5 shape, batch 32: float32 vs float64 device gradients, worst {worst:.1e} of a parameter's max")
-    assert worst < 1e-3
+    assert worst < 1e-4  # measured 1.1e-5
 
 
 def _adam_run(model, optimizer, lat, zs, pos, targets, steps):
@@ -796,7 +904,7 @@ def test_device_adam_through_train_single_epoch(batch_size):
     got = train_single_epoch(device, data, data, batch_size, DeviceAdam(device, lr=1e-3), torch.nn.MSELoss())
     assert np.isfinite(ref[0]) and np.isfinite(ref[1])
     assert got[0] == pytest.approx(ref[0], rel=1e-4) and got[1] == pytest.approx(ref[1], rel=1e-4)
-    np.testing.assert_allclose(got[2], ref[2], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(got[2], ref[2], rtol=1e-4, atol=1e-7)
 
 
 def test_device_adam_data_parallel(tmp_path):
