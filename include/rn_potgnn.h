@@ -144,6 +144,15 @@ int rn_potgnn_forward_device(rn_potgnn *h, const double *d_positions, int64_t S,
                              int synchronize);
 
 /*
+ * The device-resident entry with every kernel instantiated for float64 (see
+ * rn_potgnn_calc_polarizabilities_f64): d_positions device f64[S*N*3] -> d_alpha device f64[S*9].
+ * Used by the sharded phonon path, whose finite differences need float64 and whose results stay in
+ * HBM until the all-gather.
+ */
+int rn_potgnn_forward_device_f64(rn_potgnn *h, const double *d_positions, int64_t S, double *d_alpha,
+                                 void *stream, int synchronize);
+
+/*
  * Replaces PotGNN.forward for host callers (_gnn.py:617-665, eval mode):
  * host f64 positions -> host f32[S*6] standardised 6-vectors.
  */
@@ -302,7 +311,9 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * an instantiated pair, e.g. the documented Fn = 5, Fe = 14) are in use; bit 4 = split-f16 was
  * requested but the range guard refused it (a non-finite weight, or readout hidden activations
  * that the weights allow beyond 3e4): the exact-f32 MFMA instantiations run instead.  Weight
- * matrices of any finite scale are fine: each is prescaled by a power of two into f16's range. */
+ * matrices of any finite scale are fine: each is prescaled by a power of two into f16's range;
+ * bit 5 = the fused EdgeBlock runs in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel;
+ * opt-in with RN_POTGNN_EDGE2=1 at create time; the default is the per-frame form). */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rn_potgnn_calc_polarizabilities": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_calc_polarizabilities_f64": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int]),
+    "rn_potgnn_forward_device_f64": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int]),
     "rn_potgnn_calc_polarizabilities_async": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_wait": (C.c_int, [_P]),
     "rn_host_buffer_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(_P)]),

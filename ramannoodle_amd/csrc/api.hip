@@ -106,6 +106,7 @@ struct Lane {
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
   DeviceBuf unit4, node[2], edge[2], npc1, np3, bufA, bufB;
+  DeviceBuf c2;  // frame-pipelined EdgeBlock: the finished c2 embedding of every edge [S*E, FeP]
 };
 
 template <typename T>
@@ -141,8 +142,9 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge;
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin;
   bool use_fused = false;
+  bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
@@ -449,11 +451,21 @@ void reduce_over_ranks(rn_potgnn *h, double *dev, size_t n, hipStream_t st) {
   HIP_TRY(hipMemcpy(dev, host.data(), n * sizeof(double), hipMemcpyHostToDevice));
 }
 
+// The fused and the narrow pipelines keep no per-edge projection in HBM: of the two projection buffers only
+// the [S*E, 32] readout output (bufA) is left.  Taped runs (training, Jacobian) size the full-width buffers
+// for their own, much smaller, batch (ensure_tape).
+bool lean_workspace(const rn_potgnn *h) {
+  return (h->use_fused && h->use_node_fused && h->use_readout_fused) || h->use_narrow;
+}
+size_t bufA_width(const rn_potgnn *h, bool lean) {
+  return lean ? 32 : std::max<size_t>(std::max(2 * h->d.FnP, 2 * h->d.FeP), 32);
+}
 size_t per_structure_elems(const rn_potgnn *h) {
   const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges;
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
-  const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
-  return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA + E * 4 * FeP;
+  const bool lean = lean_workspace(h);
+  return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA_width(h, lean) +
+         (lean ? 0 : E * 4 * FeP) + (h->use_edge2 ? E * FeP : 0);
 }
 
 // May the fused kernels run their matrix products as split-f16 MFMAs (device_utils.hpp)?
@@ -581,7 +593,8 @@ void ensure_precision(rn_potgnn *h) {
 
   const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges, S = chunk_frames<T>(h);
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
-  const size_t bufA = std::max<size_t>(std::max(2 * FnP, 2 * FeP), 32);
+  const bool lean = sizeof(T) == 4 && lean_workspace(h);
+  const size_t bufA = bufA_width(h, lean);
   for (int l = 0; l < h->num_lanes; ++l) {
     Lane<T> &ln = P.lanes[l];
     HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -594,7 +607,8 @@ void ensure_precision(rn_potgnn *h) {
     ln.npc1.ensure(S * N * 2 * FnP * sizeof(T));
     ln.np3.ensure(S * N * 6 * FeP * sizeof(T));
     ln.bufA.ensure(S * E * bufA * sizeof(T));
-    ln.bufB.ensure(S * E * 4 * FeP * sizeof(T));
+    if (!lean) ln.bufB.ensure(S * E * 4 * FeP * sizeof(T));
+    if (sizeof(T) == 4 && h->use_edge2) ln.c2.ensure(S * E * FeP * sizeof(T));
   }
   if (h->keep_stages) {
     const int np = h->cfg.num_message_passes + 1;
@@ -670,7 +684,7 @@ struct ChunkRun {
   const T *d_lat = nullptr;  // per-frame lattices [S][9] of this chunk, or null: the reference structure's
   const int *d_types = nullptr;  // per-frame atom types [S][N] of this chunk, or null: the reference structure's
   int cur = 0;
-  T *node[2], *edge[2], *unit4, *npc1, *np3, *bufA, *bufB;
+  T *node[2], *edge[2], *unit4, *npc1, *np3, *bufA, *bufB, *c2;
   int64_t MN, ME;
 
   ChunkRun(rn_potgnn *h_, Lane<T> &l, const double *pos, int S_, double *alpha, float *vec6,
@@ -685,6 +699,7 @@ struct ChunkRun {
     np3 = l.np3.template as<T>();
     bufA = l.bufA.template as<T>();
     bufB = l.bufB.template as<T>();
+    c2 = l.c2.template as<T>();
     MN = (int64_t)S * h->g.N;
     ME = (int64_t)S * h->g.E;
   }
@@ -767,6 +782,12 @@ struct ChunkRun {
       launch_rowgemm<T>(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, nullptr, w.c3_nshift, false,
                         0, nullptr, g, st());
     }
+    if constexpr (sizeof(T) == 4) {
+      if (fused() && h->use_edge2) {  // c2 branch of the EdgeBlock, one finished row per edge
+        Timer t(h, st(), K_PROJ_C2);
+        launch_edge_c2(node[nxt], c2, S, g, d, w, h->mfma_f16, st());
+      }
+    }
     if (!fused()) {
       {
         Timer t(h, st(), K_PROJ_EDGE_C3);
@@ -789,6 +810,8 @@ struct ChunkRun {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
         if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, h->g, h->d, w, st());
+        else if (fused() && h->use_edge2)
+          launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
@@ -1096,6 +1119,10 @@ void ensure_tape(rn_potgnn *h, int S) {
     P.tape_edge[p].ensure((size_t)S * h->g.E * h->d.FeP * sizeof(T));
     P.tape_agg[p].ensure((size_t)S * h->g.E * h->d.FeP * sizeof(T));
   }
+  // the reverse pass and the training-mode readout work on full-width projections of the taped batch
+  Lane<T> &ln = P.lanes[0];
+  ln.bufA.ensure((size_t)S * h->g.E * bufA_width(h, false) * sizeof(T));
+  ln.bufB.ensure((size_t)S * h->g.E * 4 * h->d.FeP * sizeof(T));
 }
 
 // forward of S frames on lane 0 with the per-pass embeddings recorded
@@ -1555,6 +1582,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   // fused EdgeBlock (kernels_fused.hip): its LDS footprint bounds the tile instead
   const bool want_fused = getenv("RN_POTGNN_FUSED") ? atoi(getenv("RN_POTGNN_FUSED")) != 0 : true;
   const bool fused_mode = want_fused && d.FnP == 64 && d.FeP == 64;
+  // RN_POTGNN_EDGE2=1: the frame-pipelined form of the fused EdgeBlock (edge_block2_kernel + edge_c2_kernel).
+  // Measured level with the per-frame form at Fn = Fe = 64 (profiles/r03/edge2_experiment.txt), so it stays opt-in.
+  const bool want_edge2 = getenv("RN_POTGNN_EDGE2") ? atoi(getenv("RN_POTGNN_EDGE2")) != 0 : false;
   // narrow-width kernels (kernels_narrow.hip): one lane per destination edge, so a tile should bring
   // about one workgroup's worth (256) of destination edges and keep its LDS rows within ~40 KiB
   const bool want_narrow = getenv("RN_POTGNN_NARROW") ? atoi(getenv("RN_POTGNN_NARROW")) != 0 : true;
@@ -1582,7 +1612,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
         max_in = std::max(max_in, din);
         max_nodes = std::max(max_nodes, tb[t + 1] - tb[t]);
       }
-      const size_t lds = fused_mode ? edge_fused_lds_bytes(mr, max_in, max_nodes)
+      const size_t lds = fused_mode ? (want_edge2 ? edge2_lds_bytes(mr, max_in, max_nodes)
+                                                  : edge_fused_lds_bytes(mr, max_in, max_nodes))
                                     : (size_t)mr * (row_bytes + 4) + (size_t)max_nodes * row_bytes +
                                           (size_t)12 * d.FeP * 4 + (size_t)mr * 4 + (size_t)max_in * 24 + 96;
       // unfused: two aggregation workgroups + one projection workgroup (34 KiB) share a CU
@@ -1593,6 +1624,37 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
         best = cost;
         h->tile_begin = tb;
         max_rows = mr;
+      }
+    }
+  }
+  // node tiles of the fused NodeBlock kernel: consecutive atoms by IN-edges; four workgroups per CU
+  // (40 KiB of LDS each), as few rounds x tiles as possible
+  int nt_max_in = 0, nt_max_nodes = 0;
+  {
+    double best = 0;
+    for (int budget = 16; budget <= 256; budget += 8) {
+      std::vector<int> tb(1, 0);
+      int rows_in = 0, max_in = 0, max_nodes = 0, first = 0;
+      for (int n = 0; n < N; ++n) {
+        const int deg = h->in_ptr[n + 1] - h->in_ptr[n];
+        if (n > first && rows_in + deg > budget) {
+          max_nodes = std::max(max_nodes, n - first);
+          tb.push_back(n);
+          first = n;
+          rows_in = 0;
+        }
+        rows_in += deg;
+        max_in = std::max(max_in, rows_in);
+      }
+      max_nodes = std::max(max_nodes, N - first);
+      tb.push_back(N);
+      if (node_fused_lds_bytes(max_in, max_nodes) > (size_t)40 * 1024 && !h->nt_begin.empty()) break;
+      const double cost = (double)((max_in + 15) / 16) * (double)(tb.size() - 1);
+      if (h->nt_begin.empty() || cost < best * 0.995) {
+        best = cost;
+        h->nt_begin = tb;
+        nt_max_in = max_in;
+        nt_max_nodes = max_nodes;
       }
     }
   }
@@ -1628,7 +1690,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     };
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
-                 o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge);
+                 o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge),
+                 o_nt = push(hp->nt_begin);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -1654,6 +1717,10 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     }
     g.trip_off = base + o_to;
     g.T = hp->trip_off[E];
+    g.nt_num = (int)hp->nt_begin.size() - 1;
+    g.nt_begin = base + o_nt;
+    g.nt_max_in_rows = nt_max_in;
+    g.nt_max_nodes = nt_max_nodes;
     double ms[18];
     std::memcpy(ms, hp->mean, sizeof(hp->mean));
     std::memcpy(ms + 9, hp->stdv, sizeof(hp->stdv));
@@ -1664,7 +1731,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     refresh_mfma_mode(hp);
     // The fused kernels (kernels_fused.hip) are the default where they apply (float32, Fn and
     // Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
-    hp->use_fused = want_fused && edge_fused_supported(hp->g, hp->d);
+    hp->use_edge2 = want_fused && want_edge2 && edge2_supported(hp->g, hp->d);
+    hp->use_fused = hp->use_edge2 || (want_fused && edge_fused_supported(hp->g, hp->d));
     hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
     // Chunk size and lanes.  Throughput rises monotonically with the frames per launch
@@ -1673,6 +1741,10 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // second lane has nothing to overlap with: ONE lane with an 8 GiB workspace (of 288 GB HBM)
     // beats two lanes of 1.5 GiB (63.7 k vs 62.1 k structures/s at 4000 frames).  The unfused
     // pipeline keeps two alternating lanes of 1.5 GiB.
+    const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
+    hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
+    const bool want_ro = getenv("RN_POTGNN_READOUT_FUSED") ? atoi(getenv("RN_POTGNN_READOUT_FUSED")) != 0 : true;
+    hp->use_readout_fused = hp->use_fused && want_ro;
     if (!getenv("RN_POTGNN_LANES")) hp->num_lanes = (hp->use_fused || hp->use_narrow) ? 1 : 2;
     int chunk = cfg->max_chunk_structures;
     if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
@@ -1686,10 +1758,6 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       chunk = std::min(chunk, 4096);
     }
     hp->chunk = chunk;
-    const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
-    hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
-    const bool want_ro = getenv("RN_POTGNN_READOUT_FUSED") ? atoi(getenv("RN_POTGNN_READOUT_FUSED")) != 0 : true;
-    hp->use_readout_fused = hp->use_fused && want_ro;
     ensure_precision<float>(hp);
   });
   if (rc != RN_OK) return rc;
@@ -1731,6 +1799,20 @@ int rn_potgnn_forward_device(rn_potgnn *h, const double *d_positions, int64_t S,
   return guarded(h, [&]() {
     forward_device<float>(h, d_positions, S, d_alpha, d_vec6, nullptr, (hipStream_t)stream,
                           synchronize != 0);
+  });
+}
+
+int rn_potgnn_forward_device_f64(rn_potgnn *h, const double *d_positions, int64_t S, double *d_alpha,
+                                 void *stream, int synchronize) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!d_positions || !d_alpha))) {
+    set_error(h, "invalid positions / alpha / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    sync_host(h);  // the float64 copy of the weights is made from the host master copy
+    forward_device<double>(h, d_positions, S, d_alpha, nullptr, nullptr, (hipStream_t)stream, synchronize != 0);
   });
 }
 
@@ -2192,7 +2274,7 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
-              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0);
+              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0);
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);

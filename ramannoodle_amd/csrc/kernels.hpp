@@ -23,6 +23,11 @@ struct Graph {
   int max_tile_out_rows;  // LDS rows needed by the largest tile
   int max_tile_in_rows;   // most destination edges entering one tile
   int max_tile_nodes;     // most atoms in one tile
+  // node tiles of the fused NodeBlock kernel (its own partition: it holds no Q' rows, so its tiles can
+  // be larger than the EdgeBlock's and fill their rounds better)
+  int nt_num;
+  const int *nt_begin;    // [nt_num+1] node ranges
+  int nt_max_in_rows, nt_max_nodes;
   // triplet enumeration
   const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
   int64_t T;
@@ -195,6 +200,7 @@ constexpr size_t kFusedLdsBudget = 80 * 1024;
 size_t edge_fused_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
 bool edge_fused_supported(const Graph &g, Dims d);
 size_t node_fused_lds_bytes(const Graph &g);
+size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes);
 // `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
                           hipStream_t st);
@@ -204,6 +210,16 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
                        float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
                        hipStream_t st);
+
+// Frame-pipelined EdgeBlock (kernels_fused.hip: edge_block2_kernel) and the c2 branch as its own
+// streaming kernel: float32, FnP == FeP == 64, same LDS budget for two workgroups per CU.
+size_t edge2_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
+bool edge2_supported(const Graph &g, Dims d);
+// c2[S*E, FeP] = LayerNorm(gate(LayerNorm(c2_linear(node[b] * node[a]))))  (_gnn.py:200-228)
+void launch_edge_c2(const float *node, float *c2, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
+                    hipStream_t st);
+void launch_edge2(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
+                  const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
 
 // Device-resident optimisation step (kernels_train.hip); offsets index the packed weight blob.
 struct DerivedOp {

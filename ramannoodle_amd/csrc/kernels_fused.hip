@@ -290,9 +290,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   WaveB<F16> bW4, bWc;
   bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad, s4);
   bWc.load(a.w.c2_WT, 2 * FP, colbase, l15, quad, sc2);
-  f32x4 c2bias[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) c2bias[t] = *reinterpret_cast<const f32x4 *>(a.w.c2_bias + colbase + 16 * t + 4 * quad);
+  const float *c2bias_p = a.w.c2_bias + colbase + 4 * quad;  // (re-read per round: 8 VGPRs the kernel does not have)
 
   // ---- VALU-phase constants: lane q4 of group grp owns columns 4q4..4q4+3 (+FP)
   const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
@@ -455,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {  // row l15, columns colbase + 16 t + 4 quad .. + 3
           *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = accP[t];
-          *reinterpret_cast<f32x4 *>(bufC + l15 * LDQ + colbase + 16 * t + 4 * quad) = accC[t] * invc2 + c2bias[t];
+          *reinterpret_cast<f32x4 *>(bufC + l15 * LDQ + colbase + 16 * t + 4 * quad) =
+              accC[t] * invc2 + *reinterpret_cast<const f32x4 *>(c2bias_p + 16 * t);
         }
       }
       __syncthreads();  // S1: bufP / bufC complete, operand tiles free
@@ -730,14 +729,14 @@ template <bool PAD, bool F16>
 __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
-  const NodeFusedLds L = node_fused_lds(g.max_tile_in_rows, g.max_tile_nodes);
+  const NodeFusedLds L = node_fused_lds(g.nt_max_in_rows, g.nt_max_nodes);
   float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);    // [16][LDQ] W_e edge_e of a round
   float *atile = reinterpret_cast<float *>(smem_raw + L.atile);  // [16][64] swizzled operand rows
   float *gated = reinterpret_cast<float *>(smem_raw + L.gated);  // [maxD][LDG] gate outputs of the tile
   float *nj = reinterpret_cast<float *>(smem_raw + L.nj);        // [maxN][2FP] W_n node + bias
   float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
   float *s_c1g = lnp, *s_c1b = lnp + 2 * FP, *s_fg = lnp + 4 * FP, *s_fb = lnp + 5 * FP;
-  int *d_edge = reinterpret_cast<int *>(smem_raw + L.ints), *d_bl = d_edge + g.max_tile_in_rows;
+  int *d_edge = reinterpret_cast<int *>(smem_raw + L.ints), *d_bl = d_edge + g.nt_max_in_rows;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -745,9 +744,9 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
   const int colbase = wave * 32;
   int logical = blockIdx.x;
   if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int tile = logical % g.num_tiles;
-  const int sg = logical / g.num_tiles, nsg = gridDim.x / g.num_tiles;
-  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int tile = logical % g.nt_num;
+  const int sg = logical / g.nt_num, nsg = gridDim.x / g.nt_num;
+  const int j0 = g.nt_begin[tile], j1 = g.nt_begin[tile + 1];
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
   const int nrounds = (dcount + NG - 1) / NG;
 
@@ -863,7 +862,8 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
   }
 }
 
-size_t node_fused_lds_bytes(const Graph &g) { return node_fused_lds(g.max_tile_in_rows, g.max_tile_nodes).total; }
+size_t node_fused_lds_bytes(const Graph &g) { return node_fused_lds(g.nt_max_in_rows, g.nt_max_nodes).total; }
+size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes) { return node_fused_lds(tile_in_rows, tile_nodes).total; }
 
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
@@ -887,9 +887,9 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   per_cu = std::min(per_cu, 4);
-  int nsg = per_cu * cus / g.num_tiles;
+  int nsg = per_cu * cus / g.nt_num;
   nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
-  kern<<<(unsigned)nsg * (unsigned)g.num_tiles, 256, lds, st>>>(a);
+  kern<<<(unsigned)nsg * (unsigned)g.nt_num, 256, lds, st>>>(a);
 }
 
 // ============================================================================ EdgeBlock, frame-pipelined form
@@ -910,6 +910,12 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
 //     weight fragments are what made room for a resident W5.
 // The double buffer halves the tile (2 x rows of Q'), so the last round of a frame is usually a short one:
 // destinations are then split over 2, 4, 8 or 16 lane groups (partial sums added in a fixed order).
+// Timing-only probe builds of edge_block2_kernel (RN_EXTRA_FLAGS=-DRN_E2_PROBE=mask; wrong results):
+// 1 no output store, 2 no final vmcnt(0) wait, 4 no triplet loop, 8 no MFMA phase, 16 no LDS-DMA / split,
+// 32 no centring, 64 no epilogue arithmetic
+#ifndef RN_E2_PROBE
+#define RN_E2_PROBE 0
+#endif
 struct Edge2Args {
   const float *edge_in;
   float *edge_out;
@@ -924,19 +930,18 @@ struct Edge2Args {
 
 namespace {
 struct Edge2Lds {
-  size_t bufQ, sq, bufP, atile, npI, npK, nj, lnp, ints, total;
+  size_t bufQ, bufP, atile, npI, npK, nj, lnp, ints, total;
 };
 __host__ __device__ inline Edge2Lds edge2_lds(int maxR, int maxD, int maxN) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   Edge2Lds L;
   size_t off = 0;
-  L.bufQ = off; off += 2 * up((size_t)maxR * LDQ * 4);   // [2][maxR][LDQ] centred source rows: this frame | next frame
-  L.sq = off; off += 2 * up((size_t)maxR * 4);           // [2][maxR] |q|^2
+  L.bufQ = off; off += 2 * up((size_t)maxR * LDQ * 4);   // [2][maxR][LDQ] centred source rows (|q|^2 in column 2FP): this frame | next frame
   L.bufP = off; off += up((size_t)NG * LDQ * 4);         // [16][LDQ] W4 edge_d of a round
   L.atile = off; off += 2 * (size_t)NG * FP * 4;         // 2 x [16][64] swizzled operand rows: destinations | staged sources
   L.npI = off; off += (size_t)NG * 2 * FP * 4;           // [16][2FP] Wi node[b_e] of the staged rows
   L.npK = off; off += (size_t)NG * 2 * FP * 4;           // [16][2FP] Wk node[a_d] of the destinations
-  L.nj = off; off += 2 * up((size_t)maxN * 2 * FP * 4);  // [2][maxN][2FP] Wj node[j] + bias: this frame | next frame
+  L.nj = off; off += 2 * (size_t)((maxN + 1) & ~1) * 2 * FP * 4;  // [2][maxN rounded up to even][2FP] Wj node[j] + bias: this frame | next frame (requests bring two rows)
   L.lnp = off; off += (size_t)6 * FP * 4;
   L.ints = off; off += up(((size_t)maxR + 6 * (size_t)maxD) * 4);
   L.total = off;
@@ -951,10 +956,8 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
   const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
   const Edge2Lds L = edge2_lds(maxR, maxD, maxN);
   float *bufQ0 = reinterpret_cast<float *>(smem_raw + L.bufQ);
-  float *sq0 = reinterpret_cast<float *>(smem_raw + L.sq);
   const int bufQ_stride = (int)((((size_t)maxR * LDQ * 4 + 15) & ~size_t(15)) / 4);
-  const int sq_stride = (int)((((size_t)maxR * 4 + 15) & ~size_t(15)) / 4);
-  const int nj_stride = (int)((((size_t)maxN * 2 * FP * 4 + 15) & ~size_t(15)) / 4);
+  const int nj_stride = ((maxN + 1) & ~1) * 2 * FP;
   float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);
   float *atile = reinterpret_cast<float *>(smem_raw + L.atile);
   float *npI = reinterpret_cast<float *>(smem_raw + L.npI);
@@ -1034,42 +1037,53 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
 
   // ---- LDS-DMA requests.  A frame index outside [0, S) or a round beyond what the tile has: nothing is
   //      requested (the consumers test the same conditions).  All conditions are workgroup-uniform.
+  // The rows a round will ask for are named by five table entries per lane; they are read from LDS in one
+  // go (one round trip instead of one per request) right after S1.
+  struct RoundIdx {
+    int e_dst;       // destination edge of operand row 4 wave + quad
+    int r_src;       // staged source row (tile-local) of operand row 4 wave + quad
+    int b0, b1;      // b_e of the staged rows 4 wave + (lane >> 5) and + 2: rows of np3's Wi block
+    int a0, a1;      // a_d of the destinations 4 wave + (lane >> 5) and + 2: rows of np3's Wk block
+  };
+  auto lookup = [&](int r) {
+    RoundIdx x;
+    const int row = r * NG + 4 * wave + quad, rw = r * NG + 4 * wave + (lane >> 5);
+    const int dl = max(dcount - 1, 0), rl = max(rows - 1, 0);
+    x.e_dst = d_edge[min(row, dl)];
+    x.r_src = min(row, rl);
+    x.b0 = qb[min(rw, rl)];
+    x.b1 = qb[min(rw + 2, rl)];
+    x.a0 = d_a[min(rw, dl)];
+    x.a1 = d_a[min(rw + 2, dl)];
+    return x;
+  };
   // operand rows of the MFMA phase of round r: destinations of frame sd, staged source rows of frame ss;
   // wave w brings rows 4w..4w+3 of each tile, slot (row, piece p) receives global piece p ^ row
-  auto request_tiles = [&](int sd, int ss, int r) {
+  auto request_tiles = [&](int sd, int ss, int r, const RoundIdx &x) {
+    if (RN_E2_PROBE & 16) return;
     const int row = 4 * wave + quad;
     const int piece = (l15 ^ row) & 15;
-    if (sd >= 0 && sd < a.S && r < nrD) {
-      const int i = min(r * NG + row, dcount - 1);
-      dma16(a.edge_in + ((int64_t)sd * g.E + d_edge[i]) * FP + 4 * piece, atile + wave * 256);
-    }
-    if (ss < a.S && r < nrS) {
-      const int rr = min(r * NG + row, rows - 1);
-      dma16(a.edge_in + ((int64_t)ss * g.E + eo0 + rr) * FP + 4 * piece, atile + NG * FP + wave * 256);
-    }
+    if (sd >= 0 && sd < a.S && r < nrD)
+      dma16(a.edge_in + ((int64_t)sd * g.E + x.e_dst) * FP + 4 * piece, atile + wave * 256);
+    if (ss < a.S && r < nrS)
+      dma16(a.edge_in + ((int64_t)ss * g.E + eo0 + x.r_src) * FP + 4 * piece, atile + NG * FP + wave * 256);
   };
   // the 2FP-wide rows of np3 a round's VALU phase adds: wave w brings rows 4w..4w+3 (two per request), which
   // are the rows its own four lane groups read -- except in rounds whose destinations are split over groups
-  auto request_npI = [&](int ss, int r) {  // Wi node[b_e] of the staged rows (np3 columns 0 .. 2FP)
-    if (!(ss < a.S && r < nrS)) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = 4 * wave + 2 * j + (lane >> 5);
-      const int rr = min(r * NG + row, rows - 1);
-      dma16(a.np3 + ((int64_t)ss * g.N + qb[rr]) * (6 * FP) + 4 * (lane & 31), npI + (4 * wave + 2 * j) * 2 * FP);
-    }
+  auto request_npI = [&](int ss, int r, const RoundIdx &x) {  // Wi node[b_e] of the staged rows (np3 columns 0 .. 2FP)
+    if (!(ss < a.S && r < nrS) || (RN_E2_PROBE & 16)) return;
+    const float *base = a.np3 + (int64_t)ss * g.N * (6 * FP) + 4 * (lane & 31);
+    dma16(base + (int64_t)x.b0 * (6 * FP), npI + (4 * wave) * 2 * FP);
+    dma16(base + (int64_t)x.b1 * (6 * FP), npI + (4 * wave + 2) * 2 * FP);
   };
-  auto request_npK = [&](int sd, int r) {  // Wk node[a_d] of the destinations (np3 columns 4FP .. 6FP)
-    if (!(sd >= 0 && sd < a.S && r < nrD)) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = 4 * wave + 2 * j + (lane >> 5);
-      const int i = min(r * NG + row, dcount - 1);
-      dma16(a.np3 + ((int64_t)sd * g.N + d_a[i]) * (6 * FP) + 4 * FP + 4 * (lane & 31), npK + (4 * wave + 2 * j) * 2 * FP);
-    }
+  auto request_npK = [&](int sd, int r, const RoundIdx &x) {  // Wk node[a_d] of the destinations (np3 columns 4FP .. 6FP)
+    if (!(sd >= 0 && sd < a.S && r < nrD) || (RN_E2_PROBE & 16)) return;
+    const float *base = a.np3 + (int64_t)sd * g.N * (6 * FP) + 4 * FP + 4 * (lane & 31);
+    dma16(base + (int64_t)x.a0 * (6 * FP), npK + (4 * wave) * 2 * FP);
+    dma16(base + (int64_t)x.a1 * (6 * FP), npK + (4 * wave + 2) * 2 * FP);
   };
   auto request_nj = [&](int sd, float *dst) {  // Wj node[j] + bias of the tile's atoms (np3 columns 2FP .. 4FP)
-    if (!(sd >= 0 && sd < a.S)) return;
+    if (!(sd >= 0 && sd < a.S) || (RN_E2_PROBE & 16)) return;
     for (int n0 = 2 * wave; n0 < j1 - j0; n0 += 8) {  // two atoms per request
       const int n = min(n0 + (lane >> 5), j1 - j0 - 1);
       dma16(a.np3 + ((int64_t)sd * g.N + j0 + n) * (6 * FP) + 2 * FP + 4 * (lane & 31), dst + n0 * 2 * FP);
@@ -1077,6 +1091,7 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
   };
   // every lane turns the 16-byte operand slots IT fetched into [hi x4 | lo x4] in place (split-f16 path)
   auto split_landed_tiles = [&](bool dests, bool stage) {
+    if (RN_E2_PROBE & 16) return;
     if constexpr (F16) {
       float *slot = atile + wave * 256 + lane * 4;
       if (dests) *reinterpret_cast<float4 *>(slot) = split_slot(*reinterpret_cast<const float4 *>(slot));
@@ -1104,8 +1119,11 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
   // The frame loop starts one frame early: frame sg - nsg has no destinations, its rounds only stage Q' of
   // frame sg.  par: which half of bufQ / sq / nj holds the frame whose destinations are being served.
   int par = 0;
-  request_tiles(-1, sg, 0);
-  request_npI(sg, 0);
+  {
+    const RoundIdx x0 = lookup(0);
+    request_tiles(-1, sg, 0, x0);
+    request_npI(sg, 0, x0);
+  }
   dma_wait();
   split_landed_tiles(false, true);
   __syncthreads();
@@ -1114,19 +1132,18 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
     const bool have_cur = s >= 0, have_nxt = s + nsg < a.S;
     const int64_t erow0 = (int64_t)s * g.E;
     float *bufQ = bufQ0 + par * bufQ_stride, *bufQn = bufQ0 + (par ^ 1) * bufQ_stride;
-    float *sq = sq0 + par * sq_stride, *sqn = sq0 + (par ^ 1) * sq_stride;
     const float *nj = nj0 + par * nj_stride;
 
     for (int r = 0; r < nrounds; ++r) {
       const bool do_dest = have_cur && r < nrD, do_stage = have_nxt && r < nrS;
       // ================= MFMA phase: P' of 16 destinations, Q' of 16 source rows of the next frame
-      if (do_dest) {
+      if (do_dest && !(RN_E2_PROBE & 8)) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         tile_product(atile, bW4, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
       }
-      if (do_stage) {
+      if (do_stage && !(RN_E2_PROBE & 8)) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         tile_product(atile + NG * FP, bW5, acc);
         if (const int rr = r * NG + l15; rr < rows) {
@@ -1140,12 +1157,13 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
       // ---- what the NEXT round needs (next round of this frame pair, or round 0 of the next pair)
       const bool wrap = r + 1 == nrounds;
       const int sd_n = wrap ? s + nsg : s, ss_n = wrap ? s + 2 * nsg : s + nsg, r_n = wrap ? 0 : r + 1;
-      request_tiles(sd_n, ss_n, r_n);
+      const RoundIdx xn = lookup(r_n);
+      request_tiles(sd_n, ss_n, r_n, xn);
       if (wrap) request_nj(sd_n, nj0 + (par ^ 1) * nj_stride);
 
       // ================= VALU phase
       // ---- centring of the staged row of this group: add Wi node[b_e], centre, fold the gate scale, |q|^2
-      if (const int rr = r * NG + grp; do_stage && rr < rows) {
+      if (const int rr = r * NG + grp; do_stage && rr < rows && !(RN_E2_PROBE & 32)) {
         float *row = bufQn + rr * LDQ;
         const float *np = npI + grp * 2 * FP + c0;
         Vec4<float> f = load4<float>(row + c0), c = load4<float>(row + FP + c0);
@@ -1176,15 +1194,15 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
         }
         store4(row + c0, f);
         store4(row + FP + c0, c);
-        if (q4 == 0) sqn[rr] = ss;
+        if (q4 == 0) row[2 * FP] = ss;
       }
       // this wave's groups have consumed their npI rows: the next round's may land (wave-private rows)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      request_npI(ss_n, r_n);
+      request_npI(ss_n, r_n, xn);
 
       // ---- destinations of this round: `parts` lane groups share one when at most 8 / 4 / 2 / 1 are left
       const int rem = do_dest ? dcount - r * NG : 0;
-      const int parts = rem > 8 ? 1 : (rem > 4 ? 2 : (rem > 2 ? 4 : (rem > 1 ? 8 : 16)));  // uniform over the workgroup
+      const int parts = (rem > 8 || rem <= 0) ? 1 : (rem > 4 ? 2 : (rem > 2 ? 4 : (rem > 1 ? 8 : 16)));  // uniform over the workgroup
       const int nslots = NG / parts;
       const int slot = grp & (nslots - 1), part = grp / nslots;
       const bool active = slot < rem;
@@ -1221,10 +1239,10 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
       // npK rows are wave-private unless the round is split over groups (then: after the exchange barrier below)
       if (parts == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        request_npK(sd_n, r_n);
+        request_npK(sd_n, r_n, xn);
       }
       if (active) {
-        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+        const int rb = d_rb[i], cnt = (RN_E2_PROBE & 4) ? 0 : d_cnt[i], rskip = d_skip[i];
 #if RN_FUSED_PRIO
         __builtin_amdgcn_s_setprio(0);  // the triplet loop is always ready to issue: let the other wave's sparse phases go first
 #endif
@@ -1256,10 +1274,11 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
             bf2[hh] = f32x2{b3f[2 * hh], b3f[2 * hh + 1]};
             bc2[hh] = f32x2{b3c[2 * hh], b3c[2 * hh + 1]};
           }
-          auto triplet = [&](int rq, float (&sumk)[4]) {
-            const float *qr = bufQ + rq * LDQ + c0;
+          // `qr`: this lane's four filter columns of a source row; the core columns sit FP floats on, |q|^2
+          // (one value per row, read by every lane) in the row's pad at column 2FP
+          auto triplet = [&](const float *qr, const float *qsq, float (&sumk)[4]) {
             const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
-            const float qs = sq[rq];
+            const float qs = *qsq;
             const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
             f32x2 d2 = pdf2[0] * qf2[0];
             f32x2 d3 = pdc2[0] * qc2[0];
@@ -1285,14 +1304,24 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
               sumk[2 * hh + 1] = sk.y;
             }
           };
-          // two independent triplets per iteration (summation order: even / odd partial sums)
+          // The triplets of a destination are the rows rb .. of its atom's out-edges without the reverse
+          // edge.  The loop keeps one LDS pointer per lane and steps it row by row (two rows where the
+          // numbering jumps over the reverse edge) instead of recomputing a row index and an address per
+          // triplet; the trip count stays uniform over the lane groups of a wave.  Two independent
+          // triplets per iteration, even / odd partial sums.
           float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+          const int tskip = rskip - rb;  // triplet number at which the row numbering jumps over the reverse edge
+          const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
+          auto step = [&](const float *p, int tnext) { return p + (tnext == tskip ? 2 * LDQ : LDQ); };
+          const float *qr = bufQ + (rb + t0 + (t0 >= tskip ? 1 : 0)) * LDQ + c0;
           int t = t0;
           for (; t + 1 < t1; t += 2) {
-            triplet(row_of(t), acc);
-            triplet(row_of(t + 1), acc2);
+            const float *qn = step(qr, t + 1);
+            triplet(qr, qr + sdelta, acc);
+            triplet(qn, qn + sdelta, acc2);
+            qr = step(qn, t + 2);
           }
-          if (t < t1) triplet(row_of(t), acc);
+          if (t < t1) triplet(qr, qr + sdelta, acc);
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
         } else {
@@ -1304,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) dot += pf[k] * qf.v[k] + pc[k] * qc.v[k];
             dot = lg_sum<LG>(dot);
-            const float var = fmaxf((sp + sq[rq] + 2.0f * dot) * inv2n, 0.0f);
+            const float var = fmaxf((sp + bufQ[rq * LDQ + 2 * FP] + 2.0f * dot) * inv2n, 0.0f);
             const float rstd = fast_rsq(var + 1e-5f);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1324,7 +1353,7 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
         if (active && part > 0)
           store4(bufP + (part * nslots + slot) * LDQ + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
         __syncthreads();
-        request_npK(sd_n, r_n);  // every group has read its npK row before the barrier
+        request_npK(sd_n, r_n, xn);  // every group has read its npK row before the barrier
         if (active && part == 0) {
           for (int p = 1; p < parts; ++p) {
             const Vec4<float> other = load4<float>(bufP + (p * nslots + slot) * LDQ + c0);
@@ -1335,14 +1364,19 @@ __global__ __launch_bounds__(256, 2) void edge_block2_kernel(Edge2Args a) {
       }
       if (active && part == 0) {
         if (a.agg_out) store4(a.agg_out + drow * FP + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
-        const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
-        const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
         Vec4<float> out;
+        if (RN_E2_PROBE & 64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2v.v[k] + c3.v[k]);
-        store4(a.edge_out + drow * FP + c0, out);
+          for (int k = 0; k < 4; ++k) out.v[k] = old.v[k] + c2v.v[k] + acc[k];
+        } else {
+          const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
+          const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2v.v[k] + c3.v[k]);
+        }
+        if (!(RN_E2_PROBE & 1) || out.v[0] == 12345.678f) store4(a.edge_out + drow * FP + c0, out);
       }
-      dma_wait();
+      if (!(RN_E2_PROBE & 2)) dma_wait();
       split_landed_tiles(sd_n >= 0 && sd_n < a.S && r_n < nrD, ss_n < a.S && r_n < nrS);
       __syncthreads();  // S2: bufP may be rewritten; the next round's operand tiles and np rows have landed
     }
@@ -1471,8 +1505,19 @@ void launch_edge_c2(const float *node, float *c2, int S, const Graph &g, Dims d,
   if (S == 0 || g.E == 0) return;
   EdgeC2Args a{node, c2, (int64_t)S * g.E, g, d, w};
   const int64_t tiles = (a.M + 15) / 16;
-  const int tpw = 8;
-  const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
+  // a resident grid (two 4-wave workgroups per CU at 252 VGPRs): every wave loads and splits its 128 VGPRs
+  // of weight fragments once and then walks a contiguous run of tiles
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int64_t waves = std::min<int64_t>((int64_t)2 * cus * 4, tiles);
+  const int tpw = (int)((tiles + waves - 1) / waves);
+  const unsigned blocks = (unsigned)((tiles + (int64_t)4 * tpw - 1) / ((int64_t)4 * tpw));
   const bool pad = d.Fe != d.FeP;
   if (f16) {
     if (pad) edge_c2_kernel<true, true><<<blocks, 256, 0, st>>>(a, tpw);

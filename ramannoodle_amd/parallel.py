@@ -43,18 +43,32 @@ def all_gather_frames(local: torch.Tensor, num_items: int, group=None) -> torch.
     return torch.cat([blocks[r, : sizes[r]] for r in range(world)])
 
 
+def _device_path(model, group) -> bool:
+    """RCCL ranks with the device model: results stay in HBM from the kernels to the all-gather."""
+    return dist.get_backend(group) == "nccl" and hasattr(model, "calc_polarizabilities_device")
+
+
 def calc_polarizabilities_sharded(model, positions_batch: np.ndarray, group=None) -> np.ndarray:
-    """Every rank passes the same ``positions_batch``; each evaluates its block with
-    ``model.calc_polarizabilities`` and all ranks return the full ``(S,3,3)`` array."""
+    """Every rank passes the same ``positions_batch``; each evaluates its block and all ranks return
+    the full ``(S,3,3)`` array.  Over RCCL the block's polarizabilities go from the kernels straight
+    into the all-gather (``calc_polarizabilities_device`` -> ``all_gather_frames``): one copy up (the
+    block's positions), one copy down (the gathered result), no bounce through the host in between."""
     if not (dist.is_available() and dist.is_initialized()):
         return model.calc_polarizabilities(positions_batch)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = positions_batch.shape[0]
     lo, hi, _ = shard_bounds(total, world, rank)
+    if _device_path(model, group):
+        model._check_positions(positions_batch[:0])  # same shape errors as the host entry
+        model.eval()
+        device = torch.device("cuda", model.device_index)
+        block = torch.from_numpy(np.ascontiguousarray(positions_batch[lo:hi], dtype=np.float64)).to(device)
+        local = model.calc_polarizabilities_device(block) if hi > lo else torch.zeros((0, 3, 3), dtype=torch.float64,
+                                                                                    device=device)
+        return all_gather_frames(local, total, group).cpu().numpy()
     local = model.calc_polarizabilities(positions_batch[lo:hi])
-    on_gpu = dist.get_backend(group) == "nccl"
     tensor = torch.from_numpy(np.ascontiguousarray(local))
-    if on_gpu:
+    if dist.get_backend(group) == "nccl":
         tensor = tensor.cuda()
     return all_gather_frames(tensor, total, group).cpu().numpy()
 
@@ -64,12 +78,27 @@ def calc_raman_tensors_sharded(model, ref_positions: np.ndarray, displacements: 
     """Phonon Raman tensors ``(M,3,3)`` with the modes split into contiguous blocks, one per
     rank (96 modes = 192 displaced cells per GPU at 8 ranks), and one
     all-gather of the ``float64[M_local,3,3]`` blocks.  ``kwargs`` go to
-    ``model.calc_raman_tensors`` (``delta``, ``method``)."""
+    ``model.calc_raman_tensors`` (``delta``, ``method``).  Over RCCL the finite differences
+    (``dynamics/_phonon.py:93-106``) are formed on the device from a float64 device evaluation of the
+    block's ``2 M_local`` displaced cells, so the block goes into the all-gather without leaving HBM."""
     if not (dist.is_available() and dist.is_initialized()):
         return model.calc_raman_tensors(ref_positions, displacements, **kwargs)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = displacements.shape[0]
     lo, hi, _ = shard_bounds(total, world, rank)
+    if _device_path(model, group) and kwargs.get("method", "finite-difference") == "finite-difference":
+        from ramannoodle_amd.constants import RAMAN_TENSOR_CENTRAL_DIFFERENCE
+        delta = float(kwargs.get("delta", RAMAN_TENSOR_CENTRAL_DIFFERENCE))
+        device = torch.device("cuda", model.device_index)
+        if hi > lo:
+            ref = torch.from_numpy(np.ascontiguousarray(ref_positions, dtype=np.float64)).to(device)
+            eps = torch.from_numpy(np.ascontiguousarray(displacements[lo:hi], dtype=np.float64)).to(device) * delta
+            cells = torch.stack((ref[None] + eps, ref[None] - eps), dim=1).reshape(-1, *ref.shape).contiguous()
+            alpha = model.calc_polarizabilities_device(cells, dtype=torch.float64)
+            local = (alpha[0::2] - alpha[1::2]) / delta  # divided by delta, not 2 delta (_phonon.py:106)
+        else:
+            local = torch.zeros((0, 3, 3), dtype=torch.float64, device=device)
+        return all_gather_frames(local.contiguous(), total, group).cpu().numpy()
     if hi > lo:
         local = model.calc_raman_tensors(ref_positions, displacements[lo:hi], **kwargs)
     else:

@@ -413,9 +413,10 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             _lib.check(rc, self._handle, "rn_potgnn_wait")
 
     def calc_polarizabilities_device(self, positions: torch.Tensor, out: torch.Tensor | None = None,
-                                     synchronize: bool = False) -> torch.Tensor:
+                                     synchronize: bool = False, dtype=torch.float32) -> torch.Tensor:
         """Same computation on a device-resident ``float64[S,N,3]`` tensor; returns a device
-        ``float64[S,3,3]`` tensor.  Work is enqueued on torch's current stream."""
+        ``float64[S,3,3]`` tensor.  Work is enqueued on torch's current stream.  ``dtype`` is the
+        arithmetic of the evaluation (``torch.float64``: the kernels instantiated for ``double``)."""
         if not (positions.is_cuda and positions.dtype == torch.float64 and positions.is_contiguous()):
             raise ValueError("positions must be a contiguous float64 device tensor")
         if positions.dim() != 3 or tuple(positions.shape[1:]) != (self.num_atoms, 3):
@@ -426,6 +427,12 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             out = torch.empty((s, 3, 3), dtype=torch.float64, device=positions.device)
         handle = self._ensure_handle()
         stream = torch.cuda.current_stream(positions.device).cuda_stream
+        if _wants_float64(dtype):
+            rc = _lib.load().rn_potgnn_forward_device_f64(
+                handle, C.c_void_p(positions.data_ptr()), s, C.c_void_p(out.data_ptr()), C.c_void_p(stream),
+                int(synchronize))
+            _lib.check(rc, handle, "rn_potgnn_forward_device_f64")
+            return out
         rc = _lib.load().rn_potgnn_forward_device(
             handle, C.c_void_p(positions.data_ptr()), s, C.c_void_p(out.data_ptr()), None,
             C.c_void_p(stream), int(synchronize))
@@ -716,7 +723,7 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         flags = _lib.load().rn_potgnn_config_flags(self._ensure_handle())
         return {"fused_edge_block": bool(flags & 1), "folded_gate_scale": bool(flags & 2),
                 "split_f16_mfma": bool(flags & 4), "narrow_kernels": bool(flags & 8),
-                "mfma_range_fallback": bool(flags & 16)}
+                "mfma_range_fallback": bool(flags & 16), "pipelined_edge_block": bool(flags & 32)}
 
     def set_profiling(self, mode: int) -> None:
         """0 = off, 1 = HIP-event timing of every kernel launch, 100+k = kernel k only."""

@@ -1001,6 +1001,36 @@ def test_train_single_epoch_reduces_loss():
     assert a.shape == (3, 3, 3) and np.isfinite(a).all()
 
 
+def test_sharded_entry_points_keep_results_on_the_device():
+    """``calc_polarizabilities_sharded`` / ``calc_raman_tensors_sharded`` over RCCL (a one-rank ``nccl``
+    group is what one GPU allows): the device path -- evaluation, finite differences and all-gather
+    without a host bounce -- returns what the host entry points return."""
+    import socket
+    import torch.distributed as dist
+    from ramannoodle_amd.parallel import calc_polarizabilities_sharded, calc_raman_tensors_sharded
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g)
+    pos = g["pos_batch"][:9]
+    want = model.calc_polarizabilities(pos)
+    disp = np.random.default_rng(2).normal(size=(5,) + pos.shape[1:]) * 0.05
+    want_rt = model.calc_raman_tensors(g["positions"], disp)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        np.testing.assert_array_equal(calc_polarizabilities_sharded(model, pos), want)
+        got_rt = calc_raman_tensors_sharded(model, g["positions"], disp)
+        assert np.abs(got_rt - want_rt).max() <= 1e-9 * np.abs(want_rt).max()  # same float64 kernels; the +- cells are formed on the device
+        analytic = calc_raman_tensors_sharded(model, g["positions"], disp, method="analytic")
+        np.testing.assert_array_equal(analytic, model.calc_raman_tensors(g["positions"], disp, method="analytic"))
+        with pytest.raises(ValueError, match="wrong shape"):
+            calc_polarizabilities_sharded(model, pos[:, :-1])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_device_radius_graph_bit_exact(golden):
     """K0 on the device: same edge list as the reference (and as the host restatement)."""
     from ramannoodle_amd.pmodel import graph as G

@@ -76,6 +76,34 @@ def test_sharded_evaluation_ranks(tmp_path, world, total):
         np.testing.assert_allclose(np.load(tmp_path / f"t{r}.npy"), expect_tensors, rtol=1e-12, atol=1e-12)
 
 
+def _gather8_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for total in (10_000, 1_536, 10_003):  # config 3's frames, config 4's displaced cells, a ragged split
+            lo, hi, per = shard_bounds(total, world, rank)
+            local = (torch.arange(lo, hi, dtype=torch.float64).view(-1, 1, 1) * torch.ones(1, 3, 3, dtype=torch.float64))
+            got = all_gather_frames(local.contiguous(), total)
+            assert got.shape == (total, 3, 3)
+            assert torch.equal(got[:, 1, 2], torch.arange(total, dtype=torch.float64))
+            if rank == 0:
+                np.save(os.path.join(out_dir, f"sizes_{total}.npy"), np.array([lo, hi, per]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_partition_of_the_baseline_configs(tmp_path):
+    """The exact N = 8 partitions the scaling run uses (BASELINE configs 3 and 4): 10 000 frames ->
+    8 x 1250, 1536 displaced cells -> 8 x 192 (= 96 modes x +-), plus a ragged 10 003; the padded
+    all-gather returns every item once, in order, on every rank."""
+    mp.spawn(_gather8_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert np.load(tmp_path / "sizes_10000.npy").tolist() == [0, 1250, 1250]
+    assert np.load(tmp_path / "sizes_1536.npy").tolist() == [0, 192, 192]
+    assert np.load(tmp_path / "sizes_10003.npy").tolist() == [0, 1251, 1251]
+    assert [shard_bounds(10_000, 8, r)[:2] for r in range(8)] == [(1250 * r, 1250 * (r + 1)) for r in range(8)]
+
+
 def test_shard_bounds_cover_everything():
     for total in (0, 1, 7, 8, 10000):
         for world in (1, 2, 3, 8):
