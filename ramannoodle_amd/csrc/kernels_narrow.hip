@@ -17,6 +17,12 @@
 //     launch, one workgroup per frame, fixed summation order (deterministic).
 // Embeddings keep the padded [rows][16] float layout of the other kernels (geometry, snapshots and
 // the reverse pass share the buffers); padded columns are written as exact zeros.
+// Widths: the kernels are instantiated for compile-time widths FN, FE that are either exact (the
+// documented 5 / 14 and the 5 / 5 of the reference's own tests) or the model's widths rounded up to a
+// multiple of four (PADDED: 4, 8, 12, 16 -- every Fn, Fe <= 16 is covered).  Rounded-up columns carry
+// zero weights, biases and LayerNorm parameters, so they stay exact zeros through every product, gate
+// and tanh; only the LayerNorm statistics have to leave them out (run-time width f, at most three
+// masked columns per half).
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -78,19 +84,22 @@ __device__ __forceinline__ void gated_matvec(cptr W, const float (&x)[K], float 
 
 // LayerNorm(2F) -> sigmoid * tanh over a row held by one lane (torch semantics: biased variance,
 // eps 1e-5); g/b are the padded [filter|core] parameter arrays (wave-uniform -> SGPRs).
-template <int F, int HP>
-__device__ __forceinline__ void ln_gate_row(const float (&x)[2 * F], cptr g, cptr b, float (&out)[F]) {
+// PADDED: only the first f of the F columns of each half are real (F - 3 <= f <= F)
+template <int F, int HP, bool PADDED = false>
+__device__ __forceinline__ void ln_gate_row(const float (&x)[2 * F], cptr g, cptr b, float (&out)[F], int f = F) {
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < 2 * F; ++c) s += x[c];
-  const float mean = s * (1.0f / (2 * F));
+  const float inv = PADDED ? 1.0f / (float)(2 * f) : 1.0f / (2 * F);
+  const float mean = s * inv;
   float d[2 * F], q = 0.f;
 #pragma unroll
   for (int c = 0; c < 2 * F; ++c) {
     d[c] = x[c] - mean;
+    if (PADDED && (c % F) >= F - 3 && (c % F) >= f) d[c] = 0.f;
     q = fmaf(d[c], d[c], q);
   }
-  const float rstd = fast_rsq(q * (1.0f / (2 * F)) + 1e-5f);
+  const float rstd = fast_rsq(q * inv + 1e-5f);
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     const float yf = fmaf(d[k], rstd * g[k], b[k]);  // (one scalar operand per instruction)
@@ -98,19 +107,21 @@ __device__ __forceinline__ void ln_gate_row(const float (&x)[2 * F], cptr g, cpt
     out[k] = gate(yf, yc);
   }
 }
-template <int F>
-__device__ __forceinline__ void ln_row1(const float (&x)[F], cptr g, cptr b, float (&out)[F]) {
+template <int F, bool PADDED = false>
+__device__ __forceinline__ void ln_row1(const float (&x)[F], cptr g, cptr b, float (&out)[F], int f = F) {
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < F; ++c) s += x[c];
-  const float mean = s * (1.0f / F);
+  const float inv = PADDED ? 1.0f / (float)f : 1.0f / F;
+  const float mean = s * inv;
   float d[F], q = 0.f;
 #pragma unroll
   for (int c = 0; c < F; ++c) {
     d[c] = x[c] - mean;
+    if (PADDED && c >= F - 3 && c >= f) d[c] = 0.f;
     q = fmaf(d[c], d[c], q);
   }
-  const float rstd = fast_rsq(q * (1.0f / F) + 1e-5f);
+  const float rstd = fast_rsq(q * inv + 1e-5f);
 #pragma unroll
   for (int c = 0; c < F; ++c) out[c] = fmaf(d[c], rstd * g[c], b[c]);
 }
@@ -123,13 +134,14 @@ struct NodeNarrowArgs {
   const float *__restrict__ node_in;  // [S*N, FnP]
   float *__restrict__ node_out;       // [S*N, FnP]
   int S;
+  int fn;  // the model's Fn (PADDED instantiations: FN is Fn rounded up to a multiple of four)
   Graph g;
   // c1_linear split into its node and edge parts, transposed, padded [filter|core] (PassW layout)
   const float *__restrict__ WnT, *__restrict__ WeT, *__restrict__ bias;
   const float *__restrict__ c1g, *__restrict__ c1b, *__restrict__ fing, *__restrict__ finb;
 };
 
-template <int FN, int FE>
+template <int FN, int FE, bool PADDED>
 __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
   constexpr int FnP = 16, FeP = 16;
   const cptr WnT = as_const(a.WnT), WeT = as_const(a.WeT), bias = as_const(a.bias), c1g = as_const(a.c1g),
@@ -157,12 +169,12 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
     for (int c = 0; c < 2 * FN; ++c) c1[c] = base[c];
     gated_matvec<FE, FN, FnP, 2 * FnP, 0>(WeT, x, c1);
     float gt[FN];
-    ln_gate_row<FN, FnP>(c1, c1g, c1b, gt);
+    ln_gate_row<FN, FnP, PADDED>(c1, c1g, c1b, gt, a.fn);
 #pragma unroll
     for (int k = 0; k < FN; ++k) acc[k] += gt[k];
   }
   float ln[FN], out[FN];
-  ln_row1<FN>(acc, fing, finb, ln);
+  ln_row1<FN, PADDED>(acc, fing, finb, ln, a.fn);
 #pragma unroll
   for (int k = 0; k < FN; ++k) out[k] = fast_tanh(nb[k] + ln[k]);
   store_row<FN, FnP>(a.node_out + gid * FnP, out);
@@ -174,6 +186,7 @@ struct EdgeNarrowArgs {
   float *__restrict__ edge_out;
   const float *__restrict__ node;  // updated node embedding [S*N, FnP]
   int S;
+  int fe;  // the model's Fe (PADDED instantiations: FE is Fe rounded up to a multiple of four)
   Graph g;
   // PassW layout (kernels.hpp): c3_WeT [FeP][4FeP] = (W4 | W5), c3_WnT [FnP][6FeP] = (Wi | Wj | Wk),
   // c3_nshift [6FeP] = (0 | bias | 0), c2_WT [FnP][2FeP]
@@ -201,8 +214,11 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD) {
   return L;
 }
 
-template <int FN, int FE, bool FASTG>
-__global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
+// (two workgroups per SIMD keep 128 VGPRs each: enough for the exact instantiations up to 2 FE = 28 values per
+//  row; the rounded-up ones -- whose weights overflow the 102 SGPRs into VGPR lanes -- and FE = 16 take one
+//  workgroup per SIMD instead of spilling to scratch)
+template <int FN, int FE, bool FASTG, bool PADDED>
+__global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) void edge_narrow_kernel(EdgeNarrowArgs a) {
   constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE), W2 = 2 * FE;
   const cptr c3WeT = as_const(a.c3WeT), c3WnT = as_const(a.c3WnT), c3shift = as_const(a.c3shift),
              c2WT = as_const(a.c2WT), c2bias = as_const(a.c2bias), c3n1gs = as_const(a.c3n1gs),
@@ -246,7 +262,10 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
   // c3_norm_1 with the exp2 scale of the gate folded in (wave-uniform values: SGPRs)
   auto g3 = [&](int c) { return c3n1gs[gcol<FE, FeP>(c)]; };
   auto b3 = [&](int c) { return c3n1bs[gcol<FE, FeP>(c)]; };
-  constexpr float inv2n = 1.0f / W2;
+  const float inv2n = PADDED ? 1.0f / (float)(2 * a.fe) : 1.0f / W2;
+  // PADDED: is column c of a [filter | core] row one of the rounded-up ones?  (only the last three of a half can be)
+  const int fe_rt = a.fe;
+  auto pad_col = [fe_rt](int c) { return PADDED && (c % FE) >= FE - 3 && (c % FE) >= fe_rt; };
 
   for (int s = sg; s < a.S; s += nsg) {
     const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
 #pragma unroll
       for (int c = 0; c < W2; ++c) {
         q[c] -= mean;
+        if (pad_col(c)) q[c] = 0.f;
         ss = fmaf(q[c], q[c], ss);
       }
       if (FASTG) {
@@ -316,6 +336,7 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
 #pragma unroll
       for (int c = 0; c < W2; ++c) {
         p[c] -= mean;
+        if (pad_col(c)) p[c] = 0.f;
         sp = fmaf(p[c], p[c], sp);
       }
       float acc[FE];
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
         }
       }
       float c3[FE];
-      ln_row1<FE>(acc, c3n2g, c3n2b, c3);
+      ln_row1<FE, PADDED>(acc, c3n2g, c3n2b, c3, fe_rt);
       // c2: gate(LayerNorm(c2_linear(node[j] * node[k]))) -> LayerNorm   (_gnn.py:223-228)
       float x[FE], nj[FN], nk[FN];
       load_row<FN>(njrow, nj);
@@ -407,8 +428,8 @@ __global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
       for (int c = 0; c < W2; ++c) c2pre[c] = c2bias[gcol<FE, FeP>(c)];
       gated_matvec<FN, FE, FeP, 2 * FeP, 0>(c2WT, z, c2pre);
       float g2[FE], c2[FE], out[FE];
-      ln_gate_row<FE, FeP>(c2pre, c2n1g, c2n1b, g2);
-      ln_row1<FE>(g2, c2n2g, c2n2b, c2);
+      ln_gate_row<FE, FeP, PADDED>(c2pre, c2n1g, c2n1b, g2, fe_rt);
+      ln_row1<FE, PADDED>(g2, c2n2g, c2n2b, c2, fe_rt);
 #pragma unroll
       for (int k = 0; k < FE; ++k) out[k] = fast_tanh(x[k] + c2[k] + c3[k]);
       store_row<FE, FeP>(a.edge_out + (erow0 + dst) * FeP, out);
@@ -502,37 +523,40 @@ __global__ __launch_bounds__(256) void readout_narrow_kernel(ReadoutNarrowArgs a
 }
 
 // ============================================================================ launchers
-// Instantiated (Fn, Fe) pairs: the documented set first; the others are what the parity fixtures use.
-#define RN_NARROW_PAIRS(X) X(5, 14) X(5, 5) X(6, 10) X(8, 12) X(8, 16) X(16, 16) X(3, 2)
+// Exact instantiations: the documented widths and those of the reference's own tests.  Everything else with
+// Fn, Fe <= 16 runs on the PADDED instantiation of its widths rounded up to multiples of four.
+#define RN_NARROW_EXACT(X) X(5, 14) X(5, 5)
+#define RN_NARROW_GRID(X) \
+  X(4, 4) X(4, 8) X(4, 12) X(4, 16) X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(12, 4) X(12, 8) X(12, 12) X(12, 16) \
+  X(16, 4) X(16, 8) X(16, 12) X(16, 16)
 
-bool narrow_supported(Dims d) {
-  if (d.FnP != 16 || d.FeP != 16) return false;
-#define X(FN, FE) \
-  if (d.Fn == FN && d.Fe == FE) return true;
-  RN_NARROW_PAIRS(X)
-#undef X
-  return false;
-}
+bool narrow_supported(Dims d) { return d.FnP == 16 && d.FeP == 16 && d.Fn >= 1 && d.Fe >= 1; }
 
 size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows) {
-  return narrow_lds(fe, tile_out_rows, tile_in_rows).total;
+  return narrow_lds((fe + 3) / 4 * 4, tile_out_rows, tile_in_rows).total;  // (an upper bound for the exact widths)
 }
 
 void launch_node_narrow(const float *edge, const float *node_in, float *node_out, int S, const Graph &g, Dims d,
                         const PassW<float> &w, hipStream_t st) {
   if (S == 0 || g.N == 0) return;
-  NodeNarrowArgs a{edge, node_in, node_out, S, g, w.c1_WnT, w.c1_WeT, w.c1_bias,
+  NodeNarrowArgs a{edge, node_in, node_out, S, d.Fn, g, w.c1_WnT, w.c1_WeT, w.c1_bias,
                    w.c1_norm.g, w.c1_norm.b, w.final_norm.g, w.final_norm.b};
   const unsigned blocks = (unsigned)(((int64_t)S * g.N + 255) / 256);
 #define X(FN, FE) \
-  if (d.Fn == FN && d.Fe == FE) return (void)(node_narrow_kernel<FN, FE><<<blocks, 256, 0, st>>>(a));
-  RN_NARROW_PAIRS(X)
+  if (d.Fn == FN && d.Fe == FE) return (void)(node_narrow_kernel<FN, FE, false><<<blocks, 256, 0, st>>>(a));
+  RN_NARROW_EXACT(X)
+#undef X
+  const int fnc = (d.Fn + 3) / 4 * 4, fec = (d.Fe + 3) / 4 * 4;
+#define X(FN, FE) \
+  if (fnc == FN && fec == FE) return (void)(node_narrow_kernel<FN, FE, true><<<blocks, 256, 0, st>>>(a));
+  RN_NARROW_GRID(X)
 #undef X
 }
 
-template <int FN, int FE, bool FASTG>
-static void launch_edge_cfg(const EdgeNarrowArgs &a, size_t lds, hipStream_t st) {
-  auto kern = &edge_narrow_kernel<FN, FE, FASTG>;
+template <int FN, int FE, bool FASTG, bool PADDED>
+static void launch_edge_cfg(const EdgeNarrowArgs &a, hipStream_t st) {
+  auto kern = &edge_narrow_kernel<FN, FE, FASTG, PADDED>;
+  const size_t lds = narrow_lds(FE, a.g.max_tile_out_rows, a.g.max_tile_in_rows).total;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -555,21 +579,28 @@ static void launch_edge_cfg(const EdgeNarrowArgs &a, size_t lds, hipStream_t st)
 void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node, int S, const Graph &g, Dims d,
                         const PassW<float> &w, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
-  EdgeNarrowArgs a{edge_in, edge_out, node, S, g, w.c3_WeT, w.c3_WnT, w.c3_nshift, w.c2_WT, w.c2_bias,
+  EdgeNarrowArgs a{edge_in, edge_out, node, S, d.Fe, g, w.c3_WeT, w.c3_WnT, w.c3_nshift, w.c2_WT, w.c2_bias,
                    w.c3_norm_1s.g, w.c3_norm_1s.b, w.c3_norm_2.g, w.c3_norm_2.b,
                    w.c2_norm_1.g, w.c2_norm_1.b, w.c2_norm_2.g, w.c2_norm_2.b};
-  const size_t lds = edge_narrow_lds_bytes(d.Fe, g.max_tile_out_rows, g.max_tile_in_rows);
   // The folded-scale triplet loop (FASTG, kernels_fused.hip) keeps 2 Fe more values per lane alive;
   // here that costs a wave per SIMD (132 vs 100 VGPRs at Fe = 14) and measured 5 % slower than the
   // general loop (4.23 vs 4.03 us per 256-atom structure); forced down to 128 VGPRs (four workgroups per
   // CU again, 16 bytes of scratch) it ties with the general loop (217 k vs 219 k structures/s) although
   // it issues 209 instead of 257 instructions per triplet.  So the general loop is always used.
-#define X(FN, FE)                                        \
-  if (d.Fn == FN && d.Fe == FE) {                        \
-    launch_edge_cfg<FN, FE, false>(a, lds, st);          \
-    return;                                              \
+#define X(FN, FE)                                  \
+  if (d.Fn == FN && d.Fe == FE) {                  \
+    launch_edge_cfg<FN, FE, false, false>(a, st);  \
+    return;                                        \
   }
-  RN_NARROW_PAIRS(X)
+  RN_NARROW_EXACT(X)
+#undef X
+  const int fnc = (d.Fn + 3) / 4 * 4, fec = (d.Fe + 3) / 4 * 4;
+#define X(FN, FE)                                 \
+  if (fnc == FN && fec == FE) {                   \
+    launch_edge_cfg<FN, FE, false, true>(a, st);  \
+    return;                                       \
+  }
+  RN_NARROW_GRID(X)
 #undef X
 }
 
@@ -578,10 +609,15 @@ void launch_readout_narrow(const float *edge, const float *unit4, int S, const G
                            double *alpha, double *alpha_raw, float *pol, hipStream_t st) {
   if (S == 0) return;
   ReadoutNarrowArgs a{edge, unit4, S, g, w, mean9, std9, vec6, alpha, alpha_raw, pol};
-#define X(FN, FE) \
-  if (d.Fe == FE) return (void)(readout_narrow_kernel<FE><<<S, 256, 0, st>>>(a));
-  RN_NARROW_PAIRS(X)
-#undef X
+  // (rounded-up columns are exact zeros all the way: zero weights, BatchNorm fold and biases, ssp(0) = 0)
+  if (d.Fe == 14) return (void)(readout_narrow_kernel<14><<<S, 256, 0, st>>>(a));
+  if (d.Fe == 5) return (void)(readout_narrow_kernel<5><<<S, 256, 0, st>>>(a));
+  switch ((d.Fe + 3) / 4 * 4) {
+    case 4: return (void)(readout_narrow_kernel<4><<<S, 256, 0, st>>>(a));
+    case 8: return (void)(readout_narrow_kernel<8><<<S, 256, 0, st>>>(a));
+    case 12: return (void)(readout_narrow_kernel<12><<<S, 256, 0, st>>>(a));
+    default: return (void)(readout_narrow_kernel<16><<<S, 256, 0, st>>>(a));
+  }
 }
 
 }  // namespace rn
