@@ -17,6 +17,13 @@ struct Graph {
   const int *in_edge;  // [E]  edge ids entering b, ascending
   const int *atom_type;  // [N]
   const int *rev_edge;   // [E]  id of the reverse edge (b -> a), or -1
+  // Storage order of the per-edge arrays (edge embeddings, unit4, readout rows).  0: row e holds edge e, i.e.
+  // rows sorted by (a, b) like the reference's edge list.  1 (narrow pipeline): row p holds edge in_edge[p],
+  // i.e. rows sorted by DESTINATION atom -- the in-edge rows of an atom, which both scatter-aggregates walk,
+  // are then contiguous (whole 128-byte blocks instead of scattered 64-byte rows) and row_of_edge[e] says
+  // where edge e lives.  Edge IDs in every other array keep their (a, b) meaning.
+  int rows_by_dest;
+  const int *row_of_edge;  // [E] inverse of in_edge
   // node tiles for the edge-block kernel
   int num_tiles;
   const int *tile_begin;  // [num_tiles+1] node ranges
@@ -28,6 +35,7 @@ struct Graph {
   int nt_num;
   const int *nt_begin;    // [nt_num+1] node ranges
   int nt_max_in_rows, nt_max_nodes;
+  int nt_narrow;          // the partition was made for node_tiled_kernel (kernels_narrow.hip)
   // triplet enumeration
   const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
   int64_t T;
@@ -239,6 +247,7 @@ void launch_bn_running(float *running_mean, float *running_var, const float *bat
 // Narrow-width kernels (kernels_narrow.hip): one lane per row, compile-time (Fn, Fe) <= 16, float32.
 bool narrow_supported(Dims d);
 size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows);
+size_t node_tiled_lds_bytes(int fn, int fe, int tile_in_rows, int tile_nodes);
 void launch_node_narrow(const float *edge, const float *node_in, float *node_out, int S, const Graph &g, Dims d,
                         const PassW<float> &w, hipStream_t st);
 void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node, int S, const Graph &g, Dims d,

@@ -223,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);   // [16][LDQ] W4 edge_d
   float *bufC = reinterpret_cast<float *>(smem_raw + L.bufC);   // [16][LDQ] c2 pre-activation
   float *atile = reinterpret_cast<float *>(smem_raw + L.atile); // 3 x [16][64] swizzled operand rows
-  float *sq = reinterpret_cast<float *>(smem_raw + L.sq);       // [maxR] |q|^2
   float *nj = reinterpret_cast<float *>(smem_raw + L.nj);       // [maxN][2FP] Wj node[j] + bias
   float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
   float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
@@ -296,15 +295,12 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
   const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
   const int nvalid = min(max(a.d.Fe - c0, 0), 4);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
-  float b3f[4], b3c[4], g3f[4], g3c[4];  // c3_norm_1 with the exp2 scale of the gate folded in
+  float b3f[4], b3c[4];  // c3_norm_1's shift with the exp2 scale of the gate folded in (its scale: s_g3 in LDS)
   {
-    const Vec4<float> gf = load4<float>(a.w.c3_norm_1.g + c0), bf = load4<float>(a.w.c3_norm_1.b + c0);
-    const Vec4<float> gc = load4<float>(a.w.c3_norm_1.g + FP + c0), bc = load4<float>(a.w.c3_norm_1.b + FP + c0);
+    const Vec4<float> bf = load4<float>(a.w.c3_norm_1.b + c0), bc = load4<float>(a.w.c3_norm_1.b + FP + c0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      g3f[i] = -kLog2e * gf.v[i];
       b3f[i] = -kLog2e * bf.v[i];
-      g3c[i] = 2.0f * kLog2e * gc.v[i];
       b3c[i] = 2.0f * kLog2e * bc.v[i];
     }
   }
@@ -393,16 +389,17 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       }
       ss = lg_sum<LG>(ss);
       if (FASTG) {
+        const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          f.v[i] *= g3f[i];
-          c.v[i] *= g3c[i];
+          f.v[i] *= g3f.v[i];
+          c.v[i] *= g3c.v[i];
         }
         ss *= inv2n;
       }
       store4(row + c0, f);
       store4(row + FP + c0, c);
-      if (q4 == 0) sq[r] = ss;
+      if (q4 == 0) row[2 * FP] = ss;  // |q|^2 rides in the row's pad (column 2FP): one pointer serves the whole triplet
     }
     dma_wait();  // round 0's operand rows (issued before the frame loop / in the last round)
     if (s == sg && !RN_PROBE(32)) split_landed_tiles();  // (later frames: split at the end of the previous frame)
@@ -524,13 +521,14 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           float pdf[4], pdc[4];
           {
             const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);
+            const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
             const float two_inv = 2.0f * inv2n;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               pdf[k] = pf[k] * igf.v[k] * two_inv;
               pdc[k] = pc[k] * igc.v[k] * two_inv;
-              pf[k] *= g3f[k];
-              pc[k] *= g3c[k];
+              pf[k] *= g3f.v[k];
+              pc[k] *= g3c.v[k];
             }
           }
           const float spe = sp * inv2n + 1e-5f;
@@ -551,9 +549,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             float4 f, c;  // columns c0..c0+3 of the filter and core halves of one source row
             float s;      // its |q|^2 term
           };
-          auto load_q = [&](int rq) {
-            const float *qr = bufQ + rq * LDQ + c0;
-            return QRow{*reinterpret_cast<const float4 *>(qr), *reinterpret_cast<const float4 *>(qr + FP), sq[rq]};
+          const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
+          auto load_q = [&](const float *qr) {
+            return QRow{*reinterpret_cast<const float4 *>(qr), *reinterpret_cast<const float4 *>(qr + FP), qr[sdelta]};
           };
           auto triplet_q = [&](const QRow &q, float (&sumk)[4]) {
             const float4 qfv = q.f, qcv = q.c;
@@ -582,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
               sumk[2 * hh + 1] = sk.y;
             }
           };
-          auto triplet = [&](int rq, float (&sumk)[4]) { triplet_q(load_q(rq), sumk); };
+          auto triplet = [&](const float *qr, float (&sumk)[4]) { triplet_q(load_q(qr), sumk); };
 #else
           auto triplet = [&](int rq, float (&sumk)[4]) {
             const float *qr = bufQ + rq * LDQ + c0;
@@ -594,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
               dotc = fmaf(pdc[k], qc.v[k], dotc);
             }
             float dot = lg_sum<LG>(dotf + dotc);
-            float ve = dot + (spe + sq[rq]);
+            float ve = dot + (spe + bufQ[rq * LDQ + 2 * FP]);
             ve = ve > 1e-5f ? ve : 1e-5f;
             const float rstd = fast_rsq(ve);
 #pragma unroll
@@ -606,25 +604,35 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
             }
           };
 #endif
-#if RN_FUSED_PAIRWISE
+#if RN_FUSED_PK && RN_FUSED_PAIRWISE
           // two independent triplets per iteration: at two waves per SIMD the second chain
-          // fills the dependency stalls of the first (summation order: even/odd partial sums)
-          float acc2[4] = {0.f, 0.f, 0.f, 0.f};
-          int t = t0;
-          auto row_of = [&](int tt) { return rb + tt + ((rb + tt >= rskip) ? 1 : 0); };
+          // fills the dependency stalls of the first (summation order: even/odd partial sums).
+          // One LDS pointer per lane steps from row to row (two rows where the numbering jumps over the
+          // reverse edge) instead of a row index and an address per triplet.
           // (requesting the next pair's first row early -- a rotated loop, with or without scheduling
           //  barriers -- measured 1-3 % slower: the other wave of the SIMD already covers this latency)
+          float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+          const int tskip = rskip - rb;
+          auto step = [&](const float *p, int tnext) { return p + (tnext == tskip ? 2 * LDQ : LDQ); };
+          const float *qr = bufQ + (rb + t0 + (t0 >= tskip ? 1 : 0)) * LDQ + c0;
+          int t = t0;
           for (; t + 1 < t1; t += 2) {
-            triplet(row_of(t), acc);
-            triplet(row_of(t + 1), acc2);
+            const float *qn = step(qr, t + 1);
+            triplet(qr, acc);
+            triplet(qn, acc2);
+            qr = step(qn, t + 2);
           }
-          if (t < t1) triplet(row_of(t), acc);
+          if (t < t1) triplet(qr, acc);
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
+#elif RN_FUSED_PK
+          for (int t = t0; t < t1; ++t) triplet(bufQ + (rb + t + ((rb + t >= rskip) ? 1 : 0)) * LDQ + c0, acc);
 #else
           for (int t = t0; t < t1; ++t) triplet(rb + t + ((rb + t >= rskip) ? 1 : 0), acc);
 #endif
         } else {
+          const Vec4<float> g3fv = load4<float>(s_g3 + c0), g3cv = load4<float>(s_g3 + FP + c0);
+          const float g3f[4] = {g3fv.v[0], g3fv.v[1], g3fv.v[2], g3fv.v[3]}, g3c[4] = {g3cv.v[0], g3cv.v[1], g3cv.v[2], g3cv.v[3]};
           for (int t = t0; t < t1; ++t) {
             const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
             const float *qr = bufQ + rq * LDQ + c0;
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 #pragma unroll
             for (int k = 0; k < 4; ++k) dot += pf[k] * qf.v[k] + pc[k] * qc.v[k];
             dot = lg_sum<LG>(dot);
-            const float var = fmaxf((sp + sq[rq] + 2.0f * dot) * inv2n, 0.0f);
+            const float var = fmaxf((sp + bufQ[rq * LDQ + 2 * FP] + 2.0f * dot) * inv2n, 0.0f);
             const float rstd = fast_rsq(var + 1e-5f);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
   const float *erow0 = a.edge + (int64_t)s * a.g.E * FeP;
   for (int idx = beg; idx < end; ++idx) {  // ascending edge id == the reference's scatter order
     float x[FE];
-    load_row<FE>(erow0 + (int64_t)a.g.in_edge[idx] * FeP, x);
+    load_row<FE>(erow0 + (int64_t)(a.g.rows_by_dest ? idx : a.g.in_edge[idx]) * FeP, x);
     float c1[2 * FN];
 #pragma unroll
     for (int c = 0; c < 2 * FN; ++c) c1[c] = base[c];
@@ -178,6 +178,160 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
 #pragma unroll
   for (int k = 0; k < FN; ++k) out[k] = fast_tanh(nb[k] + ln[k]);
   store_row<FN, FnP>(a.node_out + gid * FnP, out);
+}
+
+// ---------------------------------------------------------------------------- NodeBlock, LDS-staged rows
+// node_narrow_kernel above lets every lane fetch the 64-byte rows of its atom's in-edges itself: a wave
+// instruction then touches 64 different cache lines for 16 bytes each, and the kernel ends up bound by the
+// vector-memory path at a third of the HBM rate.  Here a workgroup owns a tile of atoms (Graph::nt_*) and
+// streams the tile's in-edge rows through LDS in chunks of 256:
+//   * LDS-DMA brings 16 whole rows per wave instruction (lane l: row l / 4, 16-byte piece l % 4), two
+//     chunks ahead of the arithmetic, double-buffered; slot (row, p) receives global piece p ^ (row / 4 % 4),
+//     which makes the row-per-lane ds_read_b128 of 16 consecutive lanes conflict-free;
+//   * ONE LANE PER ROW computes W_e edge_e + (W_n node[b] + bias) -> LayerNorm(2Fn) -> gate and leaves the
+//     Fn gated values in LDS (column-major, so that the per-atom pass reads without conflicts);
+//   * one lane per atom then adds its in-edge rows in the reference's scatter order, LayerNorm(Fn),
+//     residual tanh (_gnn.py:141-151).
+// A counted vmcnt keeps the youngest chunk's requests in flight across the barrier.
+struct NodeTiledLds {
+  size_t stage, gated, base, ints, total;
+};
+__host__ __device__ inline NodeTiledLds node_tiled_lds(int fn, int maxD, int maxN) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  NodeTiledLds L;
+  size_t off = 0;
+  L.stage = off; off += (size_t)2 * 256 * 16 * 4;             // 2 x [256][16] edge rows, pieces swizzled
+  L.gated = off; off += up((size_t)fn * maxD * 4);            // [fn][maxD] gate outputs of the tile's in-edge rows
+  L.base = off; off += up((size_t)maxN * 2 * fn * 4);         // [maxN][2 fn] W_n node[b] + bias
+  L.ints = off; off += up((size_t)2 * maxD * 4);              // global edge id, tile-local atom of every row
+  L.total = off;
+  return L;
+}
+
+template <int FN, int FE, bool PADDED>
+__global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
+  constexpr int FnP = 16, FeP = 16;
+  const cptr WnT = as_const(a.WnT), WeT = as_const(a.WeT), bias = as_const(a.bias), c1g = as_const(a.c1g),
+             c1b = as_const(a.c1b), fing = as_const(a.fing), finb = as_const(a.finb);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Graph &g = a.g;
+  const int maxD = g.nt_max_in_rows;
+  const NodeTiledLds L = node_tiled_lds(FN, maxD, g.nt_max_nodes);
+  float *stage = reinterpret_cast<float *>(smem_raw + L.stage);
+  float *gated = reinterpret_cast<float *>(smem_raw + L.gated);
+  float *base = reinterpret_cast<float *>(smem_raw + L.base);
+  int *d_edge = reinterpret_cast<int *>(smem_raw + L.ints), *d_bl = d_edge + maxD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int logical = blockIdx.x;  // workgroups of one frame group share node rows: keep them on one XCD
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.nt_num;
+  const int sg = logical / g.nt_num, nsg = gridDim.x / g.nt_num;
+  const int j0 = g.nt_begin[tile], natoms = g.nt_begin[tile + 1] - j0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j0 + natoms] - di0;
+  const int nchunks = max((dcount + 255) / 256, 1);  // (a tile without in-edges still has its atoms to finish)
+  for (int i = tid; i < dcount; i += 256) {
+    const int e = g.in_edge[di0 + i];
+    d_edge[i] = g.rows_by_dest ? di0 + i : e;  // storage row (Graph::rows_by_dest: the tile's rows are contiguous)
+    d_bl[i] = g.edge_b[e] - j0;
+  }
+  __syncthreads();
+  if (sg >= a.S) return;
+  const int nframes = (a.S - sg + nsg - 1) / nsg;  // frames of this workgroup
+  const int nitems = nframes * nchunks;
+  // chunk `item` (frame sg + (item / nchunks) nsg, rows 256 (item % nchunks) ..) -> stage buffer item & 1:
+  // every wave issues exactly four requests (rows beyond the tile are clamped), so vmcnt can count them
+  auto request = [&](int item) {
+    if (item >= nitems || dcount == 0) return;
+    const int f = item / nchunks, k = item - f * nchunks;
+    const int64_t erow0 = (int64_t)(sg + f * nsg) * g.E;
+    float *buf = stage + (item & 1) * (256 * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 64 * wave + 16 * j + (lane >> 2);           // chunk-local row of this lane's piece
+      const int piece = (lane & 3) ^ ((row >> 2) & 3);
+      const int i = min(256 * k + row, dcount - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(a.edge + (erow0 + d_edge[i]) * FeP + 4 * piece),
+          (__attribute__((address_space(3))) void *)(buf + (64 * wave + 16 * j) * 16), 16, 0, 0);
+    }
+  };
+  request(0);
+  request(1);
+  for (int item = 0; item < nitems; ++item) {
+    const int f = item / nchunks, k = item - f * nchunks;
+    const int s = sg + f * nsg;
+    const int64_t nrow0 = (int64_t)s * g.N;
+    if (k == 0) {
+      // ---- frame start: W_n node[b] + bias of the tile's atoms (one lane per atom)
+      if (tid < natoms) {
+        float nb[FN], bs[2 * FN];
+        load_row<FN>(a.node_in + (nrow0 + j0 + tid) * FnP, nb);
+#pragma unroll
+        for (int c = 0; c < 2 * FN; ++c) bs[c] = bias[gcol<FN, FnP>(c)];
+        gated_matvec<FN, FN, FnP, 2 * FnP, 0>(WnT, nb, bs);
+#pragma unroll
+        for (int c = 0; c < 2 * FN; ++c) base[tid * 2 * FN + c] = bs[c];
+      }
+    }
+    // chunk `item` must have landed; the four requests of chunk item + 1 (issued one chunk ago) may stay in
+    // flight -- unless other operations are outstanding behind them (frame start: the previous frame's loads
+    // and stores) or there is no chunk item + 1
+    if (k == 0 || item + 1 >= nitems) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();  // chunk `item` landed for every wave; base / gated of the previous frame no longer read
+    // ---- one lane per in-edge row of the chunk
+    if (const int i = 256 * k + tid; i < dcount) {
+      const float *row = stage + (item & 1) * (256 * 16) + tid * 16;
+      const int sw = (tid >> 2) & 3;
+      float x[FE];
+#pragma unroll
+      for (int j = 0; j < (FE + 3) / 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * (j ^ sw));
+        const float t4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * j + q < FE) x[4 * j + q] = t4[q];
+      }
+      float c1[2 * FN];
+      const float *bs = base + d_bl[i] * 2 * FN;
+#pragma unroll
+      for (int c = 0; c < 2 * FN; ++c) c1[c] = bs[c];
+      gated_matvec<FE, FN, FnP, 2 * FnP, 0>(WeT, x, c1);
+      float gt[FN];
+      ln_gate_row<FN, FnP, PADDED>(c1, c1g, c1b, gt, a.fn);
+#pragma unroll
+      for (int c = 0; c < FN; ++c) gated[c * maxD + i] = gt[c];
+    }
+    __syncthreads();  // the chunk's stage buffer is free; after the last chunk: gated complete
+    request(item + 2);
+    if (k == nchunks - 1 && tid < natoms) {
+      // ---- one lane per atom: sum of its in-edge rows (ascending = the reference's scatter order)
+      const int b = j0 + tid;
+      const int i0 = g.in_ptr[b] - di0, i1 = g.in_ptr[b + 1] - di0;
+      float acc[FN];
+#pragma unroll
+      for (int c = 0; c < FN; ++c) acc[c] = 0.f;
+      for (int i = i0; i < i1; ++i) {
+#pragma unroll
+        for (int c = 0; c < FN; ++c) acc[c] += gated[c * maxD + i];
+      }
+      float nb[FN], ln[FN], out[FN];
+      load_row<FN>(a.node_in + (nrow0 + b) * FnP, nb);
+      ln_row1<FN, PADDED>(acc, fing, finb, ln, a.fn);
+#pragma unroll
+      for (int c = 0; c < FN; ++c) out[c] = fast_tanh(nb[c] + ln[c]);
+      store_row<FN, FnP>(a.node_out + (nrow0 + b) * FnP, out);
+    }
+  }
+}
+
+// (fn_kernel: the compile-time node width of the instantiation the launcher will pick)
+size_t node_tiled_lds_bytes(int fn, int fe, int tile_in_rows, int tile_nodes) {
+  int fn_kernel = (fn + 3) / 4 * 4;
+  if ((fn == 5 && fe == 14) || (fn == 5 && fe == 5)) fn_kernel = fn;  // RN_NARROW_EXACT
+  return node_tiled_lds(fn_kernel, tile_in_rows, tile_nodes).total;
 }
 
 // ============================================================================ EdgeBlock
@@ -210,7 +364,7 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD) {
   NarrowLds L;
   L.bufQ = 0;
   L.ints = ((size_t)maxR * narrow_ldq(fe) * 4 + 15) & ~size_t(15);
-  L.total = L.ints + (((size_t)maxR + 6 * (size_t)maxD) * 4 + 15 & ~size_t(15));
+  L.total = L.ints + (((size_t)2 * maxR + 6 * (size_t)maxD) * 4 + 15 & ~size_t(15));
   return L;
 }
 
@@ -233,6 +387,7 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   const int maxD = g.max_tile_in_rows;
   int *d_edge = qb + g.max_tile_out_rows, *d_a = d_edge + maxD, *d_bl = d_a + maxD, *d_rb = d_bl + maxD,
       *d_cnt = d_rb + maxD, *d_skip = d_cnt + maxD;
+  int *q_row = d_skip + maxD;  // [maxR] storage row of the tile's source edges
   const int tid = threadIdx.x;
 
   int logical = blockIdx.x;  // workgroups of one frame group share node rows: keep them on one XCD
@@ -244,13 +399,16 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
 
   // ---- once per launch: the tile's topology -> LDS (the graph is the same in every frame)
-  for (int r = tid; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
+  for (int r = tid; r < rows; r += 256) {
+    qb[r] = g.edge_b[eo0 + r];
+    q_row[r] = g.rows_by_dest ? g.row_of_edge[eo0 + r] : eo0 + r;
+  }
   for (int i = tid; i < dcount; i += 256) {
     const int dst = g.in_edge[di0 + i];
     const int ad = g.edge_a[dst], bd = g.edge_b[dst];
     const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
     const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
-    d_edge[i] = dst;
+    d_edge[i] = g.rows_by_dest ? di0 + i : dst;  // storage row of the destination edge
     d_a[i] = ad;
     d_bl[i] = bd - j0;
     d_rb[i] = rb;
@@ -275,7 +433,7 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
 #endif
     for (int r = tid; r < rows; r += 256) {
       float x[FE], nb[FN];
-      load_row<FE>(a.edge_in + (erow0 + eo0 + r) * FeP, x);
+      load_row<FE>(a.edge_in + (erow0 + q_row[r]) * FeP, x);
       load_row<FN>(a.node + (nrow0 + qb[r]) * FnP, nb);
       float q[W2], sum = 0.f;
 #pragma unroll
@@ -536,11 +694,50 @@ size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows) {
   return narrow_lds((fe + 3) / 4 * 4, tile_out_rows, tile_in_rows).total;  // (an upper bound for the exact widths)
 }
 
+template <int FN, int FE, bool PADDED>
+static void launch_node_tiled_cfg(const NodeNarrowArgs &a, hipStream_t st) {
+  auto kern = &node_tiled_kernel<FN, FE, PADDED>;
+  const size_t lds = node_tiled_lds(FN, a.g.nt_max_in_rows, a.g.nt_max_nodes).total;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, 4);
+  int nsg = per_cu * cus / a.g.nt_num;
+  nsg = nsg < 1 ? 1 : (nsg > a.S ? a.S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)a.g.nt_num, 256, lds, st>>>(a);
+}
+static void launch_node_tiled(const NodeNarrowArgs &a, Dims d, hipStream_t st) {
+#define X(FN, FE) \
+  if (d.Fn == FN && d.Fe == FE) return launch_node_tiled_cfg<FN, FE, false>(a, st);
+  RN_NARROW_EXACT(X)
+#undef X
+  const int fnc = (d.Fn + 3) / 4 * 4, fec = (d.Fe + 3) / 4 * 4;
+#define X(FN, FE) \
+  if (fnc == FN && fec == FE) return launch_node_tiled_cfg<FN, FE, true>(a, st);
+  RN_NARROW_GRID(X)
+#undef X
+}
+
 void launch_node_narrow(const float *edge, const float *node_in, float *node_out, int S, const Graph &g, Dims d,
                         const PassW<float> &w, hipStream_t st) {
   if (S == 0 || g.N == 0) return;
   NodeNarrowArgs a{edge, node_in, node_out, S, d.Fn, g, w.c1_WnT, w.c1_WeT, w.c1_bias,
                    w.c1_norm.g, w.c1_norm.b, w.final_norm.g, w.final_norm.b};
+  static const bool tiled_ok = !(getenv("RN_POTGNN_NODE_TILED") && atoi(getenv("RN_POTGNN_NODE_TILED")) == 0);
+  if (tiled_ok && g.nt_num > 0 && g.nt_narrow) {
+    launch_node_tiled(a, d, st);
+    return;
+  }
   const unsigned blocks = (unsigned)(((int64_t)S * g.N + 255) / 256);
 #define X(FN, FE) \
   if (d.Fn == FN && d.Fe == FE) return (void)(node_narrow_kernel<FN, FE, false><<<blocks, 256, 0, st>>>(a));
