@@ -148,7 +148,7 @@ CONFIGS = {
     3: dict(cells=(4, 4, 2), frames=10_000, seed=33, scaling="strong"),
     2: dict(cells=(4, 2, 2), frames=1_000, seed=22, scaling="weak"),
 }
-PROFILE_ROUNDS = ("r02", "r01")  # newest first: where committed PMC summaries are looked up
+PROFILE_ROUNDS = ("r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
 
 
 def algorithmic_bytes_edge_block(n, e, fn, fe):
@@ -326,16 +326,49 @@ def cpu_baseline(workload, sample, reps=3):
 
 
 # ----------------------------------------------------------------------------- launch
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT opening the HIP runtime in it (torch.cuda.device_count() falls
+    through to hipGetDeviceCount on ROCm builds without amdsmi): compute nodes of the KFD topology,
+    narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None = unknown (the ranks then find out)."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(nodes):
+        return 0  # no amdgpu compute driver on this machine
+    try:
+        count = 0
+        for node in os.listdir(nodes):
+            with open(os.path.join(nodes, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        listed = os.environ.get(var)
+        if listed is not None:
+            count = min(count, len([d for d in listed.split(",") if d.strip() != ""]))
+    return count
+
+
 def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.
-    Nothing in this (parent) process has touched the GPU: counting devices does not
-    initialise HIP, and the children are fresh interpreters."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  The parent
+    never touches the GPU (devices are counted from sysfs); the children are fresh interpreters.  The
+    rendezvous port is picked by binding port 0 and releasing it, which another process can win before
+    rank 0 binds it: a rank that finds the address in use exits with code 98 and the launch is retried on a
+    fresh port."""
     import socket
     import subprocess
     share = os.environ.get("RN_BENCH_SHARE_GPU", "0") == "1"
-    have = torch.cuda.device_count()
-    if not share and have < n:
+    have = visible_gpu_count()
+    if not share and have is not None and have < n:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    for attempt in range(3):
+        code = _spawn_once(n, socket, subprocess)
+        if code != 98 or attempt == 2:
+            return code
+    return code
+
+
+def _spawn_once(n, socket, subprocess):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -357,6 +390,8 @@ def spawn_ranks(n):
                     codes[i] = p.wait()
             break
         time.sleep(0.05)
+    if any(c == 98 for c in codes):
+        return 98
     return max((abs(c) for c in codes), default=0)
 
 
@@ -377,8 +412,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the N = 1 extras: pipelined host-buffer rate, documented widths, the reference's "
-                         "published TiO2 workload")
+                    help="skip the N = 1 extras: pipelined host-buffer rate, exact-fp32 comparison run, documented "
+                         "widths, the reference's published TiO2 workload (profiling passes: the timed steps only)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP-event timing of every kernel (perturbs the timed region)")
@@ -404,10 +439,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        try:
+            if share_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        except Exception as exc:  # pylint: disable=broad-except
+            if "address already in use" in str(exc).lower() or "eaddrinuse" in str(exc).lower():
+                sys.exit(98)  # spawn_ranks retries on a fresh port
+            raise
 
     from ramannoodle_amd.parallel import shard_bounds
     cfg = CONFIGS[args.config]
@@ -459,7 +499,7 @@ def main():
     model.set_profiling(0)
     # informational: the host-buffer entry point (adds PCIe H2D/D2H); never the headline value
     host_rate = None
-    if rank == 0 and mine:
+    if rank == 0 and mine and not args.no_extras:
         host_rate = host_pipelined_rate(model, wl["positions"])
 
     # informational (N = 1): the same step with the matrix products on the exact-fp32 MFMA instead of the
@@ -467,7 +507,7 @@ def main():
     # against a run that makes no use of f16 at all
     exact = None
     if world == 1 and mine and model.config_flags()["split_f16_mfma"] and model.config_flags()["fused_edge_block"] \
-            and "RN_POTGNN_MFMA" not in os.environ:
+            and "RN_POTGNN_MFMA" not in os.environ and not args.no_extras:
         os.environ["RN_POTGNN_MFMA"] = "f32"
         try:
             model32 = wl["model"](device=local, max_chunk_structures=args.chunk)

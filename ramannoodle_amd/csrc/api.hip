@@ -1681,7 +1681,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   }
   if (!nt_narrow) {
     double best = 0;
-    for (int budget = 16; budget <= 256; budget += 8) {
+    const int forced = getenv("RN_POTGNN_NODE_TILE_ROWS") ? atoi(getenv("RN_POTGNN_NODE_TILE_ROWS")) : 0;  // experiment knob
+    for (int budget = forced > 0 ? forced : 16; budget <= (forced > 0 ? forced : 256); budget += 8) {
       std::vector<int> tb(1, 0);
       int rows_in = 0, max_in = 0, max_nodes = 0, first = 0;
       for (int n = 0; n < N; ++n) {

@@ -2,6 +2,8 @@
 # Profile one bench.py configuration on the GPU box: rocprofv3 kernel stats, HBM traffic (two PMC
 # passes) and SQ utilisation counters (separate PMC passes; never combined with runtime traces).
 #   usage: bash tools/profile.sh TAG [bench.py arguments...]
+# (bench.py runs with --no-cpu --no-extras: every profiled launch belongs to the timed steps, so the PMC passes
+#  -- one step, no warm-up -- cover exactly `frames` structures)
 # Writes gpurun_out/TAG/{stats,fetch,write,sq1,sq2,sq3}/ and the summaries
 # gpurun_out/TAG/{kernel_summary.txt,pmc_traffic.txt,sq_counters.txt}; copy what should be judged
 # into profiles/rNN/.
@@ -15,7 +17,7 @@ cd "$root"
 args=("$@")
 run() {  # name, rocprof options..., then "--" and bench options
   local name="$1"; shift
-  rocprofv3 "$@" --output-format csv -d "$out/$name" -o "$name" -- python3 "$root/bench.py" --no-cpu "${args[@]}" "${extra[@]}" \
+  rocprofv3 "$@" --output-format csv -d "$out/$name" -o "$name" -- python3 "$root/bench.py" --no-cpu --no-extras "${args[@]}" "${extra[@]}" \
     > "$out/$name.log" 2>&1 || { echo "rocprofv3 pass $name failed"; tail -5 "$out/$name.log"; return 1; }
 }
 extra=(--steps 3 --warmup 1)
