@@ -142,9 +142,7 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin,
-      row_of_edge;
-  bool last_rows_by_dest = false;  // storage order of the last evaluation's per-edge arrays (Graph::rows_by_dest)
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin;
   bool use_fused = false;
   bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
@@ -704,9 +702,7 @@ struct ChunkRun {
     c2 = l.c2.template as<T>();
     MN = (int64_t)S * h->g.N;
     ME = (int64_t)S * h->g.E;
-    gx = h->g;
   }
-  Graph gx;  // h->g with the storage order of this run's per-edge rows (Graph::rows_by_dest: narrow pipeline)
   hipStream_t st() const { return ln->stream; }
   // With the tape on, the embeddings after pass p are written straight into tape slot p+1 (the
   // ping-pong pair is re-pointed pass by pass), so recording costs no copies.
@@ -729,14 +725,9 @@ struct ChunkRun {
   void begin() {
     Precision<T> &P = prec<T>(h);
     target_tape(0, 0);
-    // (opt-in: measured a net loss at the documented widths -- the NodeBlock gains 9 %, the EdgeBlock, whose source
-    //  rows are then scattered, loses 17 %: profiles/r03/narrow_experiments.txt)
-    static const bool by_dest = getenv("RN_POTGNN_ROWS_BY_DEST") && atoi(getenv("RN_POTGNN_ROWS_BY_DEST")) != 0;
-    gx.rows_by_dest = (narrow() && by_dest) ? 1 : 0;
-    h->last_rows_by_dest = gx.rows_by_dest != 0;
     {
       Timer t(h, st(), K_GEOM);
-      launch_geom_rbf<T>(d_pos, S, gx, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
+      launch_geom_rbf<T>(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
                          P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
     }
     {
@@ -758,7 +749,7 @@ struct ChunkRun {
     if constexpr (sizeof(T) == 4) {
       if (narrow()) {  // the whole NodeBlock, projections included, in one launch
         Timer t(h, st(), K_NODE_AGG);
-        launch_node_narrow(edge[cur], node[cur], node[nxt], S, gx, d, w, st());
+        launch_node_narrow(edge[cur], node[cur], node[nxt], S, g, d, w, st());
         return;
       }
     }
@@ -818,7 +809,7 @@ struct ChunkRun {
     {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
-        if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, gx, h->d, w, st());
+        if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, h->g, h->d, w, st());
         else if (fused() && h->use_edge2)
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
@@ -1601,7 +1592,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   int max_rows = 0;
   if (narrow_mode && !getenv("RN_POTGNN_TILE_KB")) {
     const size_t per_row = edge_narrow_lds_bytes(d.Fe, 1024, 1024) / 1024 + 1;
-    max_rows = build_tiles(std::max<size_t>(1, std::min<size_t>(256, (size_t)40 * 1024 / per_row)), h->tile_begin);
+    size_t budget = std::min<size_t>(256, (size_t)40 * 1024 / per_row);
+    if (const char *e = getenv("RN_POTGNN_NARROW_TILE_ROWS")) budget = (size_t)std::max(1, atoi(e));  // experiment knob
+    max_rows = build_tiles(std::max<size_t>(1, budget), h->tile_begin);
   } else if (getenv("RN_POTGNN_TILE_KB") || vpl8) {
     const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB")) : 64;
     max_rows = build_tiles(std::max<size_t>(1, tile_kb * 1024 / row_bytes), h->tile_begin);
@@ -1716,8 +1709,6 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     h->trip_off[e + 1] = h->trip_off[e] + cnt;
   }
 
-  h->row_of_edge.assign(E, 0);
-  for (int p = 0; p < E; ++p) h->row_of_edge[h->in_edge[p]] = p;
   h->rev_edge.assign(E, -1);
   for (int e = 0; e < E; ++e) {  // reverse edge (b -> a): binary search in b's sorted out-list
     const int bd = edge_b[e], ad = edge_a[e];
@@ -1743,7 +1734,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
                  o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge),
-                 o_nt = push(hp->nt_begin), o_re = push(hp->row_of_edge);
+                 o_nt = push(hp->nt_begin);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -1774,8 +1765,6 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.nt_max_in_rows = nt_max_in;
     g.nt_max_nodes = nt_max_nodes;
     g.nt_narrow = nt_narrow ? 1 : 0;
-    g.rows_by_dest = 0;
-    g.row_of_edge = base + o_re;
     double ms[18];
     std::memcpy(ms, hp->mean, sizeof(hp->mean));
     std::memcpy(ms + 9, hp->stdv, sizeof(hp->stdv));
@@ -2386,15 +2375,6 @@ int rn_potgnn_debug_stage(rn_potgnn *h, int stage, int index, float *out, size_t
     if ((size_t)(r * c) > out_capacity) throw HipError{hipErrorInvalidValue, "out_capacity too small"};
     HIP_TRY(hipMemcpy2D(out, c * sizeof(float), src, ld * sizeof(float), c * sizeof(float), r,
                         hipMemcpyDeviceToHost));
-    if (h->last_rows_by_dest && stage != 1) {  // per-edge rows are stored by destination atom: back to edge-id order
-      std::vector<float> tmp((size_t)h->g.E * c);
-      for (int s = 0; s < S; ++s) {
-        float *blk = out + (size_t)s * h->g.E * c;
-        std::memcpy(tmp.data(), blk, tmp.size() * sizeof(float));
-        for (int e = 0; e < h->g.E; ++e)
-          std::memcpy(blk + (size_t)e * c, tmp.data() + (size_t)h->row_of_edge[e] * c, (size_t)c * sizeof(float));
-      }
-    }
     *rows = r;
     *cols = c;
   });

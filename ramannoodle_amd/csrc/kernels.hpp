@@ -17,13 +17,6 @@ struct Graph {
   const int *in_edge;  // [E]  edge ids entering b, ascending
   const int *atom_type;  // [N]
   const int *rev_edge;   // [E]  id of the reverse edge (b -> a), or -1
-  // Storage order of the per-edge arrays (edge embeddings, unit4, readout rows).  0: row e holds edge e, i.e.
-  // rows sorted by (a, b) like the reference's edge list.  1 (narrow pipeline): row p holds edge in_edge[p],
-  // i.e. rows sorted by DESTINATION atom -- the in-edge rows of an atom, which both scatter-aggregates walk,
-  // are then contiguous (whole 128-byte blocks instead of scattered 64-byte rows) and row_of_edge[e] says
-  // where edge e lives.  Edge IDs in every other array keep their (a, b) meaning.
-  int rows_by_dest;
-  const int *row_of_edge;  // [E] inverse of in_edge
   // node tiles for the edge-block kernel
   int num_tiles;
   const int *tile_begin;  // [num_tiles+1] node ranges

@@ -111,8 +111,7 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict_
   const int64_t row = r0 + threadIdx.x;
   T dist = 0;
   if (row < total) {
-    const int s = (int)(row / g.E), p = (int)(row % g.E);
-    const int e = g.rows_by_dest ? g.in_edge[p] : p;  // the edge whose row this is (Graph::rows_by_dest)
+    const int s = (int)(row / g.E), e = (int)(row % g.E);
     const int a = g.edge_a[e], b = g.edge_b[e];
     const T *lat = lat_base + (int64_t)s * lat_stride;  // _gnn.py:607-610: the sample's own lattice
     const double *pa = pos + ((int64_t)s * g.N + a) * 3;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
   const float *erow0 = a.edge + (int64_t)s * a.g.E * FeP;
   for (int idx = beg; idx < end; ++idx) {  // ascending edge id == the reference's scatter order
     float x[FE];
-    load_row<FE>(erow0 + (int64_t)(a.g.rows_by_dest ? idx : a.g.in_edge[idx]) * FeP, x);
+    load_row<FE>(erow0 + (int64_t)a.g.in_edge[idx] * FeP, x);
     float c1[2 * FN];
 #pragma unroll
     for (int c = 0; c < 2 * FN; ++c) c1[c] = base[c];
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
   const int nchunks = max((dcount + 255) / 256, 1);  // (a tile without in-edges still has its atoms to finish)
   for (int i = tid; i < dcount; i += 256) {
     const int e = g.in_edge[di0 + i];
-    d_edge[i] = g.rows_by_dest ? di0 + i : e;  // storage row (Graph::rows_by_dest: the tile's rows are contiguous)
+    d_edge[i] = e;
     d_bl[i] = g.edge_b[e] - j0;
   }
   __syncthreads();
@@ -364,7 +364,7 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD) {
   NarrowLds L;
   L.bufQ = 0;
   L.ints = ((size_t)maxR * narrow_ldq(fe) * 4 + 15) & ~size_t(15);
-  L.total = L.ints + (((size_t)2 * maxR + 6 * (size_t)maxD) * 4 + 15 & ~size_t(15));
+  L.total = L.ints + (((size_t)maxR + 6 * (size_t)maxD) * 4 + 15 & ~size_t(15));
   return L;
 }
 
@@ -387,7 +387,6 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   const int maxD = g.max_tile_in_rows;
   int *d_edge = qb + g.max_tile_out_rows, *d_a = d_edge + maxD, *d_bl = d_a + maxD, *d_rb = d_bl + maxD,
       *d_cnt = d_rb + maxD, *d_skip = d_cnt + maxD;
-  int *q_row = d_skip + maxD;  // [maxR] storage row of the tile's source edges
   const int tid = threadIdx.x;
 
   int logical = blockIdx.x;  // workgroups of one frame group share node rows: keep them on one XCD
@@ -399,16 +398,13 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
 
   // ---- once per launch: the tile's topology -> LDS (the graph is the same in every frame)
-  for (int r = tid; r < rows; r += 256) {
-    qb[r] = g.edge_b[eo0 + r];
-    q_row[r] = g.rows_by_dest ? g.row_of_edge[eo0 + r] : eo0 + r;
-  }
+  for (int r = tid; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
   for (int i = tid; i < dcount; i += 256) {
     const int dst = g.in_edge[di0 + i];
     const int ad = g.edge_a[dst], bd = g.edge_b[dst];
     const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
     const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
-    d_edge[i] = g.rows_by_dest ? di0 + i : dst;  // storage row of the destination edge
+    d_edge[i] = dst;
     d_a[i] = ad;
     d_bl[i] = bd - j0;
     d_rb[i] = rb;
@@ -433,7 +429,7 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
 #endif
     for (int r = tid; r < rows; r += 256) {
       float x[FE], nb[FN];
-      load_row<FE>(a.edge_in + (erow0 + q_row[r]) * FeP, x);
+      load_row<FE>(a.edge_in + (erow0 + eo0 + r) * FeP, x);
       load_row<FN>(a.node + (nrow0 + qb[r]) * FnP, nb);
       float q[W2], sum = 0.f;
 #pragma unroll
