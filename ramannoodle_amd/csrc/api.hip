@@ -123,6 +123,7 @@ struct Precision {
   // forward tape + cotangent workspace of the reverse pass (Jacobian d alpha / d r)
   std::vector<DeviceBuf> tape_node, tape_edge, tape_agg;
   DeviceBuf bw[17];
+  DeviceBuf tn_arena;  // partial sums of the weight-gradient products (reverse_pass)
   DeviceBuf tape_z1, bn_stats, grad, seeds, mv, type_sums;  // training: pre-BatchNorm activations, batch sums, gradient blob
   bool tape_on = false;
 };
@@ -1011,6 +1012,23 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     launch_gemm_nt<T>(dY, R, N, Wd + w_off, N, K, dX, accumulate, st);
   };
 
+  // weight-gradient products (float32): per-workgroup partial sums into an arena, ONE reduction at the end
+  TnDeferred tn_store, *tn = nullptr;
+  if constexpr (sizeof(T) == 4) {
+    static const bool tn_atomic = getenv("RN_POTGNN_TN_ATOMIC") && atoi(getenv("RN_POTGNN_TN_ATOMIC")) != 0;
+    if (G && !tn_atomic) {
+      size_t need = tn_partial_elems(ce, HP, 32) + tn_partial_elems(ce, HP, HP) + tn_partial_elems(ce, d.FeP, HP);
+      const size_t per_pass = tn_partial_elems(ce, d.FeP, 4 * d.FeP) + tn_partial_elems(cn, d.FnP, 6 * d.FeP) +
+                              tn_partial_elems(ce, d.FnP, 2 * d.FeP) + tn_partial_elems(ce, d.FeP, 2 * d.FnP) +
+                              tn_partial_elems(cn, d.FnP, 2 * d.FnP);
+      need += per_pass * (size_t)NP;
+      P.tn_arena.ensure(need * sizeof(float));
+      tn_store.arena = P.tn_arena.template as<float>();
+      tn_store.capacity = need;
+      tn = &tn_store;
+    }
+  }
+
   // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
   const T *edgeP = P.tape_edge[NP].template as<T>();
   if (rv.train_bn) {
@@ -1023,10 +1041,10 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   launch_rowgemm<T>(bufA, fe, HP, P.ro.W3T, HP, bufB, P.ones, P.ro.b3, true, 0, nullptr, g, st);
   launch_rowgemm<T>(bufB, fe, HP, P.ro.W5T, 32, b[POL], nullptr, P.ro.b5, false, 0, nullptr, g, st);
   launch_readout_bwd<T>(rv.d_dout6, b[POL], unit4, C, B, g, b[DPOL], b[DUNIT], st);
-  if (G) launch_gemm_tn<T>(bufB, HP, b[DPOL], 32, ce, HP, 32, G + L.W5T, 32, G + L.b5, 0, nullptr, g, st);
+  if (G) launch_gemm_tn<T>(bufB, HP, b[DPOL], 32, ce, HP, 32, G + L.W5T, 32, G + L.b5, 0, nullptr, g, st, tn);
   back_gemm(b[DPOL], ce, 32, L.W5T, L.t_W5, HP, b[DH], false);                     // d h2
   launch_ssp_bwd<T>(b[DH], bufB, nullptr, E, HP, C, B, st);                        // d z2
-  if (G) launch_gemm_tn<T>(bufA, HP, b[DH], HP, ce, HP, HP, G + L.W3T, HP, G + L.b3, 0, nullptr, g, st);
+  if (G) launch_gemm_tn<T>(bufA, HP, b[DH], HP, ce, HP, HP, G + L.W3T, HP, G + L.b3, 0, nullptr, g, st, tn);
   back_gemm(b[DH], ce, HP, L.W3T, L.t_W3, HP, b[DC2], false);                      // d h1
   if (rv.train_bn) {
     launch_ssp_bwd<T>(b[DC2], bufA, nullptr, E, HP, C, B, st);                     // d (BN output)
@@ -1036,7 +1054,7 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     reduce_over_ranks(h, sums, (size_t)2 * HP, st);
     launch_bn_bwd_apply<T>(b[DC2], P.tape_z1.template as<T>(), fe, HP, d.Fe, stats, h->bn_count, sums, own,
                            Wd + L.bn_w, G + L.bn_w, G + L.bn_b, st);               // d z1
-    launch_gemm_tn<T>(edgeP, d.FeP, b[DC2], HP, ce, d.FeP, HP, G + L.W0T, HP, G + L.b0p, 0, nullptr, g, st);
+    launch_gemm_tn<T>(edgeP, d.FeP, b[DC2], HP, ce, d.FeP, HP, G + L.W0T, HP, G + L.b0p, 0, nullptr, g, st, tn);
   } else {
     launch_ssp_bwd<T>(b[DC2], bufA, P.ro.scale0, E, HP, C, B, st);                 // d acc1
   }
@@ -1066,8 +1084,6 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     launch_rowgemm<T>(edge0, fe, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0, nullptr, g, st);
     launch_rowgemm<T>(nullptr, fe, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1, node1, g, st);
     // EdgeBlock
-    HIP_TRY(hipMemsetAsync(b[DPQ], 0, sizes[DPQ] * sizeof(T), st));
-    HIP_TRY(hipMemsetAsync(b[DNP3], 0, sizes[DNP3] * sizeof(T), st));
     launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, P.tape_agg[p].template as<T>(), de_next, de_prev, b[DPQ],
                        b[DNP3], b[DC2], C, B, g, d, w, G ? &gw : nullptr, st);
     back_gemm(b[DPQ], ce, 4 * d.FeP, L.pass[p].c3_WeT, L.pass[p].t_c3We, d.FeP, de_prev, true);
@@ -1078,9 +1094,11 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     launch_prod_bwd<T>(b[DPROD], node1, dn_next, C, B, g, d, st);
     if (G) {
       const auto &q = L.pass[p];
-      launch_gemm_tn<T>(edge0, d.FeP, b[DPQ], 4 * d.FeP, ce, d.FeP, 4 * d.FeP, G + q.c3_WeT, 4 * d.FeP, nullptr, 0, nullptr, g, st);
-      launch_gemm_tn<T>(node1, d.FnP, b[DNP3], 6 * d.FeP, cn, d.FnP, 6 * d.FeP, G + q.c3_WnT, 6 * d.FeP, G + q.c3_nshift, 0, nullptr, g, st);
-      launch_gemm_tn<T>(nullptr, d.FnP, b[DC2], 2 * d.FeP, ce, d.FnP, 2 * d.FeP, G + q.c2_WT, 2 * d.FeP, G + q.c2_bias, 1, node1, g, st);
+      launch_gemm_tn<T>(edge0, d.FeP, b[DPQ], 4 * d.FeP, ce, d.FeP, 4 * d.FeP, G + q.c3_WeT, 4 * d.FeP, nullptr, 0, nullptr, g, st, tn);
+      launch_gemm_tn<T>(node1, d.FnP, b[DNP3], 6 * d.FeP, cn, d.FnP, 6 * d.FeP, G + q.c3_WnT, 6 * d.FeP, G + q.c3_nshift, 0, nullptr, g, st, tn);
+      // (d prod is consumed: its buffer takes the c2 operand node[b]*node[a], read as plain rows)
+      launch_prod_fwd<T>(node1, b[DPROD], fe, g, d, st);
+      launch_gemm_tn<T>(b[DPROD], d.FnP, b[DC2], 2 * d.FeP, ce, d.FnP, 2 * d.FeP, G + q.c2_WT, 2 * d.FeP, G + q.c2_bias, 0, nullptr, g, st, tn);
     }
     // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
     launch_rowgemm<T>(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
@@ -1090,11 +1108,12 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     back_gemm(b[DNPC1], cn, 2 * d.FnP, L.pass[p].c1_WnT, L.pass[p].t_c1Wn, d.FnP, dn_prev, true);
     if (G) {
       const auto &q = L.pass[p];
-      launch_gemm_tn<T>(edge0, d.FeP, b[DBC1], 2 * d.FnP, ce, d.FeP, 2 * d.FnP, G + q.c1_WeT, 2 * d.FnP, nullptr, 0, nullptr, g, st);
-      launch_gemm_tn<T>(node0, d.FnP, b[DNPC1], 2 * d.FnP, cn, d.FnP, 2 * d.FnP, G + q.c1_WnT, 2 * d.FnP, G + q.c1_bias, 0, nullptr, g, st);
+      launch_gemm_tn<T>(edge0, d.FeP, b[DBC1], 2 * d.FnP, ce, d.FeP, 2 * d.FnP, G + q.c1_WeT, 2 * d.FnP, nullptr, 0, nullptr, g, st, tn);
+      launch_gemm_tn<T>(node0, d.FnP, b[DNPC1], 2 * d.FnP, cn, d.FnP, 2 * d.FnP, G + q.c1_WnT, 2 * d.FnP, G + q.c1_bias, 0, nullptr, g, st, tn);
     }
     cur ^= 1;
   }
+  if (tn) launch_tn_reduce(*tn, st);
   if (G) {
     P.type_sums.ensure((size_t)h->cfg.num_atom_types * d.Fn * sizeof(T));
     launch_node_embed_bwd<T>(b[DN0 + cur], S, g, d, h->cfg.num_atom_types, Wd + L.emb, Wd + L.W2, Wd + L.b2,

@@ -164,6 +164,8 @@ void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_ne
                      const Graph &g, Dims d, const PassW<T> &w, const PassW<T> *grad_w,
                      hipStream_t st);  // grad_w: same layout as w inside the gradient blob, or null
 template <typename T>
+void launch_prod_fwd(const T *node, T *prod, int64_t rows, const Graph &g, Dims d, hipStream_t st);
+template <typename T>
 void launch_prod_bwd(const T *dprod, const T *node, T *dnode, int C, int B, const Graph &g, Dims d,
                      hipStream_t st);
 template <typename T>
@@ -171,9 +173,31 @@ void launch_node_bwd(const T *npc1, const T *bc1, const T *node_next, const T *d
                      T *dnode_prev, T *dbc1, T *dnpc1, int C, int B, const Graph &g, Dims d,
                      const PassW<T> &w, const PassW<T> *grad_w, hipStream_t st);
 // ---- training pieces (weight gradients, BatchNorm in training mode, embedding MLP)
+// Deferred reduction of the weight-gradient products (float32 MFMA path): every product stores one
+// [K+1][N] slice per workgroup into `arena`; launch_tn_reduce sums the slices of all products recorded
+// in `table` with one launch (and resets the record).
+struct TnReduceOp {
+  const float *part;
+  float *dst, *dbias;
+  int nblk, K, N, ldw;
+};
+struct TnReduceTable {
+  static constexpr int MAX_OPS = 32;
+  TnReduceOp ops[MAX_OPS];
+  int wg_begin[MAX_OPS + 1];
+  int num;
+};
+struct TnDeferred {
+  float *arena = nullptr;
+  size_t capacity = 0, used = 0;  // in floats
+  TnReduceTable table{};
+};
+size_t tn_partial_elems(int64_t R, int K, int N);
+void launch_tn_reduce(TnDeferred &df, hipStream_t st);
 template <typename T>
 void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
-                    int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st);
+                    int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st,
+                    TnDeferred *defer = nullptr);
 template <typename T>
 void launch_bn_col_sums(const T *z, int64_t R, int W, double *stats, hipStream_t st);
 template <typename T>

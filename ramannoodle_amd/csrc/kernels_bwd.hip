@@ -710,14 +710,24 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 1 : 2)) void edge_bwd_tile_k
   }
 }
 
-// ---- two-pass variant without LDS atomics ------------------------------------------------
+// ---- wave-per-(atom, half of its destinations) variant --------------------------------------
 // In edge_bwd_tile_kernel every (destination d, source row r) pair adds its 2Fe-wide term to
 // dP'_d (registers) AND to dQ'_r (ds_add_f32): 8 LDS float atomics per pair and lane, and the
-// LDS atomic unit, not the VALU (7 % busy), sets the pace (measured 0.9 ms per launch at
-// batch 32).  Here the pair term is evaluated twice instead -- once by the lane group that
-// owns d (sums over r: dP'), once by the lane group that owns r (sums over d: dQ') -- so both
-// sums stay in registers and leave with plain stores.  Needs the centred P' rows and the
-// per-destination LayerNorm cotangents of the tile in LDS (one workgroup per CU at Fe = 64).
+// LDS atomic unit, not the VALU (7 % busy), sets the pace (measured 0.9 ms per launch at batch 32).
+// Round 2 evaluated the pair term twice instead (once per owner of d, once per owner of r: 0.70 ms).
+// Here it is evaluated ONCE and without LDS atomics (measured: two ds_add_f32 per lane and pair cost
+// more than the second evaluation did, profiles/r03/train_backward.txt): a wave owns one HALF of the
+// destinations entering an atom, takes them 64/LG at a time (one per lane group) and walks the atom's
+// source rows with all its lane groups in step.  dP'_d stays in the group's registers; the wave's
+// contribution to dQ'_r is a sum ACROSS its lane groups (a reduce-scatter, 6 ds_bpermute at LG = 16,
+// leaves every lane two of the 128 values), added with a plain read-modify-write to the wave's OWN copy
+// of the dQ' rows (one copy per half), so no two waves ever touch the same LDS word.
+// LDS: the centred Q' rows, two copies of the dQ' rows and the per-destination LayerNorm cotangents of
+// the tile (one workgroup per CU at Fe = 64); the centred P' rows are parked in dpq's P' half, which
+// the same wave overwrites with dP' when it is done with them.
+#ifndef RN_BWD_PROBE
+#define RN_BWD_PROBE 0  // timing experiments only (results are wrong): 1 no pair terms, 2 no reduce-scatter
+#endif
 template <int FP, typename T, int NT>
 __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
     const T *__restrict__ pq, const T *__restrict__ np3, const T *__restrict__ c2pre,
@@ -735,7 +745,7 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
     return p;
   };
   T *qrows = reinterpret_cast<T *>(carve((size_t)maxR * 2 * FP * sizeof(T)));   // centred Q' rows
-  T *prows = reinterpret_cast<T *>(carve((size_t)maxD * 2 * FP * sizeof(T)));   // centred P' rows
+  T *dqrows = reinterpret_cast<T *>(carve((size_t)2 * maxR * 2 * FP * sizeof(T)));  // dQ' rows, one copy per half
   if (off < (size_t)4 * NT * sizeof(T)) off = (size_t)4 * NT * sizeof(T);            // scratch of wg_sum_atomic_add
   T *dagg_s = reinterpret_cast<T *>(carve((size_t)maxD * FP * sizeof(T)));       // d(sum over triplets), per destination
   T *sq = reinterpret_cast<T *>(carve((size_t)maxR * sizeof(T)));
@@ -747,6 +757,7 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
   int *dl = reinterpret_cast<int *>(carve((size_t)maxD * 6 * 4));
   int *d_edge = dl, *d_a = dl + maxD, *d_bl = dl + 2 * maxD, *d_rb = dl + 3 * maxD,
       *d_cnt = dl + 4 * maxD, *d_skip = dl + 5 * maxD;
+  constexpr int GW = 64 / LG, NW = NT / 64;                                       // lane groups per wave, waves
 
   const int tile = blockIdx.x % g.num_tiles;
   const int cg = blockIdx.x / g.num_tiles, ncg = gridDim.x / g.num_tiles;
@@ -772,6 +783,7 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
   __syncthreads();
 
   const int grp = threadIdx.x / LG, q = threadIdx.x % LG;
+  const int wave = threadIdx.x >> 6, wgrp = (threadIdx.x & 63) / LG;
   const int nvalid = min(max(d.Fe - 4 * q, 0), 4);
   const T inv2n = (T)1 / (T)(2 * d.Fe), invn = (T)1 / (T)d.Fe;
   const Vec4<T> g1f = load4<T>(w.c3_norm_1.g + 4 * q), b1f = load4<T>(w.c3_norm_1.b + 4 * q);
@@ -779,8 +791,8 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
   Vec4<T> G31f{{0, 0, 0, 0}}, B31f = G31f, G31c = G31f, B31c = G31f, G32 = G31f, B32 = G31f;
   Vec4<T> G21f = G31f, B21f = G31f, G21c = G31f, B21c = G31f, G22 = G31f, B22 = G31f;
 
-  // the term of pair (d, r): x = d(P'_d + Q'_r) through LayerNorm(c3_norm_1) and the gate;
-  // `stats` = also accumulate the LayerNorm parameter gradients (first pass only)
+  // the term of pair (d, r): x = d(P'_d + Q'_r) through LayerNorm(c3_norm_1) and the gate; `stats` = also
+  // accumulate the LayerNorm parameter gradients (a zero `dagg` makes the term and those sums vanish)
   auto pair_term = [&](const Vec4<T> &pf, const Vec4<T> &pc, T sp, const Vec4<T> &qf, const Vec4<T> &qc, T sqr,
                        const Vec4<T> &dagg, bool stats, Vec4<T> &xf, Vec4<T> &xc) {
     T dot = 0;
@@ -828,6 +840,7 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
       store4(nj + (size_t)n * 2 * FP + cc, load4<T>(np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + cc));
       store4(dnj + (size_t)n * 2 * FP + cc, Vec4<T>{{0, 0, 0, 0}});
     }
+    for (int i = threadIdx.x; i < 2 * maxR * (2 * FP / 4); i += NT) store4(dqrows + (size_t)i * 4, Vec4<T>{{0, 0, 0, 0}});
     for (int r = grp; r < rows; r += G) {  // centred source rows, as in the forward kernel
       const T *qp = pq + (erow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
       const T *np = np3 + (nrow0 + qb[r]) * (6 * FP) + 4 * q;
@@ -888,8 +901,8 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) sp += pf.v[k] * pf.v[k] + pc.v[k] * pc.v[k];
       sp = lg_sum<LG>(sp);
-      store4(prows + (size_t)i * 2 * FP + 4 * q, pf);
-      store4(prows + (size_t)i * 2 * FP + FP + 4 * q, pc);
+      store4(dpq + cdrow * (4 * FP) + 4 * q, pf);  // parked: read back and replaced by dP' in the pair pass
+      store4(dpq + cdrow * (4 * FP) + FP + 4 * q, pc);
       if (q == 0) sp_s[i] = sp;
       {
         Vec4<T> dagg;
@@ -942,59 +955,102 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
         store4(dc2pre + cdrow * (2 * FP) + FP + 4 * q, dc);
       }
     }
-    __syncthreads();  // qrows, prows, dagg complete
+    __syncthreads();  // qrows, dagg, the parked P' rows complete
 
-    // ---- pass over destinations: dP'_d = sum over source rows
-    for (int i = grp; i < dcount; i += G) {
-      const Vec4<T> pf = load4<T>(prows + (size_t)i * 2 * FP + 4 * q), pc = load4<T>(prows + (size_t)i * 2 * FP + FP + 4 * q);
-      const Vec4<T> dagg = load4<T>(dagg_s + (size_t)i * FP + 4 * q);
-      const T sp = sp_s[i];
-      Vec4<T> dpf{{0, 0, 0, 0}}, dpc{{0, 0, 0, 0}};
-      const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
-      for (int t = 0; t < cnt; ++t) {
-        const int r = rb + t + ((rb + t >= rskip) ? 1 : 0);
-        const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
-        Vec4<T> xf, xc;
-        pair_term(pf, pc, sp, load4<T>(qr), load4<T>(qr + FP), sq[r], dagg, true, xf, xc);
+    // ---- pair terms, once each: wave <- (atom n, half of the destinations entering it); GW destinations at a
+    // time, all lane groups walk the atom's source rows together
+    for (int item = wave; item < ((RN_BWD_PROBE & 1) ? 0 : 2 * (j1 - j0)); item += NW) {
+      const int natoms = j1 - j0;
+      const int half = item / natoms, n = item - half * natoms;  // (halves 0 of all atoms first: the longer ones)
+      const int in0 = g.in_ptr[j0 + n] - di0, in1 = g.in_ptr[j0 + n + 1] - di0;
+      const int nblk = (in1 - in0 + GW - 1) / GW, cut = (nblk + 1) / 2;
+      const int r0 = g.out_ptr[j0 + n] - eo0, r1 = g.out_ptr[j0 + n + 1] - eo0;
+      T *dqh = dqrows + (size_t)half * maxR * 2 * FP;
+      for (int blk = half ? cut : 0; blk < (half ? nblk : cut); ++blk) {
+        const int i = in0 + blk * GW + wgrp;
+        const bool valid = i < in1;
+        const int ic = valid ? i : in0;
+        const int64_t cdrow = cerow0 + d_edge[ic];
+        Vec4<T> pf = load4<T>(dpq + cdrow * (4 * FP) + 4 * q), pc = load4<T>(dpq + cdrow * (4 * FP) + FP + 4 * q);
+        Vec4<T> dagg = load4<T>(dagg_s + (size_t)ic * FP + 4 * q);
+        if (!valid) pf = pc = dagg = Vec4<T>{{0, 0, 0, 0}};  // (an idle lane group: its terms vanish)
+        const T sp = sp_s[ic];
+        const int rskip = d_skip[ic];
+        Vec4<T> dpf{{0, 0, 0, 0}}, dpc{{0, 0, 0, 0}};
+        for (int r = r0; r < r1; ++r) {
+          const T *qr = qrows + (size_t)r * 2 * FP + 4 * q;
+          Vec4<T> dg = dagg;
+          if (r == rskip) dg = Vec4<T>{{0, 0, 0, 0}};  // r is the reverse of this destination: that triplet does not exist
+          Vec4<T> xf, xc;
+          pair_term(pf, pc, sp, load4<T>(qr), load4<T>(qr + FP), sq[r], dg, true, xf, xc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          dpf.v[k] += xf.v[k];
-          dpc.v[k] += xc.v[k];
+          for (int k = 0; k < 4; ++k) {
+            dpf.v[k] += xf.v[k];
+            dpc.v[k] += xc.v[k];
+          }
+          T *dq = dqh + (size_t)r * 2 * FP + 4 * q;
+          if constexpr ((RN_BWD_PROBE & 2) != 0) {
+            dpf.v[0] += xc.v[0];
+          } else if constexpr (GW == 4) {
+            // reduce-scatter over the four lane groups: halves swap xf/xc, then quarters swap column pairs
+            const bool upper = (threadIdx.x & 32) != 0, odd = (threadIdx.x & 16) != 0;
+            T a4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const T send = upper ? xf.v[k] : xc.v[k], keep = upper ? xc.v[k] : xf.v[k];
+              a4[k] = keep + __shfl_xor(send, 32);
+            }
+            T b2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const T send = odd ? a4[k] : a4[2 + k], keep = odd ? a4[2 + k] : a4[k];
+              b2[k] = keep + __shfl_xor(send, 16);
+            }
+            T *o = dq + (upper ? FP : 0) + (odd ? 2 : 0);  // this wave's copy: a plain read-modify-write
+            o[0] += b2[0];
+            o[1] += b2[1];
+          } else {
+            // all-reduce over the wave's lane groups, then lane group 0 adds the row
+#pragma unroll
+            for (int sft = LG; sft < 64; sft <<= 1)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                xf.v[k] += __shfl_xor(xf.v[k], sft);
+                xc.v[k] += __shfl_xor(xc.v[k], sft);
+              }
+            if (wgrp == 0) {
+              Vec4<T> of = load4<T>(dq), oc = load4<T>(dq + FP);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                of.v[k] += xf.v[k];
+                oc.v[k] += xc.v[k];
+              }
+              store4(dq, of);
+              store4(dq + FP, oc);
+            }
+          }
+        }
+        if (valid) {
+          store4(dpq + cdrow * (4 * FP) + 4 * q, dpf);
+          store4(dpq + cdrow * (4 * FP) + FP + 4 * q, dpc);
+          T *dj = dnj + (size_t)d_bl[i] * 2 * FP + 4 * q;  // LDS: the atom belongs to this tile only
+          T *dk = dnp3 + (cnrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
+          atomic_add4(dj, dpf);
+          atomic_add4(dj + FP, dpc);
+          atomic_add4(dk, dpf);
+          atomic_add4(dk + FP, dpc);
         }
       }
-      const int64_t cdrow = cerow0 + d_edge[i];
-      store4(dpq + cdrow * (4 * FP) + 4 * q, dpf);
-      store4(dpq + cdrow * (4 * FP) + FP + 4 * q, dpc);
-      T *dj = dnj + (size_t)d_bl[i] * 2 * FP + 4 * q;  // LDS: the atom belongs to this tile only
-      T *dk = dnp3 + (cnrow0 + d_a[i]) * (6 * FP) + 4 * FP + 4 * q;
-      atomic_add4(dj, dpf);
-      atomic_add4(dj + FP, dpc);
-      atomic_add4(dk, dpf);
-      atomic_add4(dk + FP, dpc);
     }
-    // ---- pass over source rows: dQ'_r = sum over the destinations entering the row's atom
-    for (int r = grp; r < rows; r += G) {
-      const Vec4<T> qf = load4<T>(qrows + (size_t)r * 2 * FP + 4 * q), qc = load4<T>(qrows + (size_t)r * 2 * FP + FP + 4 * q);
-      const T sqr = sq[r];
-      const int n = qn[r];
-      const int i0 = g.in_ptr[j0 + n] - di0, i1 = g.in_ptr[j0 + n + 1] - di0;
-      Vec4<T> dqf{{0, 0, 0, 0}}, dqc{{0, 0, 0, 0}};
-      for (int i = i0; i < i1; ++i) {
-        if (d_skip[i] == r) continue;  // r is the reverse of destination i: that triplet does not exist
-        Vec4<T> xf, xc;
-        pair_term(load4<T>(prows + (size_t)i * 2 * FP + 4 * q), load4<T>(prows + (size_t)i * 2 * FP + FP + 4 * q),
-                  sp_s[i], qf, qc, sqr, load4<T>(dagg_s + (size_t)i * FP + 4 * q), false, xf, xc);
+    __syncthreads();  // dQ' rows and dnj complete
+    for (int i = threadIdx.x; i < rows * (2 * FP / 4); i += NT) {
+      const int r = i / (2 * FP / 4), cc = (i % (2 * FP / 4)) * 4;
+      Vec4<T> v = load4<T>(dqrows + (size_t)r * 2 * FP + cc);
+      const Vec4<T> v1 = load4<T>(dqrows + ((size_t)maxR + r) * 2 * FP + cc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          dqf.v[k] += xf.v[k];
-          dqc.v[k] += xc.v[k];
-        }
-      }
-      T *o = dpq + (cerow0 + eo0 + r) * (4 * FP) + 2 * FP + 4 * q;
-      store4(o, dqf);
-      store4(o + FP, dqc);
+      for (int k = 0; k < 4; ++k) v.v[k] += v1.v[k];
+      store4(dpq + (cerow0 + eo0 + r) * (4 * FP) + 2 * FP + cc, v);
     }
-    __syncthreads();  // dnj complete
     for (int ii = threadIdx.x; ii < (j1 - j0) * (2 * FP / 4); ii += NT) {
       const int n = ii / (2 * FP / 4), cc = (ii % (2 * FP / 4)) * 4;
       store4(dnp3 + (cnrow0 + j0 + n) * (6 * FP) + 2 * FP + cc, load4<T>(dnj + (size_t)n * 2 * FP + cc));
@@ -1019,8 +1075,9 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
 
 static size_t edge_bwd_tile2_lds(const Graph &g, int FP, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  // (qrows and the two dQ' copies; qrows doubles as the scratch of wg_sum_atomic_add)
   const size_t row_arrays = std::max(up((size_t)g.max_tile_out_rows * 2 * FP * elem) +
-                                         up((size_t)g.max_tile_in_rows * 2 * FP * elem), (size_t)2048 * elem);
+                                         up((size_t)2 * g.max_tile_out_rows * 2 * FP * elem), (size_t)2048 * elem);
   return row_arrays + up((size_t)g.max_tile_in_rows * FP * elem) + up((size_t)g.max_tile_out_rows * elem) +
          up((size_t)g.max_tile_in_rows * elem) + 2 * up((size_t)g.max_tile_nodes * 2 * FP * elem) +
          2 * up((size_t)g.max_tile_out_rows * 4) + up((size_t)g.max_tile_in_rows * 6 * 4);
@@ -1087,6 +1144,25 @@ __global__ void prod_bwd_kernel(const T *__restrict__ dprod, const T *__restrict
     for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * nb.v[k];
   }
   store4(dnode + gid * FP + 4 * q, acc);
+}
+
+// prod[c-frame rows][FnP] = node[b_e] * node[a_e]: the operand of c2_linear written out once, so that the
+// weight-gradient product reads plain rows (the gathering form of gemm_tn_mfma_kernel spent 3x the
+// time of the plain one on its dependent index loads).
+template <int LG, typename T>
+__global__ void prod_fwd_kernel(const T *__restrict__ node, T *__restrict__ prod, int64_t rows, Graph g) {
+  constexpr int FP = LG * 4;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG;
+  const int q = threadIdx.x % LG;
+  if (row >= rows) return;
+  const int64_t s = row / g.E;
+  const int e = (int)(row - s * g.E);
+  const Vec4<T> nb = load4<T>(node + (s * g.N + g.edge_b[e]) * FP + 4 * q);
+  const Vec4<T> na = load4<T>(node + (s * g.N + g.edge_a[e]) * FP + 4 * q);
+  Vec4<T> o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o.v[k] = nb.v[k] * na.v[k];
+  store4(prod + row * FP + 4 * q, o);
 }
 
 // =========================================================================== node block
@@ -1250,14 +1326,20 @@ template void launch_geom_bwd<double>(const double *, const double *, const doub
     case 32: CALL(32); break;    \
   }
 
+static bool edge_bwd_two_pass(const Graph &g, int FP, size_t elem) {
+  static const bool no_two_pass = getenv("RN_POTGNN_BWD_ATOMIC") && atoi(getenv("RN_POTGNN_BWD_ATOMIC")) != 0;
+  static const bool simple = getenv("RN_POTGNN_BWD_SIMPLE") && atoi(getenv("RN_POTGNN_BWD_SIMPLE")) != 0;
+  if (FP != 16 && FP != 32 && FP != 64 && FP != 128) return false;
+  return !simple && !no_two_pass && edge_bwd_tile2_lds(g, FP, elem) <= 160 * 1024 - 512;
+}
+
 template <int FP, typename T>
 static bool launch_edge_bwd_tile(const T *pq, const T *np3, const T *c2pre, const T *edge_next,
                                  const T *agg, const T *dedge_next, T *dedge_prev, T *dpq, T *dnp3,
                                  T *dc2pre, int C, int B, const Graph &g, Dims d, const PassW<T> &w,
                                  const PassW<T> &gwv, int want, hipStream_t st) {
-  static const bool no_two_pass = getenv("RN_POTGNN_BWD_ATOMIC") && atoi(getenv("RN_POTGNN_BWD_ATOMIC")) != 0;
   const size_t lds2 = edge_bwd_tile2_lds(g, FP, sizeof(T));
-  const bool two_pass = !no_two_pass && lds2 <= 160 * 1024 - 512;
+  const bool two_pass = edge_bwd_two_pass(g, FP, sizeof(T));
   const size_t lds = two_pass ? lds2 : edge_bwd_tile_lds(g, FP, sizeof(T));
   if (lds > 160 * 1024 - 512) return false;
   // the two-pass kernel holds one tile per CU: 512 threads (two waves per SIMD) share it
@@ -1294,6 +1376,11 @@ void launch_edge_bwd(const T *pq, const T *np3, const T *c2pre, const T *edge_ne
   const int64_t threads = (int64_t)C * g.E * lg;
   if (threads == 0) return;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
+  // dnp3's Wk block is accumulated atomically by every variant; dpq only by the variants that scatter
+  // into it (the two-pass kernel writes every row of both halves exactly once)
+  (void)hipMemsetAsync(dnp3, 0, (size_t)C * g.N * 6 * d.FeP * sizeof(T), st);
+  if (!edge_bwd_two_pass(g, d.FeP, sizeof(T)) || !agg)
+    (void)hipMemsetAsync(dpq, 0, (size_t)C * g.E * 4 * d.FeP * sizeof(T), st);
   static const bool simple = getenv("RN_POTGNN_BWD_SIMPLE") && atoi(getenv("RN_POTGNN_BWD_SIMPLE")) != 0;
   bool done = false;
   if (!simple && agg) {
@@ -1337,6 +1424,18 @@ template void launch_prod_bwd<float>(const float *, const float *, float *, int,
                                      Dims, hipStream_t);
 template void launch_prod_bwd<double>(const double *, const double *, double *, int, int,
                                       const Graph &, Dims, hipStream_t);
+
+template <typename T>
+void launch_prod_fwd(const T *node, T *prod, int64_t rows, const Graph &g, Dims d, hipStream_t st) {
+  const int lg = d.FnP / 4;
+  if (rows == 0) return;
+  const unsigned blocks = (unsigned)((rows * lg + 255) / 256);
+#define CALL(LGV) prod_fwd_kernel<LGV, T><<<blocks, 256, 0, st>>>(node, prod, rows, g)
+  RN_LG_SWITCH(d.FnP, CALL)
+#undef CALL
+}
+template void launch_prod_fwd<float>(const float *, float *, int64_t, const Graph &, Dims, hipStream_t);
+template void launch_prod_fwd<double>(const double *, double *, int64_t, const Graph &, Dims, hipStream_t);
 
 template <typename T>
 void launch_node_bwd(const T *npc1, const T *bc1, const T *node_next, const T *dnode_next,
@@ -1481,7 +1580,12 @@ __global__ __launch_bounds__(256) void gemm_tn_tiled_kernel(const T *__restrict_
 // owns 32 output columns and keeps all K/32 accumulator tiles; partial sums leave with one
 // atomic per element and workgroup.  (The VALU kernel above spent 164 us per call on this.)
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-template <int KT, int AMODE>
+// PART: instead of adding its [K][N] block sum to dWT with atomics (512 workgroups x K x N float
+// atomics per product, up to 1024 of them on one address for the bias: measured 40-60 us of a 60-120 us
+// launch), the workgroup stores it to its own slice of a partial-sum arena (`dWT` = arena base of this
+// product, `ldw` = slice stride in elements); tn_reduce_kernel adds the slices up at the end of the
+// reverse pass, one writer per gradient element (which also makes the weight gradients reproducible).
+template <int KT, int AMODE, bool PART>
 __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restrict__ X, int ldx,
                                                            const float *__restrict__ dY, int ldy, int64_t R,
                                                            int K, int N, float *__restrict__ dWT, int ldw,
@@ -1543,6 +1647,19 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
       for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
     }
   }
+  if (PART) {
+    float *slice = dWT + (size_t)blockIdx.x * ldw;  // [K][N] block sum, then [N] column sums of dY
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (k < K) slice[(size_t)k * N + ncol] = acc[t][i];
+      }
+    bsum += __shfl_xor(bsum, 32);
+    if (h == 0) slice[(size_t)K * N + ncol] = bsum;
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1553,22 +1670,90 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
   if (dbias) atomicAdd(dbias + ncol, bsum);  // both lane halves hold half of the rows
 }
 
+// Sum of the partial slices of every deferred product of a reverse pass: one workgroup per 32 gradient
+// elements (8 lane groups of 32 take every 8th slice, then an LDS sum), one writer per element.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(TnReduceTable t) {
+  __shared__ float red[256];
+  int o = 0;
+  while (o + 1 < t.num && (int)blockIdx.x >= t.wg_begin[o + 1]) ++o;
+  const float *part = t.ops[o].part;
+  const int K = t.ops[o].K, N = t.ops[o].N, nblk = t.ops[o].nblk, ldw = t.ops[o].ldw;
+  float *dst = t.ops[o].dst, *dbias = t.ops[o].dbias;
+  const size_t stride = (size_t)(K + 1) * N;
+  const int e = ((int)blockIdx.x - t.wg_begin[o]) * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  const int count = K * N + (dbias ? N : 0);
+  float sum = 0.f;
+  if (e < count) {
+    const float *p = part + e;
+    int b = sl;
+    for (; b + 24 < nblk; b += 32) {  // four independent loads in flight
+      const float v0 = p[(size_t)b * stride], v1 = p[(size_t)(b + 8) * stride];
+      const float v2 = p[(size_t)(b + 16) * stride], v3 = p[(size_t)(b + 24) * stride];
+      sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < nblk; b += 8) sum += p[(size_t)b * stride];
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (sl == 0 && e < count) {
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) total += red[32 * i + threadIdx.x];
+    if (e < K * N) dst[(size_t)(e / N) * ldw + e % N] += total;
+    else dbias[e - K * N] += total;
+  }
+}
+
+void launch_tn_reduce(TnDeferred &df, hipStream_t st) {
+  if (df.table.num == 0) return;
+  tn_reduce_kernel<<<(unsigned)df.table.wg_begin[df.table.num], 256, 0, st>>>(df.table);
+  df.table.num = 0;
+  df.used = 0;
+}
+
+static int tn_rows_per_block(int64_t R) {
+  static const int target_blocks = getenv("RN_POTGNN_TN_BLOCKS") ? std::max(1, atoi(getenv("RN_POTGNN_TN_BLOCKS"))) : 512;
+  const int rows_per_block = (int)((R + target_blocks - 1) / target_blocks);
+  return std::max(64, (rows_per_block + 7) / 8 * 8);
+}
+
+size_t tn_partial_elems(int64_t R, int K, int N) {
+  const int rpb = tn_rows_per_block(R);
+  return (size_t)((R + rpb - 1) / rpb) * (size_t)(K + 1) * N;
+}
+
 static bool launch_gemm_tn_mfma(const float *X, int ldx, const float *dY, int ldy, int64_t R, int K, int N,
                                 float *dWT, int ldw, float *dbias, int amode, const float *node,
-                                const Graph &g, hipStream_t st) {
+                                const Graph &g, TnDeferred *defer, hipStream_t st) {
   static const bool off = getenv("RN_POTGNN_BWD_VALU_GEMM") && atoi(getenv("RN_POTGNN_BWD_VALU_GEMM")) != 0;
   if (off || K > 128 || N % 32 != 0) return false;
-  // ~512 workgroups or >= 64 rows each: enough parallelism, few atomics per output element
-  int rows_per_block = (int)((R + 511) / 512);
-  rows_per_block = std::max(64, (rows_per_block + 7) / 8 * 8);
+  // ~512 workgroups or >= 64 rows each: enough parallelism, few partial slices per output element
+  const int rows_per_block = tn_rows_per_block(R);
   const dim3 grid((unsigned)((R + rows_per_block - 1) / rows_per_block), (unsigned)((N + 127) / 128));
   const int kt = (K + 31) / 32;
+  const size_t need = (size_t)grid.x * (size_t)(K + 1) * N;
+  bool part = defer && amode == 0 && defer->arena && defer->used + need <= defer->capacity;
+  if (part && defer->table.num == TnReduceTable::MAX_OPS) launch_tn_reduce(*defer, st), part = defer->used + need <= defer->capacity;
+  float *out = dWT;
+  int ld_out = ldw;
+  if (part) {
+    out = defer->arena + defer->used;
+    ld_out = (K + 1) * N;
+    TnReduceTable &t = defer->table;
+    t.ops[t.num] = TnReduceOp{out, dWT, dbias, (int)grid.x, K, N, ldw};
+    if (t.num == 0) t.wg_begin[0] = 0;
+    t.wg_begin[t.num + 1] = t.wg_begin[t.num] + (K * N + (dbias ? N : 0) + 31) / 32;
+    ++t.num;
+    defer->used += need;
+  }
 #define RN_TNM(KTV)                                                                                           \
   do {                                                                                                        \
-    if (amode == 0) gemm_tn_mfma_kernel<KTV, 0><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw,     \
+    if (part) gemm_tn_mfma_kernel<KTV, 0, true><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, out, ld_out,  \
                                                                       dbias, node, g, rows_per_block);        \
-    else gemm_tn_mfma_kernel<KTV, 1><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, node,   \
-                                                           g, rows_per_block);                                \
+    else if (amode == 0) gemm_tn_mfma_kernel<KTV, 0, false><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N,   \
+                                                                      dWT, ldw, dbias, node, g, rows_per_block); \
+    else gemm_tn_mfma_kernel<KTV, 1, false><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias,  \
+                                                           node, g, rows_per_block);                          \
   } while (0)
   switch (kt) {
     case 1: RN_TNM(1); break;
@@ -1582,10 +1767,11 @@ static bool launch_gemm_tn_mfma(const float *X, int ldx, const float *dY, int ld
 
 template <typename T>
 void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K, int N, T *dWT,
-                    int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st) {
+                    int ldw, T *dbias, int amode, const T *node, const Graph &g, hipStream_t st,
+                    TnDeferred *defer) {
   if (R == 0) return;
   if constexpr (sizeof(T) == 4) {
-    if (launch_gemm_tn_mfma(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g, st)) return;
+    if (launch_gemm_tn_mfma(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g, defer, st)) return;
   }
   const int64_t tiles = (R + 127) / 128;
   dim3 grid((unsigned)(tiles < 64 ? tiles : 64), (unsigned)((N + 63) / 64));
@@ -1613,10 +1799,10 @@ void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K,
 }
 template void launch_gemm_tn<float>(const float *, int, const float *, int, int64_t, int, int,
                                     float *, int, float *, int, const float *, const Graph &,
-                                    hipStream_t);
+                                    hipStream_t, TnDeferred *);
 template void launch_gemm_tn<double>(const double *, int, const double *, int, int64_t, int, int,
                                      double *, int, double *, int, const double *, const Graph &,
-                                     hipStream_t);
+                                     hipStream_t, TnDeferred *);
 
 // ---- BatchNorm1d in training mode over all R rows (_gnn.py:534; batch statistics)
 // stats[c] = sum z, stats[W + c] = sum z^2 (float64 accumulators)

@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
   // MFMA/store phase (issue-early / write-late staging), so global latency is off the
   // critical path.  NPF float4 per thread; for amode 1 both gathered node rows are held.
   constexpr int NPF = (BM * C4) / 256;
-  constexpr bool PREFETCH = (KP <= 64);
+#ifndef RN_GEMM_EXT_PREFETCH
+#define RN_GEMM_EXT_PREFETCH 0
+#endif
+  constexpr bool PREFETCH = (KP <= 64) || (RN_GEMM_EXT_PREFETCH && EXT && TN == 1);  // (KP = 128: 64 more registers, only beside one column tile)
   float4 pre[NPF], pre2[AMODE == 1 ? NPF : 1];
   auto fetch = [&](int64_t row0) {
 #pragma unroll
@@ -126,6 +129,15 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
       for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      if (EXT && a.accum) {  // Y += : the old values seed the accumulators, their loads overlap the products
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < a.M) acc[t][r] = a.Y[row * a.NOUT + ncol0 + t * 32 + l31];
+          }
+      }
 #pragma unroll
       for (int s = 0; s < KH; ++s)
 #pragma unroll
@@ -141,7 +153,6 @@ __global__ __launch_bounds__(256) void rowgemm_mfma_kernel(GemmArgs a) {
             float v = acc[t][r];
             if (EPI == 1) v += sh[t];
             if (EPI == 2) v = ssp_fast(v * sc[t] + sh[t]);
-            if (EXT && a.accum) v += a.Y[row * a.NOUT + col];
             a.Y[row * a.NOUT + col] = v;
           }
         }
