@@ -37,6 +37,18 @@ int pad_pow2(int f) {
   return p;
 }
 
+// Fe padded to 64 with a narrower Fn (e.g. Fn = 32 / Fe = 64, Fn = 20 / Fe = 48): padding Fn to 64 as well puts
+// the model on the fused MFMA kernels (their masked LayerNorms handle F < FP) instead of the unfused per-stage
+// chain -- measured 15.4 -> 12.4 us per 128-atom structure (profiles/r03/width_sweep.txt).  The other
+// combinations keep the minimal power-of-two padding: at FeP = 32 the unfused chain moves half the bytes and is
+// faster than the 64-wide fused kernels (7.6 / 9.2 us).  RN_POTGNN_WIDEN=0 disables, =2 widens every 17..64.
+void widen_for_fused(rn::Dims &d) {
+  static const int widen = getenv("RN_POTGNN_WIDEN") ? atoi(getenv("RN_POTGNN_WIDEN")) : 1;
+  if (widen == 0) return;
+  if (d.FeP == 64 && d.FnP < 64) d.FnP = 64;
+  if (widen >= 2 && std::max(d.FnP, d.FeP) == 32) d.FnP = d.FeP = 64;
+}
+
 struct HipError {
   hipError_t code;
   const char *what;
@@ -1545,6 +1557,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   h->cfg = *cfg;
   h->d = {cfg->size_node_embedding, cfg->size_edge_embedding, pad_pow2(cfg->size_node_embedding),
           pad_pow2(cfg->size_edge_embedding)};
+  widen_for_fused(h->d);
   std::memcpy(h->lattice, lattice, sizeof(h->lattice));
   std::memcpy(h->mean, mean, sizeof(h->mean));
   std::memcpy(h->stdv, stddev, sizeof(h->stdv));

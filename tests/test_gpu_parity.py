@@ -667,6 +667,26 @@ def test_every_width_up_to_16_takes_the_narrow_kernels(fn, fe):
     assert _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL, (fn, fe)
 
 
+@pytest.mark.parametrize("fn, fe", [(32, 64), (20, 48), (5, 64), (16, 40)])
+def test_edge_width_padded_to_64_widens_the_node_width_onto_the_fused_kernels(fn, fe):
+    """Fe padded to 64 with a narrower Fn: Fn is padded to 64 as well, so the model runs on the fused MFMA kernels
+    (masked LayerNorms) instead of the unfused chain (profiles/r03/width_sweep.txt).  Inference against the
+    pinned oracle and the reverse-mode Jacobian against autograd through the float64 oracle, ragged graph."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("triclinic20")
+    model, oracle = _random_model(g, 3.0, fn, fe, 2, seed=fn * 97 + fe)
+    pos = g["pos_batch"][:3]
+    got = model.calc_polarizabilities(pos)
+    assert model.config_flags()["fused_edge_block"]
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    assert _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL, (fn, fe)
+    oracle64 = oracle.to(torch.float64)
+    jac_want = O.jacobian(oracle64, pos[1])
+    jac_got = model.alpha_jacobian(pos[1], float64=True)
+    scale = np.abs(jac_want).max()
+    assert np.abs(jac_got - jac_want).max() < 1e-9 * scale, np.abs(jac_got - jac_want).max() / scale
+
+
 @pytest.mark.parametrize(
     "case, cutoff, fn, fe, passes, frames",
     [
