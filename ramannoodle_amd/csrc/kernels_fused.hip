@@ -733,6 +733,15 @@ __host__ __device__ inline NodeFusedLds node_fused_lds(int maxD, int maxN) {
 }
 }  // namespace
 
+// RN_NODE_REGRING = D > 0: the operand rows of the next D rounds travel through a ring of D float4 registers per
+// lane (plain global loads issued D rounds ahead, split and stored to the operand tile one round ahead) instead
+// of one LDS-DMA per round: D x 4 KiB in flight per workgroup instead of 4 KiB.  0 = the LDS-DMA form.
+#ifndef RN_NODE_REGRING
+#define RN_NODE_REGRING 2
+#endif
+#ifndef RN_NODE_PROBE
+#define RN_NODE_PROBE 0  // timing experiments only (results wrong): 1 no MFMA, 2 no gate, 4 no per-atom phase, 8 no npc1 staging
+#endif
 template <bool PAD, bool F16>
 __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -779,33 +788,73 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
   const int nvalid = min(max(a.d.Fn - c0, 0), 4);
   const float inv2n = 1.0f / (float)(2 * a.d.Fn), invn = 1.0f / (float)a.d.Fn;
   __syncthreads();
+  // this lane's LayerNorm(2Fn) parameters stay in registers (16 VGPRs): re-reading them every round was a
+  // quarter of the kernel's LDS traffic
+  const LnParams<float> pf{load4<float>(s_c1g + c0), load4<float>(s_c1b + c0)};
+  const LnParams<float> pc{load4<float>(s_c1g + FP + c0), load4<float>(s_c1b + FP + c0)};
 
-  auto prefetch_round = [&](int s, int r) {
+  [[maybe_unused]] auto prefetch_round = [&](int s, int r) {
     const int row = 4 * wave + quad;
     const int i = min(r * NG + row, dcount - 1);
     const int piece = (l15 ^ row) & 15;
     dma16(a.edge + ((int64_t)s * g.E + d_edge[i]) * FP + 4 * piece, atile + wave * 256);
   };
   // Split-f16 path: as in the EdgeBlock kernel, every lane splits the slot it fetched itself.
-  auto split_landed_tiles = [&]() {
+  [[maybe_unused]] auto split_landed_tiles = [&]() {
     if constexpr (F16) {
       float *slot = atile + wave * 256 + lane * 4;
       *reinterpret_cast<float4 *>(slot) = split_slot(*reinterpret_cast<const float4 *>(slot));
     }
   };
+#if RN_NODE_REGRING
+  constexpr int RING = RN_NODE_REGRING;
+  float4 ring[RING];
+  int fs = sg, fr = 0;  // (frame, round) the next fetch is for
+  auto fetch_next = [&]() {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fs < a.S) {
+      const int row = 4 * wave + quad;
+      const int i = min(fr * NG + row, dcount - 1);
+      const int piece = (l15 ^ row) & 15;
+      v = *reinterpret_cast<const float4 *>(a.edge + ((int64_t)fs * g.E + d_edge[i]) * FP + 4 * piece);
+      if (++fr == nrounds) {
+        fr = 0;
+        fs += nsg;
+      }
+    }
+    return v;
+  };
+  // the ring's head (the next round's rows) -> this lane's slot of the operand tile; refill the tail
+  auto publish_next = [&]() {
+    float4 v = ring[0];
+    if constexpr (F16) v = split_slot(v);
+    *reinterpret_cast<float4 *>(atile + tid * 4) = v;
+#pragma unroll
+    for (int j = 0; j + 1 < RING; ++j) ring[j] = ring[j + 1];
+    ring[RING - 1] = fetch_next();
+  };
+  if (dcount > 0) {
+#pragma unroll
+    for (int j = 0; j < RING; ++j) ring[j] = fetch_next();
+    if (sg < a.S) publish_next();
+  }
+#else
   if (sg < a.S && dcount > 0) prefetch_round(sg, 0);
+#endif
 
   for (int s = sg; s < a.S; s += nsg) {
     const int64_t nrow0 = (int64_t)s * g.N;
-    for (int i = tid; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+    for (int i = tid; i < ((RN_NODE_PROBE & 8) ? 0 : (j1 - j0) * (2 * FP / 4)); i += 256) {
       const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
       store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.npc1 + (nrow0 + j0 + n) * (2 * FP) + c));
     }
+#if !RN_NODE_REGRING
     dma_wait();
     if (s == sg) split_landed_tiles();  // (later frames: split at the end of the previous frame)
-    __syncthreads();  // the DMA'd operand rows of round 0 (every wave's share) have landed
+#endif
+    __syncthreads();  // the operand rows of round 0 (every wave's share) have landed
     for (int r = 0; r < nrounds; ++r) {
-      {
+      if (!(RN_NODE_PROBE & 1)) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if constexpr (F16) {
           f16x8 ah[2], al[2];
@@ -824,13 +873,17 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
       }
       __syncthreads();  // S1: bufP complete, operand tile free
+#if RN_NODE_REGRING
+      if (r + 1 < nrounds || s + nsg < a.S) publish_next();
+#else
       if (r + 1 < nrounds) prefetch_round(s, r + 1);
       else if (s + nsg < a.S) prefetch_round(s + nsg, 0);
+#endif
 #if RN_NODE_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
       const int i = r * NG + grp;
-      if (i < dcount) {
+      if (i < dcount && !(RN_NODE_PROBE & 2)) {
         const float *njr = nj + (size_t)d_bl[i] * 2 * FP + c0;
         Vec4<float> xf = load4<float>(bufP + grp * LDQ + c0), xc = load4<float>(bufP + grp * LDQ + FP + c0);
         const Vec4<float> af = load4<float>(njr), ac = load4<float>(njr + FP);
@@ -839,19 +892,19 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
           xf.v[k] = fmaf(xf.v[k], inv1, af.v[k]);
           xc.v[k] = fmaf(xc.v[k], inv1, ac.v[k]);
         }
-        const LnParams<float> pf{load4<float>(s_c1g + c0), load4<float>(s_c1b + c0)};
-        const LnParams<float> pc{load4<float>(s_c1g + FP + c0), load4<float>(s_c1b + FP + c0)};
         store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
       }
 #if RN_NODE_PRIO
       __builtin_amdgcn_s_setprio(RN_NODE_PRIO);
 #endif
+#if !RN_NODE_REGRING
       dma_wait();
       if (r + 1 < nrounds || s + nsg < a.S) split_landed_tiles();
+#endif
       __syncthreads();  // S2: bufP may be rewritten, next round's operand rows landed; after the last round: gated complete
     }
     // ---- per atom: sum over its in-edges (ascending, as the reference's scatter), LayerNorm, residual
-    for (int n = grp; n < j1 - j0; n += NG) {
+    for (int n = grp; n < ((RN_NODE_PROBE & 4) ? 0 : j1 - j0); n += NG) {
       const int i0 = g.in_ptr[j0 + n] - di0, i1 = g.in_ptr[j0 + n + 1] - di0;
       Vec4<float> acc{{0.f, 0.f, 0.f, 0.f}};
       for (int i = i0; i < i1; ++i) {
