@@ -1706,6 +1706,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   }
   if (!nt_narrow) {
     double best = 0;
+    const bool node_wave = node_fused_wave_tiles() && d.FnP == 64 && d.FeP == 64;
     const int forced = getenv("RN_POTGNN_NODE_TILE_ROWS") ? atoi(getenv("RN_POTGNN_NODE_TILE_ROWS")) : 0;  // experiment knob
     for (int budget = forced > 0 ? forced : 16; budget <= (forced > 0 ? forced : 256); budget += 8) {
       std::vector<int> tb(1, 0);
@@ -1723,8 +1724,20 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       }
       max_nodes = std::max(max_nodes, N - first);
       tb.push_back(N);
-      if (node_fused_lds_bytes(max_in, max_nodes) > (size_t)40 * 1024 && !h->nt_begin.empty()) break;
-      const double cost = (double)((max_in + 15) / 16) * (double)(tb.size() - 1);
+      double cost;
+      if (node_wave) {
+        // wave-autonomous kernel: a workgroup's four waves take the tile's 16-row pieces four at a time;
+        // two workgroups per CU (register-bound), so up to 72 KiB of LDS each
+        if (node_wave_lds_bytes(max_in, max_nodes) > (size_t)72 * 1024 && !h->nt_begin.empty()) break;
+        cost = 0;
+        for (size_t t = 0; t + 1 < tb.size(); ++t) {
+          const int rows_t = h->in_ptr[tb[t + 1]] - h->in_ptr[tb[t]];
+          cost += (double)(((rows_t + 15) / 16 + 3) / 4);
+        }
+      } else {
+        if (node_fused_lds_bytes(max_in, max_nodes) > (size_t)40 * 1024 && !h->nt_begin.empty()) break;
+        cost = (double)((max_in + 15) / 16) * (double)(tb.size() - 1);
+      }
       if (h->nt_begin.empty() || cost < best * 0.995) {
         best = cost;
         h->nt_begin = tb;

@@ -225,6 +225,8 @@ constexpr size_t kFusedLdsBudget = 80 * 1024;
 size_t edge_fused_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
 bool edge_fused_supported(const Graph &g, Dims d);
 size_t node_fused_lds_bytes(const Graph &g);
+bool node_fused_wave_tiles();  // the split-f16 NodeBlock runs wave-autonomous: 16-row tiles, four per workgroup step
+size_t node_wave_lds_bytes(int tile_in_rows, int tile_nodes);
 size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes);
 // `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,

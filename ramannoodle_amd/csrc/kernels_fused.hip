@@ -923,6 +923,195 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
   }
 }
 
+// ---------------------------------------------------------------------------- wave-autonomous NodeBlock
+// The round structure above spends its time between barriers (phase probe, profiles/r03/node_tile_sweep.txt:
+// MFMA stage, gate and per-atom phase of a workgroup are serialised by two barriers per 16-row round).  Here a
+// WAVE owns a 16-row tile of in-edge rows for ALL 128 output columns: the edge part of c1_linear stays in its
+// registers as split-f16 B fragments (128 VGPRs), the operand rows go from global memory straight into A
+// fragments (one 64-byte run per lane, fetched one tile ahead), and LayerNorm(2Fn) + gate run on the
+// accumulators -- a row is spread over the four lanes l15 + 16 quad, so its statistics take two cross-row
+// exchanges.  Only the per-atom sums need the workgroup: the gated rows of the whole atom tile meet in LDS, two
+// barriers per (frame, atom tile) instead of two per 16 rows.  Two workgroups per CU (register-bound).
+namespace {
+struct NodeWaveLds {
+  size_t gated, nj, lnp, ints, total;
+};
+__host__ __device__ inline NodeWaveLds node_wave_lds(int maxD, int maxN) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  NodeWaveLds L;
+  size_t off = 0;
+  L.gated = off; off += up((size_t)maxD * LDG * 4);
+  L.nj = off; off += up((size_t)maxN * 2 * FP * 4);
+  L.lnp = off; off += (size_t)6 * FP * 4;
+  L.ints = off; off += up((size_t)2 * maxD * 4);
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+template <bool PAD>
+__global__ __launch_bounds__(256, 2) void node_block_wave_kernel(NodeFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Graph &g = a.g;
+  const NodeWaveLds L = node_wave_lds(g.nt_max_in_rows, g.nt_max_nodes);
+  float *gated = reinterpret_cast<float *>(smem_raw + L.gated);  // [maxD][LDG] gate outputs of the tile
+  float *nj = reinterpret_cast<float *>(smem_raw + L.nj);        // [maxN][2FP] W_n node + bias
+  float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
+  float *s_c1g = lnp, *s_c1b = lnp + 2 * FP, *s_fg = lnp + 4 * FP, *s_fb = lnp + 5 * FP;
+  int *d_edge = reinterpret_cast<int *>(smem_raw + L.ints), *d_bl = d_edge + g.nt_max_in_rows;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.nt_num;
+  const int sg = logical / g.nt_num, nsg = gridDim.x / g.nt_num;
+  const int j0 = g.nt_begin[tile], j1 = g.nt_begin[tile + 1];
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  const int nmt = (dcount + 15) / 16;
+
+  for (int c = tid; c < 2 * FP; c += 256) {
+    s_c1g[c] = a.w.c1_norm.g[c];
+    s_c1b[c] = a.w.c1_norm.b[c];
+    if (c < FP) {
+      s_fg[c] = a.w.final_norm.g[c];
+      s_fb[c] = a.w.final_norm.b[c];
+    }
+  }
+  for (int i = tid; i < dcount; i += 256) {
+    const int e = g.in_edge[di0 + i];
+    d_edge[i] = e;
+    d_bl[i] = g.edge_b[e] - j0;
+  }
+  WaveB<true> bW[4];  // all 128 columns of the edge part of c1_linear: column tile T = 2 p + t covers 16 T .. 16 T + 15
+  const float s1 = a.w.mfma_scale[0], inv1 = a.w.mfma_scale[1];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) bW[p].load(a.w.c1_WeT, 2 * FP, 32 * p, l15, quad, s1);
+
+  const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
+  const int nvalid = min(max(a.d.Fn - c0, 0), 4);
+  const float inv2n = 1.0f / (float)(2 * a.d.Fn), invn = 1.0f / (float)a.d.Fn;
+  __syncthreads();
+
+  // this lane's run of the operand row of tile-row 16 mt + l15: k = 16 quad .. 16 quad + 15
+  float4 nxt[4];
+  auto fetch = [&](int s, int mt) {
+    const int i = min(mt * 16 + l15, dcount - 1);
+    const float *p = a.edge + ((int64_t)s * g.E + d_edge[i]) * FP + 16 * quad;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const float4 *>(p + 4 * j);
+  };
+  if (sg < a.S && wave < nmt) fetch(sg, wave);
+
+  for (int s = sg; s < a.S; s += nsg) {
+    const int64_t nrow0 = (int64_t)s * g.N;
+    for (int i = tid; i < (j1 - j0) * (2 * FP / 4); i += 256) {
+      const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
+      store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.npc1 + (nrow0 + j0 + n) * (2 * FP) + c));
+    }
+    __syncthreads();  // A: nj complete; the previous frame's per-atom phase is done with `gated`
+    for (int mt = wave; mt < nmt; mt += 4) {
+      float af[KS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        af[4 * j] = nxt[j].x; af[4 * j + 1] = nxt[j].y; af[4 * j + 2] = nxt[j].z; af[4 * j + 3] = nxt[j].w;
+      }
+      {  // the wave's next tile: further down this frame, else its first of the next frame
+        int nm = mt + 4, ns = s;
+        if (nm >= nmt) {
+          nm = wave;
+          ns = s + nsg;
+        }
+        if (ns < a.S && nm < nmt) fetch(ns, nm);
+      }
+      f16x8 ah[2], al[2];
+      split_f16x8(af, ah[0], al[0]);
+      split_f16x8(af + 8, ah[1], al[1]);
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        acc[p][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bW[p].product_split(ah, al, acc[p]);
+      }
+      const int irow = mt * 16 + l15, i = min(irow, dcount - 1);
+      const float *njr = nj + (size_t)d_bl[i] * 2 * FP + 4 * quad;
+      // x[T][j]: column 16 T + 4 quad + j of row l15 (T < 4 filter, T >= 4 core)
+      float x[8][4];
+      float sum = 0.f;
+#pragma unroll
+      for (int T = 0; T < 8; ++T) {
+        const float4 nb = *reinterpret_cast<const float4 *>(njr + 16 * T);
+        const f32x4 v = acc[T >> 1][T & 1];
+        x[T][0] = fmaf(v[0], inv1, nb.x);
+        x[T][1] = fmaf(v[1], inv1, nb.y);
+        x[T][2] = fmaf(v[2], inv1, nb.z);
+        x[T][3] = fmaf(v[3], inv1, nb.w);
+        sum += (x[T][0] + x[T][1]) + (x[T][2] + x[T][3]);
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * inv2n;
+      float q = 0.f;
+#pragma unroll
+      for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[T][j] -= mean;
+          if (PAD) {
+            if (16 * (T & 3) + 4 * quad + j >= a.d.Fn) x[T][j] = 0.f;
+          }
+          q += x[T][j] * x[T][j];
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rstd = fast_rsq(q * inv2n + 1e-5f);
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        const int col = 16 * T + 4 * quad;
+        const float4 gf = *reinterpret_cast<const float4 *>(s_c1g + col), bf = *reinterpret_cast<const float4 *>(s_c1b + col);
+        const float4 gc = *reinterpret_cast<const float4 *>(s_c1g + FP + col), bc = *reinterpret_cast<const float4 *>(s_c1b + FP + col);
+        Vec4<float> out;
+        out.v[0] = gate(x[T][0] * rstd * gf.x + bf.x, x[T + 4][0] * rstd * gc.x + bc.x);
+        out.v[1] = gate(x[T][1] * rstd * gf.y + bf.y, x[T + 4][1] * rstd * gc.y + bc.y);
+        out.v[2] = gate(x[T][2] * rstd * gf.z + bf.z, x[T + 4][2] * rstd * gc.z + bc.z);
+        out.v[3] = gate(x[T][3] * rstd * gf.w + bf.w, x[T + 4][3] * rstd * gc.w + bc.w);
+        if (irow < dcount) store4(gated + (size_t)irow * LDG + col, out);
+      }
+    }
+    __syncthreads();  // B: the tile's gated rows are complete
+    // ---- per atom: sum over its in-edges (ascending, as the reference's scatter), LayerNorm, residual
+    for (int n = grp; n < j1 - j0; n += NG) {
+      const int i0 = g.in_ptr[j0 + n] - di0, i1 = g.in_ptr[j0 + n + 1] - di0;
+      Vec4<float> sacc{{0.f, 0.f, 0.f, 0.f}};
+      for (int i = i0; i < i1; ++i) {
+        const Vec4<float> v = load4<float>(gated + (size_t)i * LDG + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sacc.v[k] += v.v[k];
+      }
+      const LnParams<float> pn{load4<float>(s_fg + c0), load4<float>(s_fb + c0)};
+      const Vec4<float> ln = ln_row<LG, PAD>(sacc, pn, invn, nvalid);
+      const Vec4<float> old = load4<float>(a.node_in + (nrow0 + j0 + n) * FP + c0);
+      Vec4<float> out;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + ln.v[k]);
+      store4(a.node_out + (nrow0 + j0 + n) * FP + c0, out);
+    }
+  }
+}
+
+// RN_POTGNN_NODE_WAVE=1 selects it (with its own atom tiles, csrc/api.hip).  Measured 1.29-1.30 ms per 2000 frames
+// against 1.18 ms for the round-structured kernel (profiles/r03/node_tile_sweep.txt): with 128 VGPRs of weights
+// only eight waves fit a CU, and the kernel turns out throughput-bound (VALU ~0.58 ms + matrix pipe ~0.36 ms per
+// 2000 frames, poorly overlapped at two waves per SIMD) rather than barrier-bound, so it stays opt-in.
+static bool node_wave_enabled() {
+  static const bool on = getenv("RN_POTGNN_NODE_WAVE") ? atoi(getenv("RN_POTGNN_NODE_WAVE")) != 0 : false;
+  return on;
+}
+bool node_fused_wave_tiles() { return node_wave_enabled(); }
+size_t node_wave_lds_bytes(int tile_in_rows, int tile_nodes) { return node_wave_lds(tile_in_rows, tile_nodes).total; }
+
 size_t node_fused_lds_bytes(const Graph &g) { return node_fused_lds(g.nt_max_in_rows, g.nt_max_nodes).total; }
 size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes) { return node_fused_lds(tile_in_rows, tile_nodes).total; }
 
@@ -930,8 +1119,28 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
   if (S == 0 || g.N == 0) return;
   NodeFusedArgs a{edge, node_in, npc1, node_out, S, g, d, w};
-  const size_t lds = node_fused_lds_bytes(g);
   const bool pad = d.Fn != d.FnP;
+  if (f16 && node_wave_enabled()) {
+    const size_t wlds = node_wave_lds(g.nt_max_in_rows, g.nt_max_nodes).total;
+    auto wkern = pad ? &node_block_wave_kernel<true> : &node_block_wave_kernel<false>;
+    if (wlds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+    static int wcus = 0;
+    if (wcus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) wcus = prop.multiProcessorCount;
+      if (wcus <= 0) wcus = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wkern, 256, wlds) != hipSuccess || per_cu < 1) per_cu = 1;
+    per_cu = std::min(per_cu, 2);
+    int nsg = per_cu * wcus / g.nt_num;
+    nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
+    wkern<<<(unsigned)nsg * (unsigned)g.nt_num, 256, wlds, st>>>(a);
+    return;
+  }
+  const size_t lds = node_fused_lds_bytes(g);
   auto kern = f16 ? (pad ? &node_block_fused_kernel<true, true> : &node_block_fused_kernel<false, true>)
                          : (pad ? &node_block_fused_kernel<true, false> : &node_block_fused_kernel<false, false>);
   if (lds > 48 * 1024)
