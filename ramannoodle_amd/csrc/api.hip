@@ -155,9 +155,10 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin;
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin;
   bool use_fused = false;
   bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
+  bool use_edge3 = false;  // fused EdgeBlock on twelve waves, one workgroup per CU (edge_block3_kernel + edge_c2_kernel)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
@@ -478,7 +479,7 @@ size_t per_structure_elems(const rn_potgnn *h) {
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
   const bool lean = lean_workspace(h);
   return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA_width(h, lean) +
-         (lean ? 0 : E * 4 * FeP) + (h->use_edge2 ? E * FeP : 0);
+         (lean ? 0 : E * 4 * FeP) + ((h->use_edge2 || h->use_edge3) ? E * FeP : 0);
 }
 
 // May the fused kernels run their matrix products as split-f16 MFMAs (device_utils.hpp)?
@@ -621,7 +622,7 @@ void ensure_precision(rn_potgnn *h) {
     ln.np3.ensure(S * N * 6 * FeP * sizeof(T));
     ln.bufA.ensure(S * E * bufA * sizeof(T));
     if (!lean) ln.bufB.ensure(S * E * 4 * FeP * sizeof(T));
-    if (sizeof(T) == 4 && h->use_edge2) ln.c2.ensure(S * E * FeP * sizeof(T));
+    if (sizeof(T) == 4 && (h->use_edge2 || h->use_edge3)) ln.c2.ensure(S * E * FeP * sizeof(T));
   }
   if (h->keep_stages) {
     const int np = h->cfg.num_message_passes + 1;
@@ -796,7 +797,7 @@ struct ChunkRun {
                         0, nullptr, g, st());
     }
     if constexpr (sizeof(T) == 4) {
-      if (fused() && h->use_edge2) {  // c2 branch of the EdgeBlock, one finished row per edge
+      if (fused() && (h->use_edge2 || (h->use_edge3 && edge3_applicable(w, h->mfma_f16)))) {  // c2 branch of the EdgeBlock, one finished row per edge
         Timer t(h, st(), K_PROJ_C2);
         launch_edge_c2(node[nxt], c2, S, g, d, w, h->mfma_f16, st());
       }
@@ -823,6 +824,8 @@ struct ChunkRun {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
         if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, h->g, h->d, w, st());
+        else if (fused() && h->use_edge3 && edge3_applicable(w, h->mfma_f16))
+          launch_edge3(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, st());
         else if (fused() && h->use_edge2)
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
@@ -1661,6 +1664,37 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       }
     }
   }
+  // node tiles of the twelve-wave EdgeBlock (edge_block3_kernel): one 768-thread workgroup per CU with the CU's LDS,
+  // 48 destinations per round -> as few rounds as possible in total; among equals the larger tiles (fewer per-tile phases)
+  const bool want_edge3 = getenv("RN_POTGNN_EDGE3") ? atoi(getenv("RN_POTGNN_EDGE3")) != 0 : false;
+  int et_max_rows = 0, et_max_in = 0, et_max_nodes = 0;
+  if (fused_mode && want_edge3) {
+    double best = 0;
+    std::vector<int> tb;
+    const int forced = getenv("RN_POTGNN_EDGE3_TILE_ROWS") ? atoi(getenv("RN_POTGNN_EDGE3_TILE_ROWS")) : 0;  // experiment knob
+    for (size_t budget = forced > 0 ? forced : 16; budget <= (size_t)(forced > 0 ? forced : 300); budget += 2) {
+      const int mr = build_tiles(budget, tb);
+      int max_in = 0, max_nodes = 0;
+      double cost = 0;
+      for (size_t t = 0; t + 1 < tb.size(); ++t) {
+        const int din = h->in_ptr[tb[t + 1]] - h->in_ptr[tb[t]];
+        cost += (double)((din + edge3_dests_per_round() - 1) / edge3_dests_per_round());
+        max_in = std::max(max_in, din);
+        max_nodes = std::max(max_nodes, tb[t + 1] - tb[t]);
+      }
+      if (edge3_lds_bytes(mr, max_in, max_nodes) > kEdge3LdsBudget) {
+        if (!h->et_begin.empty()) break;
+        continue;
+      }
+      if (h->et_begin.empty() || cost <= best) {
+        best = cost;
+        h->et_begin = tb;
+        et_max_rows = mr;
+        et_max_in = max_in;
+        et_max_nodes = max_nodes;
+      }
+    }
+  }
   // node tiles of the fused NodeBlock kernel: consecutive atoms by IN-edges; four workgroups per CU
   // (40 KiB of LDS each), as few rounds x tiles as possible
   int nt_max_in = 0, nt_max_nodes = 0;
@@ -1779,7 +1813,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
                  o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge),
-                 o_nt = push(hp->nt_begin);
+                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -1810,6 +1844,11 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.nt_max_in_rows = nt_max_in;
     g.nt_max_nodes = nt_max_nodes;
     g.nt_narrow = nt_narrow ? 1 : 0;
+    g.et_num = hp->et_begin.empty() ? 0 : (int)hp->et_begin.size() - 1;
+    g.et_begin = base + o_et;
+    g.et_max_out_rows = et_max_rows;
+    g.et_max_in_rows = et_max_in;
+    g.et_max_nodes = et_max_nodes;
     double ms[18];
     std::memcpy(ms, hp->mean, sizeof(hp->mean));
     std::memcpy(ms + 9, hp->stdv, sizeof(hp->stdv));
@@ -1822,6 +1861,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
     hp->use_edge2 = want_fused && want_edge2 && edge2_supported(hp->g, hp->d);
     hp->use_fused = hp->use_edge2 || (want_fused && edge_fused_supported(hp->g, hp->d));
+    hp->use_edge3 = hp->use_fused && !hp->use_edge2 && want_edge3 && edge3_supported(hp->g, hp->d);
     hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
     // Chunk size and lanes.  Throughput rises monotonically with the frames per launch
@@ -2363,7 +2403,7 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
-              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0);
+              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0) | (h->use_edge3 ? 64 : 0);
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);

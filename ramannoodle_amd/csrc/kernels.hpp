@@ -29,6 +29,10 @@ struct Graph {
   const int *nt_begin;    // [nt_num+1] node ranges
   int nt_max_in_rows, nt_max_nodes;
   int nt_narrow;          // the partition was made for node_tiled_kernel (kernels_narrow.hip)
+  // node tiles of the twelve-wave EdgeBlock kernel (edge_block3_kernel: one workgroup per CU, 48 destinations a round)
+  int et_num;
+  const int *et_begin;    // [et_num+1] node ranges
+  int et_max_out_rows, et_max_in_rows, et_max_nodes;
   // triplet enumeration
   const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
   int64_t T;
@@ -222,6 +226,17 @@ void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *l
 // Fused EdgeBlock (kernels_fused.hip): float32, FnP == FeP == 64.  Two workgroups per CU
 // need their LDS footprint within this budget.
 constexpr size_t kFusedLdsBudget = 80 * 1024;
+// Twelve-wave EdgeBlock (edge_block3_kernel + edge_c2_kernel): ONE 768-thread workgroup per CU with the CU's LDS.
+#ifndef RN_E3_WAVES
+#define RN_E3_WAVES 12
+#endif
+constexpr size_t kEdge3LdsBudget = RN_E3_WAVES <= 4 ? 54272 : (RN_E3_WAVES <= 6 ? 80 : 158) * 1024;
+size_t edge3_lds_bytes(int rows, int in_rows, int nodes);
+inline int edge3_dests_per_round() { return 4 * RN_E3_WAVES; }
+bool edge3_supported(const Graph &g, Dims d);
+bool edge3_applicable(const PassW<float> &w, bool f16);
+void launch_edge3(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
+                  const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);
 size_t edge_fused_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
 bool edge_fused_supported(const Graph &g, Dims d);
 size_t node_fused_lds_bytes(const Graph &g);

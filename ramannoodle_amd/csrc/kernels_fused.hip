@@ -84,6 +84,9 @@ struct EdgeFusedArgs {
 #ifndef RN_FUSED_NK_SAMEROUND
 #define RN_FUSED_NK_SAMEROUND 0
 #endif
+#ifndef RN_E3_PAIRWISE
+#define RN_E3_PAIRWISE 1  // twelve-wave kernel: two triplets per loop iteration
+#endif
 #ifndef RN_FUSED_PAIRWISE
 #define RN_FUSED_PAIRWISE 1  // measured +1.3 % isolated, +3 % with two lanes; 240 VGPRs, no spills
 #endif
@@ -694,6 +697,410 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
       __syncthreads();  // S2: bufP / bufC (and, after the last round, bufQ / nj) may be rewritten; next operand rows landed
     }
   }
+}
+
+// ============================================================================ EdgeBlock, twelve waves
+// The same frame structure as edge_block_fused_kernel with THREE waves per SIMD instead of two: its VALU idles
+// 39 % of the time at two waves per SIMD (profiles/r03/edge2_experiment.txt), and a third wave needs <= 168
+// VGPRs.  Two things make room: the c2 branch runs in edge_c2_kernel (its weight fragments, 32 VGPRs, its operand
+// tiles and its pre-activation rows leave this kernel; the finished c2 row of a destination is one 16-byte load
+// per lane in the epilogue), and ONE 768-thread workgroup owns the CU's whole LDS, so a tile holds 8-10 atoms and
+// a round serves 48 destinations: three 16-row MFMA tiles side by side (wave w: tile w / 4, columns 32 (w % 4)),
+// fewer, fuller rounds, and a third of the barriers per destination.
+struct Edge3Args {
+  const float *edge_in;
+  float *edge_out;
+  const float *np3;  // [S*N, 6FP] = node * (Wi | Wj(+bias) | Wk)
+  const float *c2;   // [S*E, FP]  the finished c2 embedding of every edge (edge_c2_kernel)
+  float *agg_out;    // taped runs: the pre-LayerNorm triplet sums [S*E, FP]; else null
+  int S;
+  Graph g;
+  Dims d;
+  PassW<float> w;
+};
+
+namespace {
+#ifndef RN_E3_WAVES
+#define RN_E3_WAVES 12  // 12: one workgroup per CU (158 KiB of LDS); 6: two workgroups per CU (80 KiB each)
+#endif
+constexpr int NW3 = RN_E3_WAVES;     // waves per workgroup
+constexpr int NT3 = 64 * NW3;        // threads
+constexpr int NG3 = NT3 / LG;        // lane groups = destinations per round
+constexpr int MT3 = (NG3 + 15) / 16; // 16-row MFMA tiles per round
+constexpr int G43 = NW3 / 4;         // complete groups of four waves (one wave per 32 of the 128 columns): they run the MFMAs
+constexpr int WGS3 = NW3 <= 4 ? 3 : (NW3 <= 6 ? 2 : 1);  // workgroups per CU (three waves per SIMD in every form)
+constexpr bool NJ_LDS3 = NW3 > 4;    // four waves: the Wj node[j] rows come from L2 per destination (53 KiB of LDS per workgroup)
+struct Fused3Lds {
+  size_t bufQ, bufP, atile, nj, lnp, ints, total;
+};
+__host__ __device__ inline Fused3Lds fused3_lds(int maxR, int maxD, int maxN) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  Fused3Lds L;
+  size_t off = 0;
+  L.bufQ = off; off += up((size_t)maxR * LDQ * 4);
+  L.bufP = off; off += up((size_t)MT3 * 16 * LDQ * 4);
+  L.atile = off; off += (size_t)MT3 * 16 * FP * 4;
+  L.nj = off; off += NJ_LDS3 ? up((size_t)maxN * 2 * FP * 4) : 0;
+  L.lnp = off; off += (size_t)6 * FP * 4;
+  L.ints = off; off += up(((size_t)maxR + 6 * (size_t)maxD) * 4);
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+template <bool PAD>
+__global__ __launch_bounds__(NT3, WGS3) void edge_block3_kernel(Edge3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Graph &g = a.g;
+  const Fused3Lds L = fused3_lds(g.et_max_out_rows, g.et_max_in_rows, g.et_max_nodes);
+  float *bufQ = reinterpret_cast<float *>(smem_raw + L.bufQ);   // [maxR][LDQ] centred source rows (|q|^2 in the pad)
+  float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);   // [48][LDQ] W4 edge_d of a round
+  float *atile = reinterpret_cast<float *>(smem_raw + L.atile); // [48][64] swizzled operand rows
+  float *nj = reinterpret_cast<float *>(smem_raw + L.nj);       // [maxN][2FP] Wj node[j] + bias
+  float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
+  float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_g3 = lnp + 2 * FP, *s_ig3 = lnp + 4 * FP;
+  int *qb = reinterpret_cast<int *>(smem_raw + L.ints);
+  const int maxD = g.et_max_in_rows;
+  int *d_edge = qb + g.et_max_out_rows, *d_a = d_edge + maxD, *d_bl = d_a + maxD, *d_rb = d_bl + maxD,
+      *d_cnt = d_rb + maxD, *d_skip = d_cnt + maxD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int mtile = wave >> 2;           // first 16-row tile of a step this wave multiplies (then every G43-th)
+  const int colbase = (wave & 3) * 32;   // and which 32 of the 128 pre-activation columns
+  const bool mma = wave < 4 * G43;       // (waves beyond the last complete group of four sit the MFMA phases out)
+  __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.et_num;
+  const int sg = logical / g.et_num, nsg = gridDim.x / g.et_num;
+  const int j0 = g.et_begin[tile], j1 = g.et_begin[tile + 1];
+  const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
+  const int nrounds = (dcount + NG3 - 1) / NG3;
+
+  for (int c = tid; c < 2 * FP; c += NT3) {
+    const float gam = a.w.c3_norm_1.g[c] * (c < FP ? -kLog2e : 2.0f * kLog2e);
+    s_g3[c] = gam;
+    s_ig3[c] = ((c % FP) < a.d.Fe) ? 1.0f / gam : 0.0f;
+    if (c < FP) {
+      s_c3n2g[c] = a.w.c3_norm_2.g[c];
+      s_c3n2b[c] = a.w.c3_norm_2.b[c];
+    }
+  }
+  for (int r = tid; r < rows; r += NT3) qb[r] = g.edge_b[eo0 + r];
+  for (int i = tid; i < dcount; i += NT3) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_bl[i] = bd - j0;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+  }
+
+  const float s4 = a.w.mfma_scale[2], inv4 = a.w.mfma_scale[3];
+  const float s5 = a.w.mfma_scale[4], inv5 = a.w.mfma_scale[5];
+  WaveB<true> bW4;  // resident; W5's fragments are rebuilt every frame (the registers are the loop's in between)
+  bW4.load(a.w.c3_WeT, 4 * FP, colbase, l15, quad, s4);
+
+  const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
+  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
+  const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
+  float b3f[4], b3c[4];  // c3_norm_1's shift with the exp2 scale of the gate folded in (its scale: s_g3 in LDS)
+  {
+    const Vec4<float> bf = load4<float>(a.w.c3_norm_1.b + c0), bc = load4<float>(a.w.c3_norm_1.b + FP + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      b3f[i] = -kLog2e * bf.v[i];
+      b3c[i] = 2.0f * kLog2e * bc.v[i];
+    }
+  }
+  __syncthreads();
+
+  // LDS-DMA of the 48 destination rows of round `r` of frame `s`: wave w brings rows 4w..4w+3;
+  // slot (row, piece p) receives global piece p ^ row
+  auto prefetch_round = [&](int s, int r) {
+    const int row = 4 * wave + quad;
+    const int i = min(r * NG3 + row, dcount - 1);
+    const int piece = (l15 ^ row) & 15;
+    dma16(a.edge_in + ((int64_t)s * g.E + d_edge[i]) * FP + 4 * piece, atile + wave * 256);
+  };
+  auto split_landed_tile = [&]() {  // every lane turns the slot IT fetched into [hi x4 | lo x4] halves
+    float *slot = atile + wave * 256 + lane * 4;
+    *reinterpret_cast<float4 *>(slot) = split_slot(*reinterpret_cast<const float4 *>(slot));
+  };
+  if (sg < a.S && dcount > 0) prefetch_round(sg, 0);
+
+  for (int s = sg; s < a.S; s += nsg) {
+    const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
+    if constexpr (NJ_LDS3) {
+      for (int i = tid; i < (j1 - j0) * (2 * FP / 4); i += NT3) {
+        const int n = i / (2 * FP / 4), c = (i % (2 * FP / 4)) * 4;
+        store4(nj + (size_t)n * 2 * FP + c, load4<float>(a.np3 + (nrow0 + j0 + n) * (6 * FP) + 2 * FP + c));
+      }
+    }
+    // ================= source rows: W5 edge_e by MFMA -> bufQ (raw), 16 G43 rows per step
+    {
+      WaveB<true> bW5;
+      bW5.load(a.w.c3_WeT + 2 * FP, 4 * FP, colbase, l15, quad, s5);
+      for (int mt = mtile; mma && mt * 16 < rows; mt += G43) {
+        float af[KS];
+        const float *src = a.edge_in + (erow0 + eo0 + min(mt * 16 + l15, rows - 1)) * FP + quad * KS;
+#pragma unroll
+        for (int k4 = 0; k4 < KS; k4 += 4) {
+          const float4 v = *reinterpret_cast<const float4 *>(src + k4);
+          af[k4] = v.x; af[k4 + 1] = v.y; af[k4 + 2] = v.z; af[k4 + 3] = v.w;
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        bW5.product(af, acc);
+        if (const int r = mt * 16 + l15; r < rows) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<f32x4 *>(bufQ + r * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- add Wi node[b_e], centre, fold the gate scale, record |q|^2 (padded columns forced to 0)
+    for (int r = grp; r < rows; r += NG3) {
+      float *row = bufQ + r * LDQ;
+      const float *np = a.np3 + (nrow0 + qb[r]) * (6 * FP) + c0;
+      Vec4<float> f = load4<float>(row + c0), c = load4<float>(row + FP + c0);
+      const Vec4<float> nf = load4<float>(np), nc = load4<float>(np + FP);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f.v[i] = fmaf(f.v[i], inv5, nf.v[i]);
+        c.v[i] = fmaf(c.v[i], inv5, nc.v[i]);
+        sum += f.v[i] + c.v[i];
+      }
+      const float mean = lg_sum<LG>(sum) * inv2n;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f.v[i] = (!PAD || i < nvalid) ? f.v[i] - mean : 0.f;
+        c.v[i] = (!PAD || i < nvalid) ? c.v[i] - mean : 0.f;
+        ss += f.v[i] * f.v[i] + c.v[i] * c.v[i];
+      }
+      ss = lg_sum<LG>(ss);
+      const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f.v[i] *= g3f.v[i];
+        c.v[i] *= g3c.v[i];
+      }
+      store4(row + c0, f);
+      store4(row + FP + c0, c);
+      if (q4 == 0) row[2 * FP] = ss * inv2n;
+    }
+    dma_wait();  // round 0's operand rows (issued before the frame loop / in the last round)
+    if (s == sg) split_landed_tile();  // (later frames: split at the end of the previous frame)
+    __syncthreads();
+
+    // Destination of this lane group in round `round` (-1: none).  A round with at most 24 destinations is
+    // split: groups g and g+24 share destination g, half of its triplets each.
+    auto dest_index = [&](int round) {
+      const int rm = dcount - round * NG3;
+      const int sl = (rm <= NG3 / 2) ? (grp >= NG3 / 2 ? grp - NG3 / 2 : grp) : grp;
+      return sl < rm ? round * NG3 + sl : -1;
+    };
+    Vec4<float> nkf, nkc;  // Wk node[a_d] of this group's destination, fetched one round ahead
+    if (const int i0 = dest_index(0); i0 >= 0) {
+      const float *nk = a.np3 + (nrow0 + d_a[i0]) * (6 * FP) + 4 * FP + c0;
+      nkf = load4<float>(nk);
+      nkc = load4<float>(nk + FP);
+    }
+    for (int r = 0; r < nrounds; ++r) {
+      // ---- MFMA: P' of the round's destinations from the DMA'd, pre-split operand rows
+      for (int mt = mtile; mma && mt < MT3; mt += G43) {
+        f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f16x8 ah[2], al[2];
+        load_split_a(atile + mt * 16 * FP, l15, quad, ah, al);
+        bW4.product_split(ah, al, accP);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *reinterpret_cast<f32x4 *>(bufP + (mt * 16 + l15) * LDQ + colbase + 16 * t + 4 * quad) = accP[t];
+      }
+      __syncthreads();  // S1: bufP complete, operand tile free
+      if (r + 1 < nrounds) prefetch_round(s, r + 1);
+      else if (s + nsg < a.S) prefetch_round(s + nsg, 0);
+
+      const int rem = dcount - r * NG3;
+      const bool split = rem <= NG3 / 2;                        // uniform over the workgroup
+      const int part = (split && grp >= NG3 / 2) ? 1 : 0;       // which half of the triplets
+      const int slot = part ? grp - NG3 / 2 : grp;
+      const bool active = slot < rem;
+      const int i = r * NG3 + slot;
+      const int64_t drow = active ? erow0 + d_edge[i] : 0;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      Vec4<float> old, c2v;
+      if (active) {
+        if (part == 0) {
+          old = load4<float>(a.edge_in + drow * FP + c0);
+          c2v = load4<float>(a.c2 + drow * FP + c0);
+        }
+        float pf[4], pc[4];
+        {
+          const Vec4<float> xf = load4<float>(bufP + slot * LDQ + c0), xc = load4<float>(bufP + slot * LDQ + FP + c0);
+          const float *njr = NJ_LDS3 ? nj + (size_t)d_bl[i] * 2 * FP + c0
+                                     : a.np3 + (nrow0 + j0 + d_bl[i]) * (6 * FP) + 2 * FP + c0;
+          const Vec4<float> jf = load4<float>(njr), jc = load4<float>(njr + FP);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pf[k] = fmaf(xf.v[k], inv4, nkf.v[k]) + jf.v[k];
+            pc[k] = fmaf(xc.v[k], inv4, nkc.v[k]) + jc.v[k];
+          }
+        }
+        if (const int inext = (r + 1 < nrounds) ? dest_index(r + 1) : -1; inext >= 0) {  // next round's Wk node[a_d]
+          const float *nk = a.np3 + (nrow0 + d_a[inext]) * (6 * FP) + 4 * FP + c0;
+          nkf = load4<float>(nk);
+          nkc = load4<float>(nk + FP);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += pf[k] + pc[k];
+        const float mean = lg_sum<LG>(sum) * inv2n;
+        float sp = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pf[k] = (!PAD || k < nvalid) ? pf[k] - mean : 0.f;
+          pc[k] = (!PAD || k < nvalid) ? pc[k] - mean : 0.f;
+          sp += pf[k] * pf[k] + pc[k] * pc[k];
+        }
+        sp = lg_sum<LG>(sp);
+
+        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+        __builtin_amdgcn_s_setprio(0);  // the triplet loop is always ready to issue: let the other waves' sparse phases go first
+        const int half = split ? (cnt + 1) / 2 : cnt;
+        const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's triplets
+        // pd = p/gamma * (2/2Fe), pg = p*gamma; var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
+        f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2], bf2[2], bc2[2];
+        {
+          const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);
+          const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
+          const float two_inv = 2.0f * inv2n;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            pdf2[hh] = f32x2{pf[2 * hh] * igf.v[2 * hh] * two_inv, pf[2 * hh + 1] * igf.v[2 * hh + 1] * two_inv};
+            pdc2[hh] = f32x2{pc[2 * hh] * igc.v[2 * hh] * two_inv, pc[2 * hh + 1] * igc.v[2 * hh + 1] * two_inv};
+            pf2[hh] = f32x2{pf[2 * hh] * g3f.v[2 * hh], pf[2 * hh + 1] * g3f.v[2 * hh + 1]};
+            pc2[hh] = f32x2{pc[2 * hh] * g3c.v[2 * hh], pc[2 * hh + 1] * g3c.v[2 * hh + 1]};
+            bf2[hh] = f32x2{b3f[2 * hh], b3f[2 * hh + 1]};
+            bc2[hh] = f32x2{b3c[2 * hh], b3c[2 * hh + 1]};
+          }
+        }
+        const float spe = sp * inv2n + 1e-5f;
+        const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
+        auto triplet = [&](const float *qr, float (&sumk)[4]) {
+          const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
+          const float qs = qr[sdelta];
+          const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
+          f32x2 d2 = pdf2[0] * qf2[0];
+          f32x2 d3 = pdc2[0] * qc2[0];
+          d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
+          d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
+          d2 += d3;
+          const float dot = lg_sum<LG>(d2.x + d2.y);
+          float ve = dot + (spe + qs);
+          ve = ve > 1e-5f ? ve : 1e-5f;
+          const float rstd = fast_rsq(ve);
+          const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 xf = __builtin_elementwise_fma(pf2[hh] + qf2[hh], rstd2, bf2[hh]);
+            const f32x2 xc = __builtin_elementwise_fma(pc2[hh] + qc2[hh], rstd2, bc2[hh]);
+            const f32x2 e1 = {fast_exp2(xf.x), fast_exp2(xf.y)}, e2 = {fast_exp2(xc.x), fast_exp2(xc.y)};
+            const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+            const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
+            const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
+            f32x2 sk = {sumk[2 * hh], sumk[2 * hh + 1]};
+            sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
+            sumk[2 * hh] = sk.x;
+            sumk[2 * hh + 1] = sk.y;
+          }
+        };
+        const int tskip = rskip - rb;
+        auto step = [&](const float *p, int tnext) { return p + (tnext == tskip ? 2 * LDQ : LDQ); };
+        const float *qr = bufQ + (rb + t0 + (t0 >= tskip ? 1 : 0)) * LDQ + c0;
+#if RN_E3_PAIRWISE
+        float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+        int t = t0;
+        for (; t + 1 < t1; t += 2) {
+          const float *qn = step(qr, t + 1);
+          triplet(qr, acc);
+          triplet(qn, acc2);
+          qr = step(qn, t + 2);
+        }
+        if (t < t1) triplet(qr, acc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
+#else
+        for (int t = t0; t < t1; ++t) {
+          triplet(qr, acc);
+          qr = step(qr, t + 1);
+        }
+#endif
+      }
+      __builtin_amdgcn_s_setprio(RN_FUSED_PRIO);
+      if (split) {  // second halves reach their partner through the unused rows 24..47 of bufP
+        float *xch = bufP + (NG3 / 2 + slot) * LDQ + c0;
+        if (active && part == 1) store4(xch, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
+        __syncthreads();
+        if (active && part == 0) {
+          const Vec4<float> other = load4<float>(xch);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += other.v[k];
+        }
+      }
+      if (active && part == 0) {
+        if (a.agg_out) store4(a.agg_out + drow * FP + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
+        const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
+        const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+        Vec4<float> out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2v.v[k] + c3.v[k]);
+        store4(a.edge_out + drow * FP + c0, out);
+      }
+      dma_wait();
+      if (r + 1 < nrounds || s + nsg < a.S) split_landed_tile();
+      __syncthreads();  // S2: bufP (and, after the last round, bufQ / nj) may be rewritten; next operand rows landed
+    }
+  }
+}
+
+size_t edge3_lds_bytes(int rows, int in_rows, int nodes) { return fused3_lds(rows, in_rows, nodes).total; }
+bool edge3_supported(const Graph &g, Dims d) {
+  return d.FnP == 64 && d.FeP == 64 && g.E > 0 && g.et_num > 0 &&
+         fused3_lds(g.et_max_out_rows, g.et_max_in_rows, g.et_max_nodes).total <= kEdge3LdsBudget;
+}
+// the twelve-wave kernel exists for the split-f16 products with the gate scale folded into the rows
+bool edge3_applicable(const PassW<float> &w, bool f16) { return f16 && (w.c3_fast & 1) != 0; }
+
+void launch_edge3(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
+                  const Graph &g, Dims d, const PassW<float> &w, hipStream_t st) {
+  if (S == 0 || g.E == 0) return;
+  Edge3Args a{edge_in, edge_out, np3, c2, agg_out, S, g, d, w};
+  const size_t lds = fused3_lds(g.et_max_out_rows, g.et_max_in_rows, g.et_max_nodes).total;
+  const bool pad = d.Fe != d.FeP;
+  auto kern = pad ? &edge_block3_kernel<true> : &edge_block3_kernel<false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int nsg = WGS3 * cus / g.et_num;  // three waves per SIMD: one twelve-wave, two six-wave or three four-wave workgroups per CU
+  nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)g.et_num, NT3, lds, st>>>(a);
 }
 
 // ============================================================================ NodeBlock
