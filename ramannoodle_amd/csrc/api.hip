@@ -1019,12 +1019,22 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   T *Wd = P.weights.template as<T>();
   // dX[R, K] (+)= dY[R, N] * W^T with W = the forward's [K][N] matrix at `w_off`, its
   // transposed copy at `t_off`: MFMA projection kernel in float32, simple kernel otherwise
+  // (float32 with the split-f16 products enabled: rowgemm_split_kernel where the shape allows)
+  const bool split_gemm = sizeof(T) == 4 && h->mfma_f16;
   auto back_gemm = [&](const T *dY, int64_t R, int N, size_t w_off, size_t t_off, int K, T *dX,
                        bool accumulate) {
     if constexpr (sizeof(T) == 4) {
+      if (split_gemm && launch_rowgemm_split(dY, N, N, R, Wd + t_off, K, dX, accumulate, nullptr, 0, nullptr, g, st)) return;
       if (launch_rowgemm_blocks(dY, N, N, R, Wd + t_off, K, dX, accumulate, g, st)) return;
     }
     launch_gemm_nt<T>(dY, R, N, Wd + w_off, N, K, dX, accumulate, st);
+  };
+  // Y = X W (+ bias): a recomputed forward projection of the pass
+  auto project = [&](const T *X, int64_t R, int K, const T *WT, int NOUT, T *Y, const T *bias, int amode, const T *node) {
+    if constexpr (sizeof(T) == 4) {
+      if (split_gemm && launch_rowgemm_split(X, K, K, R, WT, NOUT, Y, false, bias, amode, node, g, st)) return;
+    }
+    launch_rowgemm<T>(X, R, K, WT, NOUT, Y, nullptr, bias, false, amode, node, g, st);
   };
 
   // weight-gradient products (float32): per-workgroup partial sums into an arena, ONE reduction at the end
@@ -1094,10 +1104,10 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     T *de_next = b[DE0 + cur], *de_prev = b[DE0 + (cur ^ 1)];
     T *dn_next = b[DN0 + cur], *dn_prev = b[DN0 + (cur ^ 1)];
     // recompute this pass's projections from the tape
-    launch_rowgemm<T>(node0, fn, d.FnP, w.c1_WnT, 2 * d.FnP, c.npc1, nullptr, w.c1_bias, false, 0, nullptr, g, st);
-    launch_rowgemm<T>(node1, fn, d.FnP, w.c3_WnT, 6 * d.FeP, c.np3, nullptr, w.c3_nshift, false, 0, nullptr, g, st);
-    launch_rowgemm<T>(edge0, fe, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false, 0, nullptr, g, st);
-    launch_rowgemm<T>(nullptr, fe, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1, node1, g, st);
+    project(node0, fn, d.FnP, w.c1_WnT, 2 * d.FnP, c.npc1, w.c1_bias, 0, nullptr);
+    project(node1, fn, d.FnP, w.c3_WnT, 6 * d.FeP, c.np3, w.c3_nshift, 0, nullptr);
+    project(edge0, fe, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, 0, nullptr);
+    project(nullptr, fe, d.FnP, w.c2_WT, 2 * d.FeP, bufA, w.c2_bias, 1, node1);
     // EdgeBlock
     launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, P.tape_agg[p].template as<T>(), de_next, de_prev, b[DPQ],
                        b[DNP3], b[DC2], C, B, g, d, w, G ? &gw : nullptr, st);
@@ -1116,7 +1126,7 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
       launch_gemm_tn<T>(b[DPROD], d.FnP, b[DC2], 2 * d.FeP, ce, d.FnP, 2 * d.FeP, G + q.c2_WT, 2 * d.FeP, G + q.c2_bias, 0, nullptr, g, st, tn);
     }
     // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
-    launch_rowgemm<T>(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0, nullptr, g, st);
+    project(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, 0, nullptr);
     launch_node_bwd<T>(c.npc1, bufA, node1, dn_next, dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w,
                        G ? &gw : nullptr, st);
     back_gemm(b[DBC1], ce, 2 * d.FnP, L.pass[p].c1_WeT, L.pass[p].t_c1We, d.FeP, de_prev, true);

@@ -124,6 +124,10 @@ void launch_rowgemm(const T *X, int64_t M, int KP, const T *WT, int NOUT, T *Y,
                     const Graph &g, hipStream_t st);
 
 // float32 only: Y (+)= X[:, 0:N] * Wt[N, NOUT] on the MFMA kernel; false if the shape is unsupported
+// split-f16 row product for the reverse pass (kernels_gemm.hip: rowgemm_split_kernel); false = shape not served
+bool launch_rowgemm_split(const float *X, int ldx, int K, int64_t M, const float *Wt, int NOUT, float *Y,
+                          bool accumulate, const float *bias, int amode, const float *node, const Graph &g,
+                          hipStream_t st);
 bool launch_rowgemm_blocks(const float *X, int ldx, int N, int64_t M, const float *Wt, int NOUT,
                            float *Y, bool accumulate, const Graph &g, hipStream_t st);
 

@@ -362,6 +362,195 @@ bool launch_rowgemm_blocks(const float *X, int ldx, int N, int64_t M, const floa
   return true;
 }
 
+// ---------------------------------------------------------------------------- split-f16 row products
+// Y[M, NOUT] (+)= X[M, 0:64 KB] * Wt[64 KB, NOUT] (+ bias) on the f16 matrix pipe as three products per term
+// (x = hi + lo in f16: device_utils.hpp mfma_split3), for the reverse pass and its recomputations, where the
+// exact-f32 instruction of rowgemm_mfma_kernel is what bounds the products (2.4 GFLOP at 40 % of the 157 TFLOP/s
+// f32 MFMA peak = 35-60 us, against 14-19 us of HBM time).  Wave-autonomous: a wave owns 16 NTW output columns,
+// keeps their weights as split fragments in registers (64 KB NTW / 4 VGPRs); the workgroup's four waves share the
+// 16-row operand tile: each wave loads four whole rows (next tile requested before the products of the current one),
+// scales and splits them ONCE and leaves MFMA-ready fragments in a double-buffered LDS tile (one barrier per tile);
+// a lane stores four consecutive columns of a row.
+// Ranges: cotangent rows can be 1e-9 small and weights arbitrary, so every ROW of X and every wave's 64 x 16 NTW
+// weight block are brought to [2^12, 2^13) by an exact power of two before the split (kernels.hpp:
+// mfma_prescale) and the accumulators are scaled back in float32.
+// AMODE 1: the operand row of edge (frame s, e) is node[s, b_e] * node[s, a_e] (the c2 operand), K = 64.
+typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gf16x4 __attribute__((ext_vector_type(4)));
+template <int KB, int NTW, int AMODE>
+__global__ __launch_bounds__(256, 2) void rowgemm_split_kernel(GemmArgs a) {
+  // A tile of 16 rows as MFMA-ready fragments: [buffer][kb][slice s][hi | lo][row * 4 + quad] x 16 bytes
+  __shared__ __attribute__((aligned(16))) gf16x8 atile[2][KB][2][2][64];
+  __shared__ float s_inv[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int col0 = blockIdx.y * (64 * NTW) + wave * (16 * NTW);
+
+  gf16x8 wh[KB][NTW][2], wl[KB][NTW][2];
+  float winv[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float tmp[NTW][2][8];
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          tmp[t][s2][j] = a.WT[(int64_t)(64 * kb + 16 * quad + 8 * s2 + j) * a.NOUT + col0 + 16 * t + l15];
+          m = fmaxf(m, fabsf(tmp[t][s2][j]));
+        }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+    const float sw = mfma_prescale(m);
+    winv[kb] = 1.0f / sw;  // (a power of two: exact)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[t][s2][j] *= sw;
+        split_f16x8(tmp[t][s2], wh[kb][t][s2], wl[kb][t][s2]);
+      }
+  }
+
+  // Loading: wave w brings rows 4w .. 4w+3 of a tile whole (a row is 16 KB float4 pieces, LPR lanes wide), so a
+  // row's largest magnitude is a reduction over neighbouring lanes of ONE wave.
+  constexpr int LPR = 16 * KB;  // lanes per row (16, 32 or 64)
+  const int64_t ntiles = (a.M + 15) / 16;
+  float4 nxt[KB];
+  auto fetch = [&](int64_t tile) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int idx = j * 64 + lane;
+      int64_t row = tile * 16 + 4 * wave + idx / LPR;
+      if (row >= a.M) row = a.M - 1;
+      const int p = idx % LPR;
+      if (AMODE == 0) {
+        nxt[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * p);
+      } else {
+        const int64_t s = row / a.E;
+        const int e = (int)(row - s * a.E);
+        const float4 x = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_b[e]) * 64 + 4 * p);
+        const float4 y = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_a[e]) * 64 + 4 * p);
+        nxt[j] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+      }
+    }
+  };
+  // registers -> scaled split fragments in buffer b
+  auto stage = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int idx = j * 64 + lane;
+      const int rowl = 4 * wave + idx / LPR, p = idx % LPR;
+      float4 v = nxt[j];
+      float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+      for (int sft = 1; sft < LPR; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+      const float sr = mfma_prescale(m);
+      if (p == 0) s_inv[b][rowl] = 1.0f / sr;
+      const float x[4] = {v.x * sr, v.y * sr, v.z * sr, v.w * sr};
+      gf16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (_Float16)x[k];
+        lo[k] = (_Float16)(x[k] - (float)hi[k]);
+      }
+      const int kb = p >> 4, qd = (p >> 2) & 3, s2 = (p >> 1) & 1, half = p & 1;
+      gf16x4 *dh = reinterpret_cast<gf16x4 *>(&atile[b][kb][s2][0][rowl * 4 + qd]) + half;
+      gf16x4 *dl = reinterpret_cast<gf16x4 *>(&atile[b][kb][s2][1][rowl * 4 + qd]) + half;
+      *dh = hi;
+      *dl = lo;
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x);
+  int b = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, b ^= 1) {
+    stage(b);
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+    const int64_t row = tile * 16 + l15;
+    const bool live = row < a.M;
+    float4 old[NTW];
+    if (a.accum && live) {  // Y += : requested before the products
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) old[t] = *reinterpret_cast<const float4 *>(a.Y + row * a.NOUT + col0 + 16 * t + 4 * quad);
+    }
+    __syncthreads();  // buffer b complete (the other buffer is free: every wave has passed the previous barrier's products)
+    const float inv_sr = s_inv[b][l15];
+    f32x4_t tot[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) tot[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const gf16x8 ah0 = atile[b][kb][0][0][l15 * 4 + quad], al0 = atile[b][kb][0][1][l15 * 4 + quad];
+      const gf16x8 ah1 = atile[b][kb][1][0][l15 * 4 + quad], al1 = atile[b][kb][1][1][l15 * 4 + quad];
+      const float scale = winv[kb] * inv_sr;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mfma_split3(wh[kb][t][0], wl[kb][t][0], ah0, al0, acc);
+        acc = mfma_split3(wh[kb][t][1], wl[kb][t][1], ah1, al1, acc);
+        tot[t] += acc * scale;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = col0 + 16 * t + 4 * quad;
+        float4 v = make_float4(tot[t][0], tot[t][1], tot[t][2], tot[t][3]);
+        if (a.shift) {
+          const float4 bb = *reinterpret_cast<const float4 *>(a.shift + col);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (a.accum) {
+          v.x += old[t].x; v.y += old[t].y; v.z += old[t].z; v.w += old[t].w;
+        }
+        *reinterpret_cast<float4 *>(a.Y + row * a.NOUT + col) = v;
+      }
+    }
+  }
+}
+
+// true = launched.  K a multiple of 64 up to 256, NOUT a multiple of 64 (amode 1: K = 64).
+bool launch_rowgemm_split(const float *X, int ldx, int K, int64_t M, const float *Wt, int NOUT, float *Y,
+                          bool accumulate, const float *bias, int amode, const float *node, const Graph &g,
+                          hipStream_t st) {
+  if (M == 0) return true;
+  static const bool off = getenv("RN_POTGNN_BWD_SPLIT_GEMM") && atoi(getenv("RN_POTGNN_BWD_SPLIT_GEMM")) == 0;
+  if (off || K % 64 != 0 || K > 256 || K == 192 || NOUT % 64 != 0 || (amode == 1 && K != 64)) return false;
+  GemmArgs a{X, ldx, accumulate ? 1 : 0, M, Wt, NOUT, Y, nullptr, bias, node, g.edge_a, g.edge_b, g.N, g.E};
+  const int kb = K / 64;
+  // columns per workgroup 64 NTW: as many as the weights' registers allow (64 KB NTW / 4 <= 64)
+  int ntw = 1;
+  if (kb == 1 && NOUT % 256 == 0) ntw = 4;
+  else if (kb <= 2 && NOUT % 128 == 0) ntw = 2;
+  const int64_t ntiles = (M + 15) / 16;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  // (resident workgroups per CU follow from the registers: 80-130 VGPRs for the small fragment sets, 228 for K = 256)
+  static const int wgs_per_cu = getenv("RN_POTGNN_SPLIT_GEMM_WGS") ? std::max(1, atoi(getenv("RN_POTGNN_SPLIT_GEMM_WGS"))) : 4;
+  const dim3 grid((unsigned)std::min<int64_t>(ntiles, (int64_t)wgs_per_cu * cus), (unsigned)(NOUT / (64 * ntw)));
+#define RN_SPLIT(KBV, NTWV)                                                             \
+  do {                                                                                  \
+    if (amode == 1) rowgemm_split_kernel<1, NTWV, 1><<<grid, 256, 0, st>>>(a);          \
+    else rowgemm_split_kernel<KBV, NTWV, 0><<<grid, 256, 0, st>>>(a);                   \
+  } while (0)
+  if (kb == 1 && ntw == 4) RN_SPLIT(1, 4);
+  else if (kb == 1 && ntw == 2) RN_SPLIT(1, 2);
+  else if (kb == 1) RN_SPLIT(1, 1);
+  else if (kb == 2 && ntw == 2) { if (amode == 1) return false; rowgemm_split_kernel<2, 2, 0><<<grid, 256, 0, st>>>(a); }
+  else if (kb == 2) { if (amode == 1) return false; rowgemm_split_kernel<2, 1, 0><<<grid, 256, 0, st>>>(a); }
+  else { if (amode == 1) return false; rowgemm_split_kernel<4, 1, 0><<<grid, 256, 0, st>>>(a); }
+#undef RN_SPLIT
+  return true;
+}
+
 // ---------------------------------------------------------------------------- float64
 // Double-precision variant used by the finite-difference Raman-tensor path
 // (dynamics/_phonon.py:93-106), where fp32 cancellation would dominate.  Plain FMA
