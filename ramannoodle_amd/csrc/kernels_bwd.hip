@@ -1606,21 +1606,47 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
   const int64_t s0 = (AMODE == 1 && g.E > 0) ? r0 / g.E : 0, e0 = (AMODE == 1) ? r0 - s0 * g.E : 0;
-  constexpr int U = 4;  // row pairs in flight
-  for (int64_t rb = r0; rb < r1; rb += 2 * U) {
-    float a[U][KT], b[U];
+  constexpr int U = 4;  // row pairs per step
+  if constexpr (AMODE == 0) {
+    // two steps in flight: the next step's rows are requested before this step's MFMAs (the loads of a step
+    // otherwise wait behind 8 KT / 2 x 64 cycles of matrix-pipe issue, and the pipe then idles for their latency)
+    float a[2][U][KT], b[2][U];
+    auto request = [&](int64_t rb, int buf) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t row = rb + 2 * u + h;
-      const bool ok = row < r1;
-      b[u] = ok ? dY[row * ldy + ncol] : 0.f;
-      if (AMODE == 0) {
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = rb + 2 * u + h;
+        const bool ok = row < r1;
+        b[buf][u] = ok ? dY[row * ldy + ncol] : 0.f;
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
           const int k = 32 * t + l31;
-          a[u][t] = (ok && k < K) ? X[row * ldx + k] : 0.f;
+          a[buf][u][t] = (ok && k < K) ? X[row * ldx + k] : 0.f;
         }
-      } else {
+      }
+    };
+    auto consume = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bsum += b[buf][u];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u][t], b[buf][u], acc[t], 0, 0, 0);
+      }
+    };
+    request(r0, 0);
+    for (int64_t rb = r0; rb < r1; rb += 4 * U) {
+      request(rb + 2 * U, 1);  // (rows past r1 load nothing and contribute zeros)
+      consume(0);
+      request(rb + 4 * U, 0);
+      consume(1);
+    }
+  } else {
+    for (int64_t rb = r0; rb < r1; rb += 2 * U) {
+      float a[U][KT], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = rb + 2 * u + h;
+        const bool ok = row < r1;
+        b[u] = ok ? dY[row * ldy + ncol] : 0.f;
         int64_t nb = 0, na = 0;
         if (ok) {  // (frame, edge) of the row without a 64-bit division per row
           int64_t s = s0;
@@ -1639,12 +1665,12 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
           a[u][t] = (ok && k < K) ? node[nb + k] * node[na + k] : 0.f;
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      bsum += b[u];
+      for (int u = 0; u < U; ++u) {
+        bsum += b[u];
 #pragma unroll
-      for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
+        for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
+      }
     }
   }
   if (PART) {
