@@ -188,8 +188,8 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow
         if (fused or narrow) else None
     if rec:
         traffic = rec["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
-    return {"kernel": "node_narrow_kernel (NodeBlock scatter-aggregate, projections included: one lane per atom "
-                      "gathers its in-edge rows)" if narrow
+    return {"kernel": "node_tiled_kernel (NodeBlock scatter-aggregate, projections included: in-edge rows staged "
+                      "through LDS 256 at a time, one lane per row, per-atom sums from LDS)" if narrow
             else "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
             else "node_agg_kernel (NodeBlock scatter-aggregate; its c1 projection is a separate launch)",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
