@@ -1832,128 +1832,214 @@ template void launch_gemm_tn<double>(const double *, int, const double *, int, i
 
 // ---- BatchNorm1d in training mode over all R rows (_gnn.py:534; batch statistics)
 // stats[c] = sum z, stats[W + c] = sum z^2 (float64 accumulators)
+// Thread layout of the four kernels below: 256 threads = row lanes x column groups of 4 (W / 4 groups; W = 64: 16 x 16);
+// a block walks `rows_per_block` rows with 16-byte accesses.  Per-column quantities that need float64 division / sqrt
+// are computed once per block into LDS, not per element (the per-element form made the elementwise kernels 5x slower
+// than their traffic).
 template <typename T>
-__global__ void col_sums_kernel(const T *__restrict__ z, int64_t R, int W, double *__restrict__ stats,
-                                int rows_per_block) {
+__global__ __launch_bounds__(256) void col_sums_kernel(const T *__restrict__ z, int64_t R, int W,
+                                                       double *__restrict__ stats, int rows_per_block) {
+  __shared__ double red[2][256][4];
+  const int cg = W / 4, rl = 256 / cg;             // column groups, row lanes
+  const int c4 = (threadIdx.x % cg) * 4, rsub = threadIdx.x / cg;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-  for (int c = threadIdx.x; c < W; c += blockDim.x) {
-    double s = 0, q = 0;
-    for (int64_t r = r0; r < r1; ++r) {
-      const double v = (double)z[r * W + c];
-      s += v;
-      q += v * v;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (rsub < rl)
+    for (int64_t r = r0 + rsub; r < r1; r += rl) {
+      const Vec4<T> v = load4<T>(z + r * W + c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s[k] += (double)v.v[k];
+        q[k] += (double)v.v[k] * (double)v.v[k];
+      }
     }
-    atomicAdd(stats + c, s);
-    atomicAdd(stats + W + c, q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][threadIdx.x][k] = s[k];
+    red[1][threadIdx.x][k] = q[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * W) {  // one thread per (sum kind, column): add the row lanes in a fixed order
+    const int kind = threadIdx.x / W, c = threadIdx.x % W;
+    double t = 0;
+    for (int j = 0; j < rl; ++j) t += red[kind][j * cg + c / 4][c % 4];
+    atomicAdd(stats + kind * W + c, t);
   }
 }
 // h = ssp(gamma * (z - mean) * rstd + beta);  mean/rstd derived from the sums; also writes
 // batch mean and biased variance (for the running-statistics update) into mv[0:W], mv[W:2W].
 template <typename T>
-__global__ void bn_train_fwd_kernel(const T *__restrict__ z, int64_t R, int W, int F,
-                                    const double *__restrict__ stats, double count,
-                                    const T *__restrict__ gamma, const T *__restrict__ beta,
-                                    T *__restrict__ h, T *__restrict__ mv) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R * W) return;
-  const int c = (int)(idx % W);
-  T out = 0;
-  if (c < F) {
-    const double mean = stats[c] / count;
-    double var = stats[W + c] / count - mean * mean;
-    var = var > 0 ? var : 0;
-    const T rstd = (T)(1.0 / sqrt(var + 1e-5));
-    out = ssp(gamma[c] * ((z[idx] - (T)mean) * rstd) + beta[c]);
-    if (idx < W) {
-      mv[c] = (T)mean;
-      mv[W + c] = (T)var;
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const T *__restrict__ z, int64_t R, int W, int F,
+                                                           const double *__restrict__ stats, double count,
+                                                           const T *__restrict__ gamma, const T *__restrict__ beta,
+                                                           T *__restrict__ h, T *__restrict__ mv, int rows_per_block) {
+  __shared__ T s_mean[256], s_rstd[256], s_gamma[256], s_beta[256];
+  for (int c = threadIdx.x; c < W; c += 256) {
+    T mean_t = 0, rstd = 0;
+    if (c < F) {
+      const double mean = stats[c] / count;
+      double var = stats[W + c] / count - mean * mean;
+      var = var > 0 ? var : 0;
+      rstd = (T)(1.0 / sqrt(var + 1e-5));
+      mean_t = (T)mean;
+      if (blockIdx.x == 0) {
+        mv[c] = (T)mean;
+        mv[W + c] = (T)var;
+      }
     }
+    s_mean[c] = mean_t;
+    s_rstd[c] = rstd;
+    s_gamma[c] = c < F ? gamma[c] : (T)0;
+    s_beta[c] = c < F ? beta[c] : (T)0;
   }
-  h[idx] = out;
+  __syncthreads();
+  const int cg = W / 4, rl = 256 / cg;
+  const int c4 = (threadIdx.x % cg) * 4, rsub = threadIdx.x / cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  if (rsub >= rl) return;
+  for (int64_t r = r0 + rsub; r < r1; r += rl) {
+    const Vec4<T> v = load4<T>(z + r * W + c4);
+    Vec4<T> o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)  // (the same operation order as the per-element form: results unchanged)
+      o.v[k] = (c4 + k < F) ? ssp(s_gamma[c4 + k] * ((v.v[k] - s_mean[c4 + k]) * s_rstd[c4 + k]) + s_beta[c4 + k]) : (T)0;
+    store4(h + r * W + c4, o);
+  }
 }
 // BatchNorm backward.  dy (cotangent of the BN output, i.e. already through ssp') in `d`:
 //   pass 1 (bn_bwd_sums): sums[c] = sum dy, sums[W+c] = sum dy * zhat      (also = dbeta, dgamma)
 //   pass 2 (bn_bwd_apply): d <- gamma * rstd * (dy - mean(dy) - zhat * mean(dy zhat))
 template <typename T>
-__global__ void bn_bwd_sums_kernel(const T *__restrict__ dy, const T *__restrict__ z, int64_t R, int W,
-                                   int F, const double *__restrict__ stats, double count,
-                                   double *__restrict__ sums, int rows_per_block) {
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-  for (int c = threadIdx.x; c < F; c += blockDim.x) {
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T *__restrict__ dy, const T *__restrict__ z, int64_t R,
+                                                          int W, int F, const double *__restrict__ stats, double count,
+                                                          double *__restrict__ sums, int rows_per_block) {
+  __shared__ double red[2][256][4];
+  __shared__ double s_mean[256], s_rstd[256];
+  for (int c = threadIdx.x; c < W; c += 256) {
     const double mean = stats[c] / count;
     double var = stats[W + c] / count - mean * mean;
     var = var > 0 ? var : 0;
-    const double rstd = 1.0 / sqrt(var + 1e-5);
-    double a = 0, b = 0;
-    for (int64_t r = r0; r < r1; ++r) {
-      const double g = (double)dy[r * W + c];
-      a += g;
-      b += g * ((double)z[r * W + c] - mean) * rstd;
+    s_mean[c] = mean;
+    s_rstd[c] = 1.0 / sqrt(var + 1e-5);
+  }
+  __syncthreads();
+  const int cg = W / 4, rl = 256 / cg;
+  const int c4 = (threadIdx.x % cg) * 4, rsub = threadIdx.x / cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  if (rsub < rl)
+    for (int64_t r = r0 + rsub; r < r1; r += rl) {
+      const Vec4<T> g = load4<T>(dy + r * W + c4), v = load4<T>(z + r * W + c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] += (double)g.v[k];
+        b[k] += (double)g.v[k] * ((double)v.v[k] - s_mean[c4 + k]) * s_rstd[c4 + k];
+      }
     }
-    atomicAdd(sums + c, a);
-    atomicAdd(sums + W + c, b);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][threadIdx.x][k] = a[k];
+    red[1][threadIdx.x][k] = b[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * W) {
+    const int kind = threadIdx.x / W, c = threadIdx.x % W;
+    if (c < F) {
+      double t = 0;
+      for (int j = 0; j < rl; ++j) t += red[kind][j * cg + c / 4][c % 4];
+      atomicAdd(sums + kind * W + c, t);
+    }
   }
 }
 template <typename T>
-__global__ void bn_bwd_apply_kernel(T *__restrict__ d, const T *__restrict__ z, int64_t R, int W, int F,
-                                    const double *__restrict__ stats, double count,
-                                    const double *__restrict__ sums, const double *__restrict__ own_sums,
-                                    const T *__restrict__ gamma, T *__restrict__ dgamma,
-                                    T *__restrict__ dbeta) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R * W) return;
-  const int c = (int)(idx % W);
-  if (c >= F) {
-    d[idx] = 0;
-    return;
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T *__restrict__ d, const T *__restrict__ z, int64_t R, int W,
+                                                           int F, const double *__restrict__ stats, double count,
+                                                           const double *__restrict__ sums,
+                                                           const double *__restrict__ own_sums,
+                                                           const T *__restrict__ gamma, T *__restrict__ dgamma,
+                                                           T *__restrict__ dbeta, int rows_per_block) {
+  __shared__ double s_mean[256], s_rstd[256], s_ma[256], s_mb[256], s_g[256];
+  for (int c = threadIdx.x; c < W; c += 256) {
+    double mean = 0, rstd = 0, ma = 0, mb = 0, gm = 0;
+    if (c < F) {
+      mean = stats[c] / count;
+      double var = stats[W + c] / count - mean * mean;
+      var = var > 0 ? var : 0;
+      rstd = 1.0 / sqrt(var + 1e-5);
+      ma = sums[c] / count;
+      mb = sums[W + c] / count;
+      gm = (double)gamma[c];
+      if (blockIdx.x == 0) {  // parameter gradients from this rank's rows only (averaged across ranks later)
+        dbeta[c] += (T)own_sums[c];
+        dgamma[c] += (T)own_sums[W + c];
+      }
+    }
+    s_mean[c] = mean;
+    s_rstd[c] = rstd;
+    s_ma[c] = ma;
+    s_mb[c] = mb;
+    s_g[c] = gm;
   }
-  const double mean = stats[c] / count;
-  double var = stats[W + c] / count - mean * mean;
-  var = var > 0 ? var : 0;
-  const double rstd = 1.0 / sqrt(var + 1e-5);
-  const double zhat = ((double)z[idx] - mean) * rstd;
-  const double ma = sums[c] / count, mb = sums[W + c] / count;
-  d[idx] = (T)((double)gamma[c] * rstd * ((double)d[idx] - ma - zhat * mb));
-  if (idx < W) {  // parameter gradients from this rank's rows only (averaged across ranks later)
-    dbeta[c] += (T)own_sums[c];
-    dgamma[c] += (T)own_sums[W + c];
+  __syncthreads();
+  const int cg = W / 4, rl = 256 / cg;
+  const int c4 = (threadIdx.x % cg) * 4, rsub = threadIdx.x / cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  if (rsub >= rl) return;
+  for (int64_t r = r0 + rsub; r < r1; r += rl) {
+    const Vec4<T> g = load4<T>(d + r * W + c4), v = load4<T>(z + r * W + c4);
+    Vec4<T> o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c4 + k;
+      const double zhat = ((double)v.v[k] - s_mean[c]) * s_rstd[c];
+      o.v[k] = c < F ? (T)(s_g[c] * s_rstd[c] * ((double)g.v[k] - s_ma[c] - zhat * s_mb[c])) : (T)0;
+    }
+    store4(d + r * W + c4, o);
   }
 }
 
 // The four steps are separate launches because a data-parallel run all-reduces the column
 // sums between (col_sums, apply) and between (bwd_sums, bwd_apply); `count` is the number of
 // rows the statistics cover (all ranks), R the rows of this rank.
+// (W, the padded hidden width, is 32, 64 or 128: W / 4 column groups divide 256)
+static int bn_rows_per_block(int64_t R) {
+  const int64_t per = (R + 1023) / 1024;  // ~1024 blocks
+  return (int)std::max<int64_t>(64, (per + 15) / 16 * 16);
+}
 template <typename T>
 void launch_bn_col_sums(const T *z, int64_t R, int W, double *stats, hipStream_t st) {
   (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * W, st);
   if (R == 0) return;
-  const int rpb = 256;
-  col_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(z, R, W, stats, rpb);
+  const int rpb = bn_rows_per_block(R);
+  col_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 256, 0, st>>>(z, R, W, stats, rpb);
 }
 template <typename T>
 void launch_bn_train_apply(const T *z, int64_t R, int W, int F, const double *stats, double count,
                            const T *gamma, const T *beta, T *h, T *mv, hipStream_t st) {
   if (R == 0) return;
-  bn_train_fwd_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(z, R, W, F, stats, count, gamma,
-                                                                          beta, h, mv);
+  const int rpb = bn_rows_per_block(R);
+  bn_train_fwd_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 256, 0, st>>>(z, R, W, F, stats, count, gamma, beta, h, mv, rpb);
 }
 template <typename T>
 void launch_bn_bwd_sums(const T *d, const T *z, int64_t R, int W, int F, const double *stats, double count,
                         double *sums, hipStream_t st) {
   (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * W, st);
   if (R == 0) return;
-  const int rpb = 256;
-  bn_bwd_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 128, 0, st>>>(d, z, R, W, F, stats, count, sums, rpb);
+  const int rpb = bn_rows_per_block(R);
+  bn_bwd_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 256, 0, st>>>(d, z, R, W, F, stats, count, sums, rpb);
 }
 template <typename T>
 void launch_bn_bwd_apply(T *d, const T *z, int64_t R, int W, int F, const double *stats, double count,
                          const double *sums, const double *own_sums, const T *gamma, T *dgamma, T *dbeta,
                          hipStream_t st) {
   if (R == 0) return;
-  bn_bwd_apply_kernel<T><<<(unsigned)((R * W + 255) / 256), 256, 0, st>>>(d, z, R, W, F, stats, count, sums,
-                                                                          own_sums, gamma, dgamma, dbeta);
+  const int rpb = bn_rows_per_block(R);
+  bn_bwd_apply_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), 256, 0, st>>>(d, z, R, W, F, stats, count, sums, own_sums, gamma,
+                                                                        dgamma, dbeta, rpb);
 }
 #define RN_BN_INST(T)                                                                                     \
   template void launch_bn_col_sums<T>(const T *, int64_t, int, double *, hipStream_t);                    \
