@@ -885,6 +885,36 @@ def test_training_step_at_config5_shape():
     assert worst < 1e-4  # measured 1.1e-5
 
 
+def test_training_gradients_with_a_widened_node_width():
+    """Fn = 12 / Fe = 40: Fe pads to 64, so Fn is padded to 64 as well (fused kernels, masked LayerNorms) and
+    every parameter gradient has to come back through the padding: float64 device step against float64 autograd
+    through the oracle, float32 device step (fused taped forward, split-f16 reverse products) against that."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("triclinic20")
+    model, oracle = _random_model(g, 3.0, 12, 40, 2, seed=1240)
+    pos = g["pos_batch"][:5]
+    rng = np.random.default_rng(7)
+    targets = rng.normal(size=(5, 6))
+    out64, loss64, grads64 = model.train_gradients_f64(pos, targets)
+    o_out, o_loss, o_grads = O.train_gradients(oracle.to(torch.float64), pos, targets)
+    np.testing.assert_allclose(out64, o_out, rtol=0, atol=1e-9 * np.abs(o_out).max())
+    assert loss64 == pytest.approx(o_loss, rel=1e-9)
+    for name, ref in o_grads.items():
+        scale = np.abs(ref).max()
+        assert np.abs(grads64[name] - ref).max() < 1e-8 * scale + 1e-12, name
+    model.train()
+    lat = torch.tensor(g["lattice"], dtype=torch.float32).expand(5, 3, 3)
+    zs = torch.tensor(model._ref_structure.atomic_numbers).expand(5, -1)
+    out = model.forward(lat, zs, torch.tensor(pos, dtype=torch.float32))
+    assert model.config_flags()["fused_edge_block"]
+    torch.nn.MSELoss()(out, torch.tensor(targets, dtype=torch.float32)).backward()
+    for name, p in model.named_parameters():
+        scale = np.abs(grads64[name]).max()
+        if scale < 1e-12:
+            continue
+        assert np.abs(p.grad.numpy() - grads64[name]).max() < 2e-4 * scale, name
+
+
 def _adam_run(model, optimizer, lat, zs, pos, targets, steps):
     losses = []
     model.train()
