@@ -1606,7 +1606,10 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
   const int64_t s0 = (AMODE == 1 && g.E > 0) ? r0 / g.E : 0, e0 = (AMODE == 1) ? r0 - s0 * g.E : 0;
-  constexpr int U = 4;  // row pairs per step
+#ifndef RN_TN_U
+#define RN_TN_U 4
+#endif
+  constexpr int U = RN_TN_U;  // row pairs per step
   if constexpr (AMODE == 0) {
     // two steps in flight: the next step's rows are requested before this step's MFMAs (the loads of a step
     // otherwise wait behind 8 KT / 2 x 64 cycles of matrix-pipe issue, and the pipe then idles for their latency)
