@@ -209,24 +209,35 @@ template void launch_readout_bwd<double>(const double *, const double *, const d
 
 // dz = dh * ssp'(z) * scale, with ssp'(z) = sigmoid(z) = 1 - exp(-(h + ln2)) expressed through
 // the stored activation h = ssp(z).  `h` is indexed by forward row, `d` by cotangent row.
+// One thread per four columns of a row (width a multiple of 4): the row arithmetic (64-bit divisions) once per
+// sixteen bytes instead of once per element.
 template <typename T>
 __global__ void ssp_bwd_kernel(T *__restrict__ d, const T *__restrict__ h, const T *__restrict__ scale,
                                int64_t rows_per_frame, int width, int C, int B) {
+  const int cg = width / 4;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)C * rows_per_frame * width;
+  const int64_t total = (int64_t)C * rows_per_frame * cg;
   if (idx >= total) return;
-  const int col = (int)(idx % width);
-  const int64_t crow = idx / width;
-  const int c = (int)(crow / rows_per_frame);
-  const int64_t frow = (int64_t)(c / B) * rows_per_frame + crow % rows_per_frame;
-  const T hv = h[frow * width + col];
-  const T sg = (T)1 - (T)0.5 * exp(-hv);
-  d[idx] *= sg * (scale ? scale[col] : (T)1);
+  const int col = (int)(idx % cg) * 4;
+  const int64_t crow = idx / cg;
+  int64_t frow = crow;
+  if (B != 1) {
+    const int c = (int)(crow / rows_per_frame);
+    frow = (int64_t)(c / B) * rows_per_frame + crow % rows_per_frame;
+  }
+  const Vec4<T> hv = load4<T>(h + frow * width + col);
+  Vec4<T> dv = load4<T>(d + crow * width + col);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T sg = (T)1 - (T)0.5 * exp(-hv.v[k]);
+    dv.v[k] *= sg * (scale ? scale[col + k] : (T)1);
+  }
+  store4(d + crow * width + col, dv);
 }
 template <typename T>
 void launch_ssp_bwd(T *d, const T *h, const T *scale, int64_t rows_per_frame, int width, int C,
                     int B, hipStream_t st) {
-  const int64_t total = (int64_t)C * rows_per_frame * width;
+  const int64_t total = (int64_t)C * rows_per_frame * (width / 4);
   if (total == 0) return;
   ssp_bwd_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d, h, scale, rows_per_frame,
                                                                      width, C, B);
@@ -1103,7 +1114,22 @@ __global__ void q_gather_kernel(const T *__restrict__ dpq, T *__restrict__ dnp3,
   if (gid >= (int64_t)C * g.N) return;
   const int c = (int)(gid / g.N), n = (int)(gid % g.N);
   Vec4<T> sf{{0, 0, 0, 0}}, sc{{0, 0, 0, 0}};
-  for (int i = g.in_ptr[n]; i < g.in_ptr[n + 1]; ++i) {
+  const int i0 = g.in_ptr[n], i1 = g.in_ptr[n + 1];
+  int i = i0;
+  for (; i + 3 < i1; i += 4) {  // four rows in flight (the sum keeps the ascending order)
+    const T *s0 = dpq + ((int64_t)c * g.E + g.in_edge[i]) * (4 * FP) + 2 * FP + 4 * q;
+    const T *s1 = dpq + ((int64_t)c * g.E + g.in_edge[i + 1]) * (4 * FP) + 2 * FP + 4 * q;
+    const T *s2 = dpq + ((int64_t)c * g.E + g.in_edge[i + 2]) * (4 * FP) + 2 * FP + 4 * q;
+    const T *s3 = dpq + ((int64_t)c * g.E + g.in_edge[i + 3]) * (4 * FP) + 2 * FP + 4 * q;
+    const Vec4<T> f0 = load4<T>(s0), c0 = load4<T>(s0 + FP), f1 = load4<T>(s1), c1 = load4<T>(s1 + FP);
+    const Vec4<T> f2 = load4<T>(s2), c2 = load4<T>(s2 + FP), f3 = load4<T>(s3), c3 = load4<T>(s3 + FP);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sf.v[k] = (((sf.v[k] + f0.v[k]) + f1.v[k]) + f2.v[k]) + f3.v[k];
+      sc.v[k] = (((sc.v[k] + c0.v[k]) + c1.v[k]) + c2.v[k]) + c3.v[k];
+    }
+  }
+  for (; i < i1; ++i) {
     const T *src = dpq + ((int64_t)c * g.E + g.in_edge[i]) * (4 * FP) + 2 * FP + 4 * q;
     const Vec4<T> f = load4<T>(src), cc = load4<T>(src + FP);
 #pragma unroll
@@ -1130,18 +1156,37 @@ __global__ void prod_bwd_kernel(const T *__restrict__ dprod, const T *__restrict
   const int c = (int)(gid / g.N), n = (int)(gid % g.N);
   const int64_t nrow0 = (int64_t)(c / B) * g.N, cerow0 = (int64_t)c * g.E;
   Vec4<T> acc = load4<T>(dnode + gid * FP + 4 * q);
-  for (int i = g.in_ptr[n]; i < g.in_ptr[n + 1]; ++i) {
-    const int e = g.in_edge[i];
-    const Vec4<T> dp = load4<T>(dprod + (cerow0 + e) * FP + 4 * q);
-    const Vec4<T> na = load4<T>(node + (nrow0 + g.edge_a[e]) * FP + 4 * q);
+  {  // (two edges in flight per step, summed in ascending order)
+    const int i0 = g.in_ptr[n], i1 = g.in_ptr[n + 1];
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {
+      const int e0 = g.in_edge[i], e1 = g.in_edge[i + 1];
+      const Vec4<T> dp0 = load4<T>(dprod + (cerow0 + e0) * FP + 4 * q), dp1 = load4<T>(dprod + (cerow0 + e1) * FP + 4 * q);
+      const Vec4<T> na0 = load4<T>(node + (nrow0 + g.edge_a[e0]) * FP + 4 * q), na1 = load4<T>(node + (nrow0 + g.edge_a[e1]) * FP + 4 * q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * na.v[k];
-  }
-  for (int e = g.out_ptr[n]; e < g.out_ptr[n + 1]; ++e) {
-    const Vec4<T> dp = load4<T>(dprod + (cerow0 + e) * FP + 4 * q);
-    const Vec4<T> nb = load4<T>(node + (nrow0 + g.edge_b[e]) * FP + 4 * q);
+      for (int k = 0; k < 4; ++k) acc.v[k] = (acc.v[k] + dp0.v[k] * na0.v[k]) + dp1.v[k] * na1.v[k];
+    }
+    if (i < i1) {
+      const int e = g.in_edge[i];
+      const Vec4<T> dp = load4<T>(dprod + (cerow0 + e) * FP + 4 * q);
+      const Vec4<T> na = load4<T>(node + (nrow0 + g.edge_a[e]) * FP + 4 * q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * nb.v[k];
+      for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * na.v[k];
+    }
+    const int o1 = g.out_ptr[n + 1];
+    int e = g.out_ptr[n];
+    for (; e + 1 < o1; e += 2) {
+      const Vec4<T> dp0 = load4<T>(dprod + (cerow0 + e) * FP + 4 * q), dp1 = load4<T>(dprod + (cerow0 + e + 1) * FP + 4 * q);
+      const Vec4<T> nb0 = load4<T>(node + (nrow0 + g.edge_b[e]) * FP + 4 * q), nb1 = load4<T>(node + (nrow0 + g.edge_b[e + 1]) * FP + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc.v[k] = (acc.v[k] + dp0.v[k] * nb0.v[k]) + dp1.v[k] * nb1.v[k];
+    }
+    if (e < o1) {
+      const Vec4<T> dp = load4<T>(dprod + (cerow0 + e) * FP + 4 * q);
+      const Vec4<T> nb = load4<T>(node + (nrow0 + g.edge_b[e]) * FP + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc.v[k] += dp.v[k] * nb.v[k];
+    }
   }
   store4(dnode + gid * FP + 4 * q, acc);
 }
@@ -1870,6 +1915,9 @@ __global__ __launch_bounds__(256) void col_sums_kernel(const T *__restrict__ z, 
     atomicAdd(stats + kind * W + c, t);
   }
 }
+// (float32: the hardware exp2 / log2 form of the projection epilogues, abs error ~1e-7; float64: libm)
+__device__ __forceinline__ float ssp_hw(float x) { return ssp_fast(x); }
+__device__ __forceinline__ double ssp_hw(double x) { return ssp(x); }
 // h = ssp(gamma * (z - mean) * rstd + beta);  mean/rstd derived from the sums; also writes
 // batch mean and biased variance (for the running-statistics update) into mv[0:W], mv[W:2W].
 template <typename T>
@@ -1907,7 +1955,7 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const T *__restrict__
     Vec4<T> o;
 #pragma unroll
     for (int k = 0; k < 4; ++k)  // (the same operation order as the per-element form: results unchanged)
-      o.v[k] = (c4 + k < F) ? ssp(s_gamma[c4 + k] * ((v.v[k] - s_mean[c4 + k]) * s_rstd[c4 + k]) + s_beta[c4 + k]) : (T)0;
+      o.v[k] = (c4 + k < F) ? ssp_hw(s_gamma[c4 + k] * ((v.v[k] - s_mean[c4 + k]) * s_rstd[c4 + k]) + s_beta[c4 + k]) : (T)0;
     store4(h + r * W + c4, o);
   }
 }
