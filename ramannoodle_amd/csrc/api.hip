@@ -158,6 +158,7 @@ struct rn_potgnn {
   std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin;
   bool use_fused = false;
   bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
+  bool split_projections = true;  // RN_POTGNN_SPLIT_PROJ=0: the forward's stand-alone projections on the exact-f32 MFMA kernel
   bool use_edge3 = false;  // fused EdgeBlock on twelve waves, one workgroup per CU (edge_block3_kernel + edge_c2_kernel)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
@@ -760,6 +761,16 @@ struct ChunkRun {
     const Dims d = h->d;
     const int nxt = cur ^ 1;
     target_tape(p + 1, nxt);
+    // Y = X W (+ bias): float32 with the split-f16 products enabled -> rowgemm_split_kernel where it serves the shape
+    // (K a multiple of 64), else the exact-f32 MFMA projection kernel
+    auto project = [&](const T *X, int64_t R, int K, const T *WT, int NOUT, T *Y, const T *bias, int amode, const T *nd) {
+      if constexpr (sizeof(T) == 4) {
+        if (h->mfma_f16 && h->split_projections &&
+            launch_rowgemm_split(X, K, K, R, WT, NOUT, Y, false, bias, amode, nd, g, st()))
+          return;
+      }
+      launch_rowgemm<T>(X, R, K, WT, NOUT, Y, nullptr, bias, false, amode, nd, g, st());
+    };
     if constexpr (sizeof(T) == 4) {
       if (narrow()) {  // the whole NodeBlock, projections included, in one launch
         Timer t(h, st(), K_NODE_AGG);
@@ -769,8 +780,7 @@ struct ChunkRun {
     }
     {
       Timer t(h, st(), K_PROJ_NODE);
-      launch_rowgemm<T>(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, nullptr, w.c1_bias, false,
-                        0, nullptr, g, st());
+      project(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, w.c1_bias, 0, nullptr);
     }
     bool node_fused = false;
     if constexpr (sizeof(T) == 4) {
@@ -783,8 +793,7 @@ struct ChunkRun {
     if (!node_fused) {
       {
         Timer t(h, st(), K_PROJ_EDGE_C1);
-        launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, nullptr, false, 0,
-                          nullptr, g, st());
+        project(edge[cur], ME, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, 0, nullptr);
       }
       {
         Timer t(h, st(), K_NODE_AGG);
@@ -793,8 +802,7 @@ struct ChunkRun {
     }
     {  // EdgeBlock uses the UPDATED node embedding (_gnn.py:649-650)
       Timer t(h, st(), K_PROJ_NODE);
-      launch_rowgemm<T>(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, nullptr, w.c3_nshift, false,
-                        0, nullptr, g, st());
+      project(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, w.c3_nshift, 0, nullptr);
     }
     if constexpr (sizeof(T) == 4) {
       if (fused() && (h->use_edge2 || (h->use_edge3 && edge3_applicable(w, h->mfma_f16)))) {  // c2 branch of the EdgeBlock, one finished row per edge
@@ -805,13 +813,11 @@ struct ChunkRun {
     if (!fused()) {
       {
         Timer t(h, st(), K_PROJ_EDGE_C3);
-        launch_rowgemm<T>(edge[cur], ME, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, nullptr, false,
-                          0, nullptr, g, st());
+        project(edge[cur], ME, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, 0, nullptr);
       }
       {
         Timer t(h, st(), K_PROJ_C2);
-        launch_rowgemm<T>(nullptr, ME, d.FnP, w.c2_WT, 2 * d.FeP, bufA, nullptr, w.c2_bias, false, 1,
-                          node[nxt], g, st());
+        project(nullptr, ME, d.FnP, w.c2_WT, 2 * d.FeP, bufA, w.c2_bias, 1, node[nxt]);
       }
     }
   }
@@ -1872,6 +1878,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     hp->use_edge2 = want_fused && want_edge2 && edge2_supported(hp->g, hp->d);
     hp->use_fused = hp->use_edge2 || (want_fused && edge_fused_supported(hp->g, hp->d));
     hp->use_edge3 = hp->use_fused && !hp->use_edge2 && want_edge3 && edge3_supported(hp->g, hp->d);
+    hp->split_projections = getenv("RN_POTGNN_SPLIT_PROJ") ? atoi(getenv("RN_POTGNN_SPLIT_PROJ")) != 0 : true;
     hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
     // Chunk size and lanes.  Throughput rises monotonically with the frames per launch

@@ -374,7 +374,7 @@ bool launch_rowgemm_blocks(const float *X, int ldx, int N, int64_t M, const floa
 // Ranges: cotangent rows can be 1e-9 small and weights arbitrary, so every ROW of X and every wave's 64 x 16 NTW
 // weight block are brought to [2^12, 2^13) by an exact power of two before the split (kernels.hpp:
 // mfma_prescale) and the accumulators are scaled back in float32.
-// AMODE 1: the operand row of edge (frame s, e) is node[s, b_e] * node[s, a_e] (the c2 operand), K = 64.
+// AMODE 1: the operand row of edge (frame s, e) is node[s, b_e] * node[s, a_e] (the c2 operand; node rows K wide).
 typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 gf16x4 __attribute__((ext_vector_type(4)));
 template <int KB, int NTW, int AMODE>
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_split_kernel(GemmArgs a) {
       } else {
         const int64_t s = row / a.E;
         const int e = (int)(row - s * a.E);
-        const float4 x = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_b[e]) * 64 + 4 * p);
-        const float4 y = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_a[e]) * 64 + 4 * p);
+        const float4 x = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_b[e]) * (64 * KB) + 4 * p);
+        const float4 y = *reinterpret_cast<const float4 *>(a.node + (s * a.N + a.edge_a[e]) * (64 * KB) + 4 * p);
         nxt[j] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
       }
     }
@@ -518,7 +518,7 @@ bool launch_rowgemm_split(const float *X, int ldx, int K, int64_t M, const float
                           hipStream_t st) {
   if (M == 0) return true;
   static const bool off = getenv("RN_POTGNN_BWD_SPLIT_GEMM") && atoi(getenv("RN_POTGNN_BWD_SPLIT_GEMM")) == 0;
-  if (off || K % 64 != 0 || K > 256 || K == 192 || NOUT % 64 != 0 || (amode == 1 && K != 64)) return false;
+  if (off || K % 64 != 0 || K > 256 || K == 192 || NOUT % 64 != 0 || (amode == 1 && K > 128)) return false;
   GemmArgs a{X, ldx, accumulate ? 1 : 0, M, Wt, NOUT, Y, nullptr, bias, node, g.edge_a, g.edge_b, g.N, g.E};
   const int kb = K / 64;
   // columns per workgroup 64 NTW: as many as the weights' registers allow (64 KB NTW / 4 <= 64)
@@ -544,8 +544,13 @@ bool launch_rowgemm_split(const float *X, int ldx, int K, int64_t M, const float
   if (kb == 1 && ntw == 4) RN_SPLIT(1, 4);
   else if (kb == 1 && ntw == 2) RN_SPLIT(1, 2);
   else if (kb == 1) RN_SPLIT(1, 1);
-  else if (kb == 2 && ntw == 2) { if (amode == 1) return false; rowgemm_split_kernel<2, 2, 0><<<grid, 256, 0, st>>>(a); }
-  else if (kb == 2) { if (amode == 1) return false; rowgemm_split_kernel<2, 1, 0><<<grid, 256, 0, st>>>(a); }
+  else if (kb == 2 && ntw == 2) {
+    if (amode == 1) rowgemm_split_kernel<2, 2, 1><<<grid, 256, 0, st>>>(a);
+    else rowgemm_split_kernel<2, 2, 0><<<grid, 256, 0, st>>>(a);
+  } else if (kb == 2) {
+    if (amode == 1) rowgemm_split_kernel<2, 1, 1><<<grid, 256, 0, st>>>(a);
+    else rowgemm_split_kernel<2, 1, 0><<<grid, 256, 0, st>>>(a);
+  }
   else { if (amode == 1) return false; rowgemm_split_kernel<4, 1, 0><<<grid, 256, 0, st>>>(a); }
 #undef RN_SPLIT
   return true;
