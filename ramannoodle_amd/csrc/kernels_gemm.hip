@@ -612,12 +612,131 @@ __global__ __launch_bounds__(256) void rowgemm_f64_kernel(const double *X, int64
   }
 }
 
+// float64 on the matrix pipe: v_mfma_f64_16x16x4_f64 (78 TFLOP/s against the ~10 the FMA kernel above reaches).
+// Wave-autonomous like rowgemm_split_kernel's first form: a wave owns 16 NTW output columns with their weights in
+// registers (lane (l15, quad): W[KQ quad + ks][col], ks < KQ = K / 4), streams 16-row tiles from global memory into
+// the row operand (one contiguous run of KQ doubles per lane, next tile requested before the products) and ends
+// with columns quad, 4 + quad, 8 + quad, 12 + quad of row l15 per lane and tile (weights as the instruction's first operand).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+template <int KQ, int NTW>
+__global__ __launch_bounds__(256) void rowgemm_f64_mfma_kernel(const double *__restrict__ X, int64_t M,
+                                                               const double *__restrict__ WT, int NOUT,
+                                                               double *__restrict__ Y, const double *__restrict__ scale,
+                                                               const double *__restrict__ shift, int epi, int amode,
+                                                               const double *__restrict__ node, Graph g) {
+  constexpr int K = 4 * KQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int col0 = blockIdx.y * (64 * NTW) + wave * (16 * NTW);
+  double w[NTW][KQ];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) w[t][ks] = WT[(int64_t)(KQ * quad + ks) * NOUT + col0 + 16 * t + l15];
+  const int64_t ntiles = (M + 15) / 16;
+  double nxt[KQ];
+  auto fetch = [&](int64_t tile) {
+    int64_t row = tile * 16 + l15;
+    if (row >= M) row = M - 1;
+    if (amode == 0) {
+      const double *p = X + row * K + KQ * quad;
+#pragma unroll
+      for (int ks = 0; ks < KQ; ks += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(p + ks);
+        nxt[ks] = v.x;
+        nxt[ks + 1] = v.y;
+      }
+    } else {
+      const int64_t s = row / g.E;
+      const int e = (int)(row - s * g.E);
+      const double *pb = node + (s * g.N + g.edge_b[e]) * K + KQ * quad, *pa = node + (s * g.N + g.edge_a[e]) * K + KQ * quad;
+#pragma unroll
+      for (int ks = 0; ks < KQ; ks += 2) {
+        const double2 x = *reinterpret_cast<const double2 *>(pb + ks), y = *reinterpret_cast<const double2 *>(pa + ks);
+        nxt[ks] = x.x * y.x;
+        nxt[ks + 1] = x.y * y.y;
+      }
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    double x[KQ];
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) x[ks] = nxt[ks];
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+    f64x4_t acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[t][ks], x[ks], acc[t], 0, 0, 0);
+    const int64_t row = tile * 16 + l15;
+    if (row < M) {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        // (the f64 instruction's result layout differs from the f32 one: register j of lane (l15, quad) is row
+        //  4 j + quad of the product, i.e. here output column 4 j + quad -- tools/mfma_f64_layout_probe.hip)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = col0 + 16 * t + 4 * j + quad;
+          double v = acc[t][j];
+          if (epi == 1) v += shift[col];
+          if (epi == 2) v = ssp(v * scale[col] + shift[col]);
+          Y[row * NOUT + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int KQ>
+static bool launch_f64_mfma(const double *X, int64_t M, const double *WT, int NOUT, double *Y, const double *scale,
+                            const double *shift, int epi, int amode, const double *node, const Graph &g, hipStream_t st) {
+  // column tiles per wave: as many as 128 VGPRs of weights allow (2 KQ per tile) and NOUT divides into
+  int ntw = 0;
+  for (int c : {4, 2, 1})
+    if (2 * KQ * c <= 128 && NOUT % (64 * c) == 0) {
+      ntw = c;
+      break;
+    }
+  if (ntw == 0) return false;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int64_t ntiles = (M + 15) / 16;
+  const dim3 grid((unsigned)std::min<int64_t>(ntiles, (int64_t)4 * cus), (unsigned)(NOUT / (64 * ntw)));
+  if (ntw == 4) {
+    if constexpr (2 * KQ * 4 <= 128) rowgemm_f64_mfma_kernel<KQ, 4><<<grid, 256, 0, st>>>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g);
+  } else if (ntw == 2) {
+    if constexpr (2 * KQ * 2 <= 128) rowgemm_f64_mfma_kernel<KQ, 2><<<grid, 256, 0, st>>>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g);
+  } else {
+    rowgemm_f64_mfma_kernel<KQ, 1><<<grid, 256, 0, st>>>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g);
+  }
+  return true;
+}
+
 template <>
 void launch_rowgemm<double>(const double *X, int64_t M, int KP, const double *WT, int NOUT,
                             double *Y, const double *scale, const double *shift, bool act,
                             int amode, const double *node, const Graph &g, hipStream_t st) {
   if (M == 0) return;
   const int epi = act ? 2 : (shift ? 1 : 0);
+  static const bool no_mfma = getenv("RN_POTGNN_F64_MFMA") && atoi(getenv("RN_POTGNN_F64_MFMA")) == 0;
+  if (!no_mfma) {
+    bool done = false;
+    switch (KP) {
+      case 16: done = launch_f64_mfma<4>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g, st); break;
+      case 32: done = launch_f64_mfma<8>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g, st); break;
+      case 64: done = launch_f64_mfma<16>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g, st); break;
+      case 128: done = launch_f64_mfma<32>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g, st); break;
+    }
+    if (done) return;
+  }
   const int64_t tiles = (M + 31) / 32;
   const unsigned grid = (unsigned)(tiles < 8192 ? tiles : 8192);
   rowgemm_f64_kernel<<<grid, 256, (size_t)32 * KP * sizeof(double), st>>>(
