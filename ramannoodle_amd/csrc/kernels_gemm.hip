@@ -628,6 +628,7 @@ __global__ __launch_bounds__(256) void rowgemm_f64_mfma_kernel(const double *__r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   const int col0 = blockIdx.y * (64 * NTW) + wave * (16 * NTW);
+  if (col0 >= NOUT) return;  // (NOUT = 32: the last workgroup's upper waves have no columns; no barriers in this kernel)
   double w[NTW][KQ];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
@@ -700,6 +701,7 @@ static bool launch_f64_mfma(const double *X, int64_t M, const double *WT, int NO
       ntw = c;
       break;
     }
+  if (ntw == 0 && NOUT % 16 == 0) ntw = 1;  // e.g. the readout's last layer (32 columns): two waves of a workgroup idle
   if (ntw == 0) return false;
   static int cus = 0;
   if (cus == 0) {
@@ -709,7 +711,7 @@ static bool launch_f64_mfma(const double *X, int64_t M, const double *WT, int NO
     if (cus <= 0) cus = 256;
   }
   const int64_t ntiles = (M + 15) / 16;
-  const dim3 grid((unsigned)std::min<int64_t>(ntiles, (int64_t)4 * cus), (unsigned)(NOUT / (64 * ntw)));
+  const dim3 grid((unsigned)std::min<int64_t>(ntiles, (int64_t)4 * cus), (unsigned)((NOUT + 64 * ntw - 1) / (64 * ntw)));
   if (ntw == 4) {
     if constexpr (2 * KQ * 4 <= 128) rowgemm_f64_mfma_kernel<KQ, 4><<<grid, 256, 0, st>>>(X, M, WT, NOUT, Y, scale, shift, epi, amode, node, g);
   } else if (ntw == 2) {
