@@ -62,8 +62,12 @@ __device__ __forceinline__ float gate(float f, float c) {
   float den = (1.0f + e1) * (1.0f + e2);
   return (e2 - 1.0f) * fast_rcp(den);
 }
+// float64: the same identity with one division, sigmoid(f) tanh(c) = expm1(2c) / ((1 + e^-f)(expm1(2c) + 2));
+// expm1 keeps tanh's relative accuracy near c = 0, and beyond |c| = 20 tanh is +-1 to 17 digits.
 __device__ __forceinline__ double gate(double f, double c) {
-  return (1.0 / (1.0 + exp(-f))) * tanh(c);
+  c = fmin(fmax(c, -20.0), 20.0);
+  const double em = expm1(2.0 * c);
+  return em / ((1.0 + exp(-f)) * (em + 2.0));
 }
 
 __device__ __forceinline__ float acc_tanh(float x) { return tanhf(x); }
