@@ -155,7 +155,7 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin;
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin, bt_begin;
   bool use_fused = false;
   bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
   bool split_projections = true;  // RN_POTGNN_SPLIT_PROJ=0: the forward's stand-alone projections on the exact-f32 MFMA kernel
@@ -1711,6 +1711,30 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       }
     }
   }
+  // node tiles of the EdgeBlock reverse kernel: the largest whose float32 LDS footprint leaves room for two workgroups
+  // per CU (RN_POTGNN_BWD_TILES=0: the forward kernel's tiles, one 512-thread workgroup per CU)
+  int bt_max_rows = 0, bt_max_in = 0, bt_max_nodes = 0;
+  if (!(getenv("RN_POTGNN_BWD_TILES") && atoi(getenv("RN_POTGNN_BWD_TILES")) == 0)) {
+    std::vector<int> tb;
+    for (size_t budget = 1; budget <= 512; ++budget) {
+      const int mr = build_tiles(budget, tb);
+      int max_in = 0, max_nodes = 0;
+      for (size_t t = 0; t + 1 < tb.size(); ++t) {
+        max_in = std::max(max_in, h->in_ptr[tb[t + 1]] - h->in_ptr[tb[t]]);
+        max_nodes = std::max(max_nodes, tb[t + 1] - tb[t]);
+      }
+      if (edge_bwd_tile2_lds_bytes(mr, max_in, max_nodes, d.FeP, sizeof(float)) > (size_t)78 * 1024) {
+        if (!h->bt_begin.empty()) break;
+        continue;
+      }
+      if (h->bt_begin.empty() || mr > bt_max_rows) {
+        h->bt_begin = tb;
+        bt_max_rows = mr;
+        bt_max_in = max_in;
+        bt_max_nodes = max_nodes;
+      }
+    }
+  }
   // node tiles of the fused NodeBlock kernel: consecutive atoms by IN-edges; four workgroups per CU
   // (40 KiB of LDS each), as few rounds x tiles as possible
   int nt_max_in = 0, nt_max_nodes = 0;
@@ -1829,7 +1853,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
                  o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge),
-                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin);
+                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin), o_bt = push(hp->bt_begin);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -1865,6 +1889,11 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.et_max_out_rows = et_max_rows;
     g.et_max_in_rows = et_max_in;
     g.et_max_nodes = et_max_nodes;
+    g.bt_num = hp->bt_begin.empty() ? 0 : (int)hp->bt_begin.size() - 1;
+    g.bt_begin = base + o_bt;
+    g.bt_max_out_rows = bt_max_rows;
+    g.bt_max_in_rows = bt_max_in;
+    g.bt_max_nodes = bt_max_nodes;
     double ms[18];
     std::memcpy(ms, hp->mean, sizeof(hp->mean));
     std::memcpy(ms + 9, hp->stdv, sizeof(hp->stdv));

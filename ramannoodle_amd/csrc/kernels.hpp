@@ -33,6 +33,10 @@ struct Graph {
   int et_num;
   const int *et_begin;    // [et_num+1] node ranges
   int et_max_out_rows, et_max_in_rows, et_max_nodes;
+  // node tiles of the EdgeBlock reverse kernel (edge_bwd_tile2_kernel): small enough for TWO workgroups per CU
+  int bt_num;
+  const int *bt_begin;    // [bt_num+1] node ranges
+  int bt_max_out_rows, bt_max_in_rows, bt_max_nodes;
   // triplet enumeration
   const int *trip_off;  // [E+1] exclusive prefix of triplets per destination edge
   int64_t T;
@@ -124,6 +128,8 @@ void launch_rowgemm(const T *X, int64_t M, int KP, const T *WT, int NOUT, T *Y,
                     const Graph &g, hipStream_t st);
 
 // float32 only: Y (+)= X[:, 0:N] * Wt[N, NOUT] on the MFMA kernel; false if the shape is unsupported
+// LDS bytes of edge_bwd_tile2_kernel for a tile with these maxima (element size 4 or 8)
+size_t edge_bwd_tile2_lds_bytes(int rows, int in_rows, int nodes, int FP, size_t elem);
 // split-f16 row product for the reverse pass (kernels_gemm.hip: rowgemm_split_kernel); false = shape not served
 bool launch_rowgemm_split(const float *X, int ldx, int K, int64_t M, const float *Wt, int NOUT, float *Y,
                           bool accumulate, const float *bias, int amode, const float *node, const Graph &g,

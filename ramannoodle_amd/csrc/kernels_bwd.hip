@@ -748,7 +748,12 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
   constexpr int LG = FP / 4;
   constexpr int G = NT / LG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int maxR = g.max_tile_out_rows, maxD = g.max_tile_in_rows, maxN = g.max_tile_nodes;
+  // its own atom partition when the handle has one (Graph::bt_*), else the forward kernel's tiles
+  const bool own = g.bt_num > 0;
+  const int maxR = own ? g.bt_max_out_rows : g.max_tile_out_rows, maxD = own ? g.bt_max_in_rows : g.max_tile_in_rows,
+            maxN = own ? g.bt_max_nodes : g.max_tile_nodes;
+  const int num_tiles = own ? g.bt_num : g.num_tiles;
+  const int *tile_begin = own ? g.bt_begin : g.tile_begin;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     unsigned char *p = smem_raw + off;
@@ -770,9 +775,9 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
       *d_cnt = dl + 4 * maxD, *d_skip = dl + 5 * maxD;
   constexpr int GW = 64 / LG, NW = NT / 64;                                       // lane groups per wave, waves
 
-  const int tile = blockIdx.x % g.num_tiles;
-  const int cg = blockIdx.x / g.num_tiles, ncg = gridDim.x / g.num_tiles;
-  const int j0 = g.tile_begin[tile], j1 = g.tile_begin[tile + 1];
+  const int tile = blockIdx.x % num_tiles;
+  const int cg = blockIdx.x / num_tiles, ncg = gridDim.x / num_tiles;
+  const int j0 = tile_begin[tile], j1 = tile_begin[tile + 1];
   const int eo0 = g.out_ptr[j0], rows = g.out_ptr[j1] - eo0;
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
   for (int r = threadIdx.x; r < rows; r += NT) {
@@ -1084,14 +1089,16 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
   }
 }
 
-static size_t edge_bwd_tile2_lds(const Graph &g, int FP, size_t elem) {
+size_t edge_bwd_tile2_lds_bytes(int rows, int in_rows, int nodes, int FP, size_t elem) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   // (qrows and the two dQ' copies; qrows doubles as the scratch of wg_sum_atomic_add)
-  const size_t row_arrays = std::max(up((size_t)g.max_tile_out_rows * 2 * FP * elem) +
-                                         up((size_t)2 * g.max_tile_out_rows * 2 * FP * elem), (size_t)2048 * elem);
-  return row_arrays + up((size_t)g.max_tile_in_rows * FP * elem) + up((size_t)g.max_tile_out_rows * elem) +
-         up((size_t)g.max_tile_in_rows * elem) + 2 * up((size_t)g.max_tile_nodes * 2 * FP * elem) +
-         2 * up((size_t)g.max_tile_out_rows * 4) + up((size_t)g.max_tile_in_rows * 6 * 4);
+  const size_t row_arrays = std::max(up((size_t)rows * 2 * FP * elem) + up((size_t)2 * rows * 2 * FP * elem), (size_t)2048 * elem);
+  return row_arrays + up((size_t)in_rows * FP * elem) + up((size_t)rows * elem) + up((size_t)in_rows * elem) +
+         2 * up((size_t)nodes * 2 * FP * elem) + 2 * up((size_t)rows * 4) + up((size_t)in_rows * 6 * 4);
+}
+static size_t edge_bwd_tile2_lds(const Graph &g, int FP, size_t elem) {
+  if (g.bt_num > 0) return edge_bwd_tile2_lds_bytes(g.bt_max_out_rows, g.bt_max_in_rows, g.bt_max_nodes, FP, elem);
+  return edge_bwd_tile2_lds_bytes(g.max_tile_out_rows, g.max_tile_in_rows, g.max_tile_nodes, FP, elem);
 }
 
 static size_t edge_bwd_tile_lds(const Graph &g, int FP, size_t elem) {
@@ -1387,7 +1394,22 @@ static bool launch_edge_bwd_tile(const T *pq, const T *np3, const T *c2pre, cons
   const bool two_pass = edge_bwd_two_pass(g, FP, sizeof(T));
   const size_t lds = two_pass ? lds2 : edge_bwd_tile_lds(g, FP, sizeof(T));
   if (lds > 160 * 1024 - 512) return false;
-  // the two-pass kernel holds one tile per CU: 512 threads (two waves per SIMD) share it
+  // with its own small tiles: two 256-thread workgroups per CU (independent workgroups fill each other's latency-bound
+  // phases); on the forward kernel's tiles: one 512-thread workgroup per CU
+  if (two_pass && g.bt_num > 0) {
+    constexpr int NTS = 256;
+    auto k2 = &edge_bwd_tile2_kernel<FP, T, NTS>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu2 = 0, dev2 = 0, cus2 = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k2, NTS, lds) != hipSuccess || per_cu2 < 1) per_cu2 = 1;
+    hipDeviceProp_t prop2;
+    if (hipGetDevice(&dev2) == hipSuccess && hipGetDeviceProperties(&prop2, dev2) == hipSuccess) cus2 = prop2.multiProcessorCount;
+    int ncg2 = per_cu2 * cus2 / g.bt_num;
+    ncg2 = ncg2 < 1 ? 1 : (ncg2 > C ? C : ncg2);
+    edge_bwd_tile2_kernel<FP, T, NTS><<<(unsigned)ncg2 * (unsigned)g.bt_num, NTS, lds, st>>>(pq, np3, c2pre, edge_next, agg, dedge_next,
+                                                                                    dedge_prev, dpq, dnp3, dc2pre, C, B, g, d, w, gwv, want);
+    return true;
+  }
   constexpr int NT2 = 512;
   const void *kern = two_pass ? reinterpret_cast<const void *>(&edge_bwd_tile2_kernel<FP, T, NT2>)
                               : reinterpret_cast<const void *>(&edge_bwd_tile_kernel<FP, T>);
