@@ -1766,6 +1766,91 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
   if (dbias) atomicAdd(dbias + ncol, bsum);  // both lane halves hold half of the rows
 }
 
+// The same product with the operand rows staged through LDS: the workgroup loads 32-row tiles of X and dY with 16-byte
+// accesses (a quarter of the load instructions of the per-lane 4-byte form above, which keeps the texture addresser ~75 %
+// busy and the matrix pipe 27 %), the next tile in registers while the current one multiplies, and the four waves read
+// their operands from LDS (row strides padded by 32 floats: the two lane halves of an instruction read different rows).
+// K <= 128 (KT 32-column tiles of X), a 128-column slab of dY per workgroup; always writes a partial slice.
+template <int KT>
+__global__ __launch_bounds__(256) void gemm_tn_lds_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ dY,
+                                                          int ldy, int64_t R, int K, int N, float *__restrict__ part,
+                                                          int slice_stride, int rows_per_block) {
+  constexpr int RT = 32, LDX = 32 * KT + 32, LDY = 128 + 32;
+  __shared__ __attribute__((aligned(16))) float xs[2][RT * LDX];
+  __shared__ __attribute__((aligned(16))) float ys[2][RT * LDY];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.y * 128;
+  const int nslab = min(128, N - n0);           // columns of this workgroup (a multiple of 32)
+  const bool active = wave * 32 < nslab;        // waves beyond the slab only help loading
+  const int ncol = n0 + wave * 32 + l31;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  constexpr int XV = RT * KT * 8 / 256;         // float4 per thread of an X tile (KT 32-column tiles = 8 KT float4 per row)
+  constexpr int YV = RT * 32 / 256;             // float4 per thread of a dY tile (128 columns)
+  float4 px[XV], py[YV];
+  auto request = [&](int64_t rb) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int i = tid + 256 * j, r = i / (8 * KT), c = (i % (8 * KT)) * 4;
+      const int64_t row = rb + r;
+      px[j] = (row < r1 && c < K) ? *reinterpret_cast<const float4 *>(X + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < YV; ++j) {
+      const int i = tid + 256 * j, r = i / 32, c = (i % 32) * 4;
+      const int64_t row = rb + r;
+      py[j] = (row < r1 && c < nslab) ? *reinterpret_cast<const float4 *>(dY + row * ldy + n0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int i = tid + 256 * j, r = i / (8 * KT), c = (i % (8 * KT)) * 4;
+      *reinterpret_cast<float4 *>(&xs[b][r * LDX + c]) = px[j];
+    }
+#pragma unroll
+    for (int j = 0; j < YV; ++j) {
+      const int i = tid + 256 * j, r = i / 32, c = (i % 32) * 4;
+      *reinterpret_cast<float4 *>(&ys[b][r * LDY + c]) = py[j];
+    }
+  };
+  f32x16_t acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  request(r0);
+  int b = 0;
+  for (int64_t rb = r0; rb < r1; rb += RT, b ^= 1) {
+    commit(b);
+    if (rb + RT < r1) request(rb + RT);
+    __syncthreads();  // tile b complete (tile b^1 is free: every wave has finished the previous tile's products)
+    if (active) {
+#pragma unroll 4
+      for (int rp = 0; rp < RT / 2; ++rp) {
+        const float bv = ys[b][(2 * rp + h) * LDY + wave * 32 + l31];
+        bsum += bv;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[b][(2 * rp + h) * LDX + 32 * t + l31], bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  float *slice = part + (size_t)blockIdx.x * slice_stride;  // [K][N] block sum, then [N] column sums of dY
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (k < K) slice[(size_t)k * N + ncol] = acc[t][i];
+    }
+  bsum += __shfl_xor(bsum, 32);
+  if (h == 0) slice[(size_t)K * N + ncol] = bsum;
+}
+
 // Sum of the partial slices of every deferred product of a reverse pass: one workgroup per 32 gradient
 // elements (8 lane groups of 32 take every 8th slice, then an LDS sum), one writer per element.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(TnReduceTable t) {
@@ -1841,6 +1926,16 @@ static bool launch_gemm_tn_mfma(const float *X, int ldx, const float *dY, int ld
     t.wg_begin[t.num + 1] = t.wg_begin[t.num] + (K * N + (dbias ? N : 0) + 31) / 32;
     ++t.num;
     defer->used += need;
+  }
+  static const bool lds_form = !(getenv("RN_POTGNN_TN_LDS") && atoi(getenv("RN_POTGNN_TN_LDS")) == 0);
+  if (part && lds_form && ldx % 4 == 0 && ldy % 4 == 0 && K % 4 == 0) {
+    switch (kt) {
+      case 1: gemm_tn_lds_kernel<1><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, out, ld_out, rows_per_block); break;
+      case 2: gemm_tn_lds_kernel<2><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, out, ld_out, rows_per_block); break;
+      case 3: gemm_tn_lds_kernel<3><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, out, ld_out, rows_per_block); break;
+      default: gemm_tn_lds_kernel<4><<<grid, 256, 0, st>>>(X, ldx, dY, ldy, R, K, N, out, ld_out, rows_per_block); break;
+    }
+    return true;
   }
 #define RN_TNM(KTV)                                                                                           \
   do {                                                                                                        \
