@@ -1007,8 +1007,28 @@ __global__ __launch_bounds__(NT) void edge_bwd_tile2_kernel(
           T *dq = dqh + (size_t)r * 2 * FP + 4 * q;
           if constexpr ((RN_BWD_PROBE & 2) != 0) {
             dpf.v[0] += xc.v[0];
+          } else if constexpr (GW == 4 && sizeof(T) == 4) {
+            // reduce-scatter over the four lane groups on the VALU: v_permlane32_swap exchanges the upper half of one
+            // register with the lower half of another, so (xc, xf) -> lower lanes hold both halves' xc, upper lanes both
+            // halves' xf; v_permlane16_swap does the same between the 16-lane rows for the column pairs {0,1} / {2,3}
+            const bool upper = (threadIdx.x & 32) != 0, odd = (threadIdx.x & 16) != 0;
+            float a4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xc.v[k]), __float_as_uint(xf.v[k]), false, false);
+              a4[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            float b2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a4[k]), __float_as_uint(a4[2 + k]), false, false);
+              b2[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            T *o = dq + (upper ? 0 : FP) + (odd ? 2 : 0);  // this wave's copy: a plain read-modify-write
+            o[0] += b2[0];
+            o[1] += b2[1];
           } else if constexpr (GW == 4) {
-            // reduce-scatter over the four lane groups: halves swap xf/xc, then quarters swap column pairs
+            // (float64) reduce-scatter over the four lane groups: halves swap xf/xc, then quarters swap column pairs
             const bool upper = (threadIdx.x & 32) != 0, odd = (threadIdx.x & 16) != 0;
             T a4[4];
 #pragma unroll
