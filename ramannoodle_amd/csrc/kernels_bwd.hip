@@ -1995,10 +1995,11 @@ void launch_gemm_tn(const T *X, int ldx, const T *dY, int ldy, int64_t R, int K,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
     kern<<<grid, 256, lds, st>>>(X, ldx, dY, ldy, R, K, N, dWT, ldw, dbias, amode, node, g);        \
   } while (0)
+  // (float64 at K = 128 would need 197 KiB of LDS for the tiled kernel: the plain kernel takes it)
   if (K <= 16) RN_TN(16);
   else if (K <= 32) RN_TN(32);
   else if (K <= 64) RN_TN(64);
-  else if (K <= 128) RN_TN(128);
+  else if (K <= 128 && sizeof(T) == 4) RN_TN(128);
   else {
     const int rows_per_block = 512;
     dim3 g2((unsigned)((K * N + 255) / 256), (unsigned)((R + rows_per_block - 1) / rows_per_block));

@@ -915,6 +915,36 @@ def test_training_gradients_with_a_widened_node_width():
         assert np.abs(p.grad.numpy() - grads64[name]).max() < 2e-4 * scale, name
 
 
+@pytest.mark.parametrize("fn, fe", [(40, 100), (24, 20), (8, 20), (100, 30)])
+def test_training_gradients_on_the_unfused_chain(fn, fe):
+    """Widths the fused and narrow kernels do not serve (padded 64/128, 32/32, 16/32, 128/32): the reverse pass with
+    K = 16 .. 128 products -- split-f16 row products where K is a multiple of 64, the exact-f32 kernels otherwise,
+    the weight-gradient kernel with one to four 32-column tiles: float32 device gradients against the float64
+    device step, which is itself pinned to autograd through the oracle."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("triclinic20")
+    model, oracle = _random_model(g, 3.0, fn, fe, 2, seed=fn * 1000 + fe)
+    pos = g["pos_batch"][:4]
+    rng = np.random.default_rng(8)
+    targets = rng.normal(size=(4, 6))
+    out64, loss64, grads64 = model.train_gradients_f64(pos, targets)
+    o_out, o_loss, o_grads = O.train_gradients(oracle.to(torch.float64), pos, targets)
+    assert loss64 == pytest.approx(o_loss, rel=1e-9)
+    for name, ref in o_grads.items():
+        scale = np.abs(ref).max()
+        assert np.abs(grads64[name] - ref).max() < 1e-8 * scale + 1e-12, name
+    model.train()
+    lat = torch.tensor(g["lattice"], dtype=torch.float32).expand(4, 3, 3)
+    zs = torch.tensor(model._ref_structure.atomic_numbers).expand(4, -1)
+    out = model.forward(lat, zs, torch.tensor(pos, dtype=torch.float32))
+    torch.nn.MSELoss()(out, torch.tensor(targets, dtype=torch.float32)).backward()
+    for name, p in model.named_parameters():
+        scale = np.abs(grads64[name]).max()
+        if scale < 1e-12:
+            continue
+        assert np.abs(p.grad.numpy() - grads64[name]).max() < 2e-4 * scale, name
+
+
 def _adam_run(model, optimizer, lat, zs, pos, targets, steps):
     losses = []
     model.train()
