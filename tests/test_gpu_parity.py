@@ -187,6 +187,21 @@ def test_calc_polarizabilities_in_float64(golden):
         model.calc_polarizabilities(pos, dtype=torch.float16)
 
 
+@pytest.mark.parametrize("fn, fe", [(40, 100), (24, 20), (12, 40), (64, 64), (5, 14)])
+def test_float64_evaluation_at_other_widths(fn, fe):
+    """The float64 entry (``rowgemm_f64_mfma_kernel`` projections at K = 16 .. 128, the ``double`` aggregation
+    kernels) against the oracle evaluated in float64, with per-sample species on the way (``forward``)."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("triclinic20")
+    model, oracle = _random_model(g, 3.0, fn, fe, 2, seed=fn * 13 + fe)
+    pos = g["pos_batch"][:3]
+    got = model.calc_polarizabilities(pos, dtype=torch.float64)
+    want = O.calc_polarizabilities(oracle.to(torch.float64), pos, faithful=False)
+    assert _rel_err(got, np.asarray(want)) < 1e-10, (fn, fe)
+    got32 = model.calc_polarizabilities(pos)
+    assert _rel_err((got32 - oracle.mean) / oracle.std, (np.asarray(want) - oracle.mean) / oracle.std) < REL
+
+
 def test_forward_on_positions_far_outside_the_unit_cell():
     """Positions drawn from N(0,1), as in the reference's own batch test
     (``test/tests/torch/test_gnn.py:83-113``): fractional coordinates up to +-3.  Against the
@@ -755,6 +770,24 @@ def test_reverse_mode_jacobian_against_autograd(case):
     assert np.abs(got32 - want).max() < 2e-5 * scale, np.abs(got32 - want).max() / scale
     # translating every atom together changes nothing
     assert np.abs(got64.sum(axis=1)).max() < 1e-9 * scale
+
+
+@pytest.mark.parametrize("case, cutoff, fn, fe", [("tio2_notebook", 5.0, 64, 64), ("tio2_notebook", 5.0, 5, 14),
+                                                  ("triclinic20", 3.4, 40, 100), ("triclinic20", 3.0, 24, 20)])
+def test_reverse_mode_jacobian_on_other_graphs_and_widths(case, cutoff, fn, fe):
+    """The reverse pass where the fixtures do not go: 47 neighbours per atom (one-atom tiles in both EdgeBlock
+    kernels), and the unfused chain at padded widths 128 and 32.  float64 against autograd through the oracle,
+    float32 against float64."""
+    from oracle import potgnn_oracle as O
+    g = load_golden(case)
+    model, oracle = _random_model(g, cutoff, fn, fe, 1, seed=fn * 7 + fe)
+    pos = g["pos_batch"][0]
+    want = O.jacobian(oracle.to(torch.float64), pos)
+    got64 = model.alpha_jacobian(pos, float64=True)
+    scale = np.abs(want).max()
+    assert np.abs(got64 - want).max() < 1e-9 * scale, np.abs(got64 - want).max() / scale
+    got32 = model.alpha_jacobian(pos, float64=False)
+    assert np.abs(got32 - want).max() < 5e-5 * scale, np.abs(got32 - want).max() / scale
 
 
 def test_analytic_raman_tensors_match_finite_differences():
