@@ -978,6 +978,30 @@ def test_training_gradients_on_the_unfused_chain(fn, fe):
         assert np.abs(p.grad.numpy() - grads64[name]).max() < 2e-4 * scale, name
 
 
+@pytest.mark.parametrize("fn, fe", [(5, 14), (64, 64)])
+def test_training_gradients_with_six_message_passes(fn, fe):
+    """Six passes give 33 weight-gradient products per step, one more than the deferred-reduction table holds: the
+    table is flushed mid-pass and the partial-sum arena reused.  float32 device gradients against the float64 step."""
+    g = load_golden("triclinic20")
+    model, _ = _random_model(g, 3.0, fn, fe, 6, seed=fn + 600)
+    pos = g["pos_batch"][:4]
+    rng = np.random.default_rng(9)
+    targets = rng.normal(size=(4, 6))
+    out64, loss64, grads64 = model.train_gradients_f64(pos, targets)
+    model.train()
+    lat = torch.tensor(g["lattice"], dtype=torch.float32).expand(4, 3, 3)
+    zs = torch.tensor(model._ref_structure.atomic_numbers).expand(4, -1)
+    out = model.forward(lat, zs, torch.tensor(pos, dtype=torch.float32))
+    loss = torch.nn.MSELoss()(out, torch.tensor(targets, dtype=torch.float32))
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(loss64, rel=1e-4)
+    for name, p in model.named_parameters():
+        scale = np.abs(grads64[name]).max()
+        if scale < 1e-12:
+            continue
+        assert np.abs(p.grad.numpy() - grads64[name]).max() < 5e-4 * scale, name
+
+
 def _adam_run(model, optimizer, lat, zs, pos, targets, steps):
     losses = []
     model.train()
