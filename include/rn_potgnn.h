@@ -312,8 +312,10 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * requested but the range guard refused it (a non-finite weight, or readout hidden activations
  * that the weights allow beyond 3e4): the exact-f32 MFMA instantiations run instead.  Weight
  * matrices of any finite scale are fine: each is prescaled by a power of two into f16's range;
- * bit 5 = the fused EdgeBlock runs in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel;
- * opt-in with RN_POTGNN_EDGE2=1 at create time; the default is the per-frame form). */
+ * bit 7 = the library was built with -DRN_EXPERIMENTS=1 and carries the opt-in round-3 experiment kernels
+ * (csrc/experiments/); only then can bit 5 (RN_POTGNN_EDGE2=1 at create time: frame-pipelined EdgeBlock,
+ * edge_block2_kernel + edge_c2_kernel) or bit 6 (RN_POTGNN_EDGE3=1: twelve-wave EdgeBlock, edge_block3_kernel +
+ * edge_c2_kernel) be set.  The product build ignores those knobs. */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

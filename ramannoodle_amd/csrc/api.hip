@@ -805,10 +805,12 @@ struct ChunkRun {
       project(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, w.c3_nshift, 0, nullptr);
     }
     if constexpr (sizeof(T) == 4) {
+#if RN_EXPERIMENTS
       if (fused() && (h->use_edge2 || (h->use_edge3 && edge3_applicable(w, h->mfma_f16)))) {  // c2 branch of the EdgeBlock, one finished row per edge
         Timer t(h, st(), K_PROJ_C2);
         launch_edge_c2(node[nxt], c2, S, g, d, w, h->mfma_f16, st());
       }
+#endif
     }
     if (!fused()) {
       {
@@ -830,10 +832,12 @@ struct ChunkRun {
       Timer t(h, st(), K_EDGE_AGG);
       if constexpr (sizeof(T) == 4) {
         if (narrow()) launch_edge_narrow(edge[cur], edge[nxt], node[nxt], S, h->g, h->d, w, st());
+#if RN_EXPERIMENTS
         else if (fused() && h->use_edge3 && edge3_applicable(w, h->mfma_f16))
           launch_edge3(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, st());
         else if (fused() && h->use_edge2)
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
+#endif
         else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
@@ -1633,9 +1637,14 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   // fused EdgeBlock (kernels_fused.hip): its LDS footprint bounds the tile instead
   const bool want_fused = getenv("RN_POTGNN_FUSED") ? atoi(getenv("RN_POTGNN_FUSED")) != 0 : true;
   const bool fused_mode = want_fused && d.FnP == 64 && d.FeP == 64;
-  // RN_POTGNN_EDGE2=1: the frame-pipelined form of the fused EdgeBlock (edge_block2_kernel + edge_c2_kernel).
-  // Measured level with the per-frame form at Fn = Fe = 64 (profiles/r03/edge2_experiment.txt), so it stays opt-in.
+  // Experiment builds (-DRN_EXPERIMENTS=1) only -- RN_POTGNN_EDGE2=1: the frame-pipelined form of the fused EdgeBlock
+  // (edge_block2_kernel + edge_c2_kernel), measured level with the per-frame form (profiles/r03/edge2_experiment.txt).
+#if RN_EXPERIMENTS
   const bool want_edge2 = getenv("RN_POTGNN_EDGE2") ? atoi(getenv("RN_POTGNN_EDGE2")) != 0 : false;
+#else
+  const bool want_edge2 = false;
+  (void)want_edge2;
+#endif
   // narrow-width kernels (kernels_narrow.hip): one lane per destination edge, so a tile should bring
   // about one workgroup's worth (256) of destination edges and keep its LDS rows within ~40 KiB
   const bool want_narrow = getenv("RN_POTGNN_NARROW") ? atoi(getenv("RN_POTGNN_NARROW")) != 0 : true;
@@ -1665,8 +1674,12 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
         max_in = std::max(max_in, din);
         max_nodes = std::max(max_nodes, tb[t + 1] - tb[t]);
       }
-      const size_t lds = fused_mode ? (want_edge2 ? edge2_lds_bytes(mr, max_in, max_nodes)
-                                                  : edge_fused_lds_bytes(mr, max_in, max_nodes))
+#if RN_EXPERIMENTS
+      const size_t fused_lds_need = want_edge2 ? edge2_lds_bytes(mr, max_in, max_nodes) : edge_fused_lds_bytes(mr, max_in, max_nodes);
+#else
+      const size_t fused_lds_need = edge_fused_lds_bytes(mr, max_in, max_nodes);
+#endif
+      const size_t lds = fused_mode ? fused_lds_need
                                     : (size_t)mr * (row_bytes + 4) + (size_t)max_nodes * row_bytes +
                                           (size_t)12 * d.FeP * 4 + (size_t)mr * 4 + (size_t)max_in * 24 + 96;
       // unfused: two aggregation workgroups + one projection workgroup (34 KiB) share a CU
@@ -1682,8 +1695,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   }
   // node tiles of the twelve-wave EdgeBlock (edge_block3_kernel): one 768-thread workgroup per CU with the CU's LDS,
   // 48 destinations per round -> as few rounds as possible in total; among equals the larger tiles (fewer per-tile phases)
-  const bool want_edge3 = getenv("RN_POTGNN_EDGE3") ? atoi(getenv("RN_POTGNN_EDGE3")) != 0 : false;
   int et_max_rows = 0, et_max_in = 0, et_max_nodes = 0;
+#if RN_EXPERIMENTS
+  const bool want_edge3 = getenv("RN_POTGNN_EDGE3") ? atoi(getenv("RN_POTGNN_EDGE3")) != 0 : false;
   if (fused_mode && want_edge3) {
     double best = 0;
     std::vector<int> tb;
@@ -1711,6 +1725,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       }
     }
   }
+#else
+  const bool want_edge3 = false;
+#endif
   // node tiles of the EdgeBlock reverse kernel: the largest whose float32 LDS footprint leaves room for two workgroups
   // per CU (RN_POTGNN_BWD_TILES=0: the forward kernel's tiles, one 512-thread workgroup per CU)
   int bt_max_rows = 0, bt_max_in = 0, bt_max_nodes = 0;
@@ -1780,7 +1797,11 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   }
   if (!nt_narrow) {
     double best = 0;
+#if RN_EXPERIMENTS
     const bool node_wave = node_fused_wave_tiles() && d.FnP == 64 && d.FeP == 64;
+#else
+    const bool node_wave = false;
+#endif
     const int forced = getenv("RN_POTGNN_NODE_TILE_ROWS") ? atoi(getenv("RN_POTGNN_NODE_TILE_ROWS")) : 0;  // experiment knob
     for (int budget = forced > 0 ? forced : 16; budget <= (forced > 0 ? forced : 256); budget += 8) {
       std::vector<int> tb(1, 0);
@@ -1802,7 +1823,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       if (node_wave) {
         // wave-autonomous kernel: a workgroup's four waves take the tile's 16-row pieces four at a time;
         // two workgroups per CU (register-bound), so up to 72 KiB of LDS each
+#if RN_EXPERIMENTS
         if (node_wave_lds_bytes(max_in, max_nodes) > (size_t)72 * 1024 && !h->nt_begin.empty()) break;
+#endif
         cost = 0;
         for (size_t t = 0; t + 1 < tb.size(); ++t) {
           const int rows_t = h->in_ptr[tb[t + 1]] - h->in_ptr[tb[t]];
@@ -1904,9 +1927,15 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     refresh_mfma_mode(hp);
     // The fused kernels (kernels_fused.hip) are the default where they apply (float32, Fn and
     // Fe padded to 64); RN_POTGNN_FUSED=0 selects projections + edge_agg_kernel.
+#if RN_EXPERIMENTS
     hp->use_edge2 = want_fused && want_edge2 && edge2_supported(hp->g, hp->d);
+#endif
     hp->use_fused = hp->use_edge2 || (want_fused && edge_fused_supported(hp->g, hp->d));
+#if RN_EXPERIMENTS
     hp->use_edge3 = hp->use_fused && !hp->use_edge2 && want_edge3 && edge3_supported(hp->g, hp->d);
+#else
+    (void)want_edge3;
+#endif
     hp->split_projections = getenv("RN_POTGNN_SPLIT_PROJ") ? atoi(getenv("RN_POTGNN_SPLIT_PROJ")) != 0 : true;
     hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
@@ -2449,7 +2478,7 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
-              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0) | (h->use_edge3 ? 64 : 0);
+              ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0) | (h->use_edge3 ? 64 : 0) | (RN_EXPERIMENTS ? 128 : 0);
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);

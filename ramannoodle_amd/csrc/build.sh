@@ -11,11 +11,17 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function ${R
 bdir="build${tag:+_$tag}"
 mkdir -p "$here/$bdir"
 pids=()
-for f in api kernels_agg kernels_gemm kernels_fused kernels_narrow kernels_bwd kernels_train spectrum; do
-  if [ ! -f "$here/$bdir/$f.o" ] || [ "$here/$f.hip" -nt "$here/$bdir/$f.o" ] || \
-     [ "$here/kernels.hpp" -nt "$here/$bdir/$f.o" ] || [ "$here/device_utils.hpp" -nt "$here/$bdir/$f.o" ] || \
-     [ "$here/../../include/rn_potgnn.h" -nt "$here/$bdir/$f.o" ]; then
-    $HIPCC $FLAGS -c "$here/$f.hip" -o "$here/$bdir/$f.o" &
+# RN_EXTRA_FLAGS=-DRN_EXPERIMENTS=1 adds the opt-in round-3 experiment kernels (experiments/); the product build has none.
+hip_srcs="api kernels_agg kernels_gemm kernels_fused kernels_edge_ps kernels_narrow kernels_bwd kernels_train spectrum"
+case " ${RN_EXTRA_FLAGS:-} " in *" -DRN_EXPERIMENTS=1 "*) hip_srcs="$hip_srcs experiments/kernels_fused_experiments";; esac
+objs=()
+for f in $hip_srcs; do
+  o="$here/$bdir/$(basename "$f").o"
+  objs+=("$o")
+  if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/fused_common.hpp" -nt "$o" ] || \
+     [ "$here/kernels.hpp" -nt "$o" ] || [ "$here/device_utils.hpp" -nt "$o" ] || \
+     [ "$here/../../include/rn_potgnn.h" -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$here/$f.hip" -o "$o" &
     pids+=($!)
   fi
 done
@@ -28,5 +34,5 @@ for f in ingest ingest_vasprun; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "$here/$bdir/api.o" "$here/$bdir/kernels_agg.o" "$here/$bdir/kernels_gemm.o" "$here/$bdir/kernels_fused.o" "$here/$bdir/kernels_narrow.o" "$here/$bdir/kernels_bwd.o" "$here/$bdir/kernels_train.o" "$here/$bdir/spectrum.o" "$here/$bdir/ingest.o" "$here/$bdir/ingest_vasprun.o" -lpthread -ldl
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "${objs[@]}" "$here/$bdir/ingest.o" "$here/$bdir/ingest_vasprun.o" -lpthread -ldl
 echo "built $out"

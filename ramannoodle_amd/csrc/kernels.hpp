@@ -236,22 +236,9 @@ void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *l
 // Fused EdgeBlock (kernels_fused.hip): float32, FnP == FeP == 64.  Two workgroups per CU
 // need their LDS footprint within this budget.
 constexpr size_t kFusedLdsBudget = 80 * 1024;
-// Twelve-wave EdgeBlock (edge_block3_kernel + edge_c2_kernel): ONE 768-thread workgroup per CU with the CU's LDS.
-#ifndef RN_E3_WAVES
-#define RN_E3_WAVES 12
-#endif
-constexpr size_t kEdge3LdsBudget = RN_E3_WAVES <= 4 ? 54272 : (RN_E3_WAVES <= 6 ? 80 : 158) * 1024;
-size_t edge3_lds_bytes(int rows, int in_rows, int nodes);
-inline int edge3_dests_per_round() { return 4 * RN_E3_WAVES; }
-bool edge3_supported(const Graph &g, Dims d);
-bool edge3_applicable(const PassW<float> &w, bool f16);
-void launch_edge3(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
-                  const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);
 size_t edge_fused_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
 bool edge_fused_supported(const Graph &g, Dims d);
 size_t node_fused_lds_bytes(const Graph &g);
-bool node_fused_wave_tiles();  // the split-f16 NodeBlock runs wave-autonomous: 16-row tiles, four per workgroup step
-size_t node_wave_lds_bytes(int tile_in_rows, int tile_nodes);
 size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes);
 // `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
@@ -263,6 +250,25 @@ void launch_edge_fused(const float *edge_in, float *edge_out, const float *node,
                        float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
                        hipStream_t st);
 
+// Opt-in experiment kernels (experiments/kernels_fused_experiments.hip): compiled and reachable only with
+// -DRN_EXPERIMENTS=1; the product build has neither the kernels nor the RN_POTGNN_EDGE2 / EDGE3 / NODE_WAVE knobs.
+#ifndef RN_EXPERIMENTS
+#define RN_EXPERIMENTS 0
+#endif
+#if RN_EXPERIMENTS
+// Twelve-wave EdgeBlock (edge_block3_kernel + edge_c2_kernel): ONE 768-thread workgroup per CU with the CU's LDS.
+#ifndef RN_E3_WAVES
+#define RN_E3_WAVES 12
+#endif
+constexpr size_t kEdge3LdsBudget = RN_E3_WAVES <= 4 ? 54272 : (RN_E3_WAVES <= 6 ? 80 : 158) * 1024;
+size_t edge3_lds_bytes(int rows, int in_rows, int nodes);
+inline int edge3_dests_per_round() { return 4 * RN_E3_WAVES; }
+bool edge3_supported(const Graph &g, Dims d);
+bool edge3_applicable(const PassW<float> &w, bool f16);
+void launch_edge3(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
+                  const Graph &g, Dims d, const PassW<float> &w, hipStream_t st);
+bool node_fused_wave_tiles();  // the split-f16 NodeBlock runs wave-autonomous: 16-row tiles, four per workgroup step
+size_t node_wave_lds_bytes(int tile_in_rows, int tile_nodes);
 // Frame-pipelined EdgeBlock (kernels_fused.hip: edge_block2_kernel) and the c2 branch as its own
 // streaming kernel: float32, FnP == FeP == 64, same LDS budget for two workgroups per CU.
 size_t edge2_lds_bytes(int tile_out_rows, int tile_in_rows, int tile_nodes);
@@ -272,6 +278,7 @@ void launch_edge_c2(const float *node, float *c2, int S, const Graph &g, Dims d,
                     hipStream_t st);
 void launch_edge2(const float *edge_in, float *edge_out, const float *np3, const float *c2, float *agg_out, int S,
                   const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
+#endif  // RN_EXPERIMENTS
 
 // Device-resident optimisation step (kernels_train.hip); offsets index the packed weight blob.
 struct DerivedOp {

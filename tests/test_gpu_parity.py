@@ -685,7 +685,8 @@ def test_every_width_up_to_16_takes_the_narrow_kernels(fn, fe):
 @pytest.mark.parametrize("knob, flag", [("RN_POTGNN_EDGE2", "pipelined_edge_block"), ("RN_POTGNN_EDGE3", "twelve_wave_edge_block")])
 @pytest.mark.parametrize("case, cutoff, fn, fe, frames", [("triclinic20", 3.4, 64, 64, 5), ("rocksalt64_parity", 3.2, 50, 40, 9)])
 def test_opt_in_edge_block_kernels_against_oracle(monkeypatch, knob, flag, case, cutoff, fn, fe, frames):
-    """The two restructured forms of the fused EdgeBlock that stay in the tree as measured alternatives
+    """Experiment builds only (csrc/experiments/, -DRN_EXPERIMENTS=1; skipped on the product library).
+    The two restructured forms of the fused EdgeBlock that stay in the tree as measured alternatives
     (frame-pipelined: profiles/r03/edge2_experiment.txt; twelve waves with the c2 branch in its own kernel:
     profiles/r03/edge3_experiment.txt) compute the same thing as the default kernel: ragged and regular graph,
     full and padded widths, several frames per workgroup."""
@@ -697,6 +698,8 @@ def test_opt_in_edge_block_kernels_against_oracle(monkeypatch, knob, flag, case,
     base = g["pos_batch"]
     pos = base[rng.integers(0, len(base), size=frames)] + rng.normal(scale=2e-3, size=(frames,) + base.shape[1:])
     got = model.calc_polarizabilities(pos)
+    if not model.config_flags()["experiment_kernels"]:
+        pytest.skip("product build: the experiment kernels need RN_EXTRA_FLAGS=-DRN_EXPERIMENTS=1 (csrc/build.sh)")
     assert model.config_flags()[flag]
     want = O.calc_polarizabilities(oracle, pos, faithful=False)
     assert _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL, (knob, case)
