@@ -99,6 +99,9 @@ struct PackedLayout {
     size_t c3n1_gs, c3n1_bs;  // c3_norm_1 with the gate's exp2 scale folded in (-log2e | 2 log2e): narrow kernels
     size_t mfma_scale;        // [8] split-f16 prescales (s, 1/s): c1_WeT | W4 | W5 | c2_WT (kernels.hpp: mfma_prescale)
     size_t t_c3We, t_c3Wn, t_c2W, t_c1We, t_c1Wn;  // transposed copies [N][K] (reverse pass)
+    // copies of c3_linear / c2_linear centred over their real output columns (kernels_edge_ps.hip) and the
+    // split-f16 prescales (s, 1/s) of W4 | W5 | c2 in that form
+    size_t c3_WeT_c, c3_WnT_c, c3_nshift_c, c2_WT_c, c2_bias_c, mfma_scale_c;
   };
   std::vector<Pass> pass;
   size_t W0T, W3T, b3, W5T, b5, ones, b0p, t_W0, t_W3, t_W5;
@@ -155,11 +158,12 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin, bt_begin;
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin, bt_begin, pt_begin;
   bool use_fused = false;
   bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
   bool split_projections = true;  // RN_POTGNN_SPLIT_PROJ=0: the forward's stand-alone projections on the exact-f32 MFMA kernel
   bool use_edge3 = false;  // fused EdgeBlock on twelve waves, one workgroup per CU (edge_block3_kernel + edge_c2_kernel)
+  bool use_ps = false;     // role-specialised fused EdgeBlock (kernels_edge_ps.hip) on its own atom tiles (Graph::pt_*)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
@@ -168,6 +172,7 @@ struct rn_potgnn {
   bool mfma_range_fallback = false; // split-f16 was requested but the range guard (mfma_f16_range_ok) refused it
   Graph g{};
   DeviceBuf g_ints;
+  DeviceBuf ps_fail;  // [1] int: set by edge_block_ps_kernel when one of its bounded waits ran out
   double lattice[9], mean[9], stdv[9];
   DeviceBuf d_mean_std;  // [18] double
   std::vector<float> packed;  // host packed weights (float master copy)
@@ -194,7 +199,7 @@ struct rn_potgnn {
   bool grads_on_device = false;  // f32.grad holds the gradients of the last backward
   bool host_stale = false;       // the device weights are ahead of `packed`
   DeviceBuf adam_m, adam_v, trainable_mask, derived_ops;
-  int num_derived_ops = 0;
+  int num_derived_ops = 0, derived_first_stage = 0;  // (ops after the first stage read what it wrote: second launch)
   double bn_count = 0;  // rows the pending step's BatchNorm statistics cover (all ranks)
   rn_potgnn_reduce_fn reducer = nullptr;  // data-parallel training: sums doubles over ranks
   void *reducer_ctx = nullptr;
@@ -253,6 +258,37 @@ std::vector<MfmaScaleOp> mfma_scale_ops(const rn_potgnn *h) {
   return ops;
 }
 
+// The centred copies: (source, destination, rows, columns) of every matrix / bias vector whose output columns feed a
+// LayerNorm over a [filter | core] row in the role-specialised EdgeBlock.  LayerNorm(x) = LayerNorm(x - mean x), and
+// the row mean of a Linear's output is itself linear in the input, so subtracting from every weight row (and from
+// the bias) its mean over the real output columns makes the projections come out with zero row mean.
+struct CentreOp {
+  size_t src, dst;
+  int K, N;
+};
+std::vector<CentreOp> centre_ops(const rn_potgnn *h) {
+  const int FnP = h->d.FnP, FeP = h->d.FeP;
+  std::vector<CentreOp> ops;
+  for (const auto &q : h->lay.pass) {
+    ops.push_back({q.c3_WeT, q.c3_WeT_c, FeP, 4 * FeP});
+    ops.push_back({q.c3_WnT, q.c3_WnT_c, FnP, 6 * FeP});
+    ops.push_back({q.c3_nshift, q.c3_nshift_c, 1, 6 * FeP});
+    ops.push_back({q.c2_WT, q.c2_WT_c, FnP, 2 * FeP});
+    ops.push_back({q.c2_bias, q.c2_bias_c, 1, 2 * FeP});
+  }
+  return ops;
+}
+std::vector<MfmaScaleOp> centred_scale_ops(const rn_potgnn *h) {
+  const int FnP = h->d.FnP, FeP = h->d.FeP;
+  std::vector<MfmaScaleOp> ops;
+  for (const auto &q : h->lay.pass) {
+    ops.push_back({q.c3_WeT_c, FeP, 2 * FeP, 4 * FeP, q.mfma_scale_c});
+    ops.push_back({q.c3_WeT_c + 2 * FeP, FeP, 2 * FeP, 4 * FeP, q.mfma_scale_c + 2});
+    ops.push_back({q.c2_WT_c, FnP, 2 * FeP, 2 * FeP, q.mfma_scale_c + 4});
+  }
+  return ops;
+}
+
 void pack_weights(rn_potgnn *h, const float *w) {
   const int K = h->cfg.num_atom_types, Fn = h->d.Fn, Fe = h->d.Fe, FnP = h->d.FnP,
             FeP = h->d.FeP, P = h->cfg.num_message_passes;
@@ -294,6 +330,12 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.t_c2W = L.take((size_t)2 * FeP * FnP);
     p.t_c1We = L.take((size_t)2 * FnP * FeP);
     p.t_c1Wn = L.take((size_t)2 * FnP * FnP);
+    p.c3_WeT_c = L.take((size_t)FeP * 4 * FeP);
+    p.c3_WnT_c = L.take((size_t)FnP * 6 * FeP);
+    p.c3_nshift_c = L.take(6 * FeP);
+    p.c2_WT_c = L.take((size_t)FnP * 2 * FeP);
+    p.c2_bias_c = L.take(2 * FeP);
+    p.mfma_scale_c = L.take(8);
   }
   const int HP = std::max(FeP, 32);  // readout hidden width: projections emit 32-column tiles
   L.W0T = L.take((size_t)FeP * HP);
@@ -417,6 +459,28 @@ void pack_weights(rn_potgnn *h, const float *w) {
   }
   for (int i = 0; i < HP; ++i) o[L.ones + i] = 1.0f;
   for (const MfmaScaleOp &m : mfma_scale_ops(h)) {  // power-of-two prescales of the split-f16 products
+    float mx = 0.0f;
+    for (int k = 0; k < m.K; ++k)
+      for (int n = 0; n < m.N; ++n) mx = std::max(mx, std::fabs(o[m.src + (size_t)k * m.ld + n]));
+    const float sc = mfma_prescale(mx);
+    o[m.dst] = sc;
+    o[m.dst + 1] = 1.0f / sc;
+  }
+  for (const CentreOp &c : centre_ops(h)) {  // row-centred copies (float64 means; padded columns stay zero)
+    const int bw = 2 * FeP;
+    for (int k = 0; k < c.K; ++k)
+      for (int b = 0; b < c.N / bw; ++b) {
+        const size_t base = (size_t)k * c.N + (size_t)b * bw;
+        double sum = 0;
+        for (int hh = 0; hh < 2; ++hh)
+          for (int col = 0; col < Fe; ++col) sum += (double)o[c.src + base + hh * FeP + col];
+        const double mean = sum / (2.0 * Fe);
+        for (int hh = 0; hh < 2; ++hh)
+          for (int col = 0; col < FeP; ++col)
+            o[c.dst + base + hh * FeP + col] = col < Fe ? (float)((double)o[c.src + base + hh * FeP + col] - mean) : 0.0f;
+      }
+  }
+  for (const MfmaScaleOp &m : centred_scale_ops(h)) {
     float mx = 0.0f;
     for (int k = 0; k < m.K; ++k)
       for (int n = 0; n < m.N; ++n) mx = std::max(mx, std::fabs(o[m.src + (size_t)k * m.ld + n]));
@@ -599,6 +663,12 @@ void ensure_precision(rn_potgnn *h) {
     o.c3_norm_2 = {w + q.c3n2_g, w + q.c3n2_b};
     o.c3_norm_1s = {w + q.c3n1_gs, w + q.c3n1_bs};
     o.mfma_scale = w + q.mfma_scale;
+    o.c3_WeT_c = w + q.c3_WeT_c;
+    o.c3_WnT_c = w + q.c3_WnT_c;
+    o.c3_nshift_c = w + q.c3_nshift_c;
+    o.c2_WT_c = w + q.c2_WT_c;
+    o.c2_bias_c = w + q.c2_bias_c;
+    o.mfma_scale_c = w + q.mfma_scale_c;
   }
   refresh_pass_flags<T>(h);
   P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5, w + L.ro_mfma_scale};
@@ -802,7 +872,8 @@ struct ChunkRun {
     }
     {  // EdgeBlock uses the UPDATED node embedding (_gnn.py:649-650)
       Timer t(h, st(), K_PROJ_NODE);
-      project(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, w.c3_nshift, 0, nullptr);
+      if (role_split(w)) project(node[nxt], MN, d.FnP, w.c3_WnT_c, 6 * d.FeP, np3, w.c3_nshift_c, 0, nullptr);  // zero row mean
+      else project(node[nxt], MN, d.FnP, w.c3_WnT, 6 * d.FeP, np3, w.c3_nshift, 0, nullptr);
     }
     if constexpr (sizeof(T) == 4) {
 #if RN_EXPERIMENTS
@@ -838,6 +909,7 @@ struct ChunkRun {
         else if (fused() && h->use_edge2)
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
 #endif
+        else if (role_split(w)) launch_edge_ps(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->ps_fail.as<int>(), st());
         else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
@@ -892,6 +964,10 @@ struct ChunkRun {
   //  array the reverse pass needs; RN_POTGNN_TAPE_FUSED=0 keeps those runs on the unfused kernels)
   bool fused() const { return sizeof(T) == 4 && h->use_fused && (!prec<T>(h).tape_on || h->tape_fused); }
   bool narrow() const { return sizeof(T) == 4 && h->use_narrow && !prec<T>(h).tape_on; }
+  // the role-specialised EdgeBlock (kernels_edge_ps.hip): split-f16 products and the folded gate scale only, evaluation runs
+  bool role_split(const PassW<T> &w) const {
+    return sizeof(T) == 4 && fused() && h->use_ps && h->mfma_f16 && (w.c3_fast & 1) != 0 && !prec<T>(h).tape_on;
+  }
   T *tape_agg(int p) {  // where the EdgeBlock's pre-LayerNorm sums are recorded (taped runs only)
     Precision<T> &P = prec<T>(h);
     return P.tape_on ? P.tape_agg[p].template as<T>() : nullptr;
@@ -985,6 +1061,26 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
   if (sync) {
     HIP_TRY(hipStreamSynchronize(user));
     resolve_timers(h);
+    if (h->use_ps) {  // the role-specialised EdgeBlock bounds its spin waits and reports here instead of hanging the GPU
+      int fail = 0;
+      HIP_TRY(hipMemcpy(&fail, h->ps_fail.p, sizeof(int), hipMemcpyDeviceToHost));
+#ifdef RN_PS_TIMING
+      {
+        long long t[32];
+        HIP_TRY(hipMemcpy(t, (const char *)h->ps_fail.p + 64, sizeof(t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset((char *)h->ps_fail.p + 64, 0, sizeof(t)));
+        static const char *names[16] = {"P sched+dma_wait", "P loads+split", "P split sync", "P seeds", "P request", "P guard",
+                                        "P P'+c2", "P Q'", "P norm sync+publish", "", "C ready wait", "C prologue", "C loop",
+                                        "C epilogue+done", "", ""};
+        for (int i = 0; i < 16; ++i)
+          if (t[2 * i + 1]) fprintf(stderr, "[ps timing] %-22s %10.1f cycles x %lld\n", names[i], (double)t[2 * i] / (double)t[2 * i + 1], t[2 * i + 1]);
+      }
+#endif
+      if (fail != 0) {
+        HIP_TRY(hipMemset(h->ps_fail.p, 0, sizeof(int)));
+        throw HipError{hipErrorLaunchFailure, "role-specialised EdgeBlock: a wait between producer and consumer waves timed out"};
+      }
+    }
   }
 }
 
@@ -1231,7 +1327,7 @@ void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*
 // ---- device-resident optimisation step: which entries of the packed blob are parameters, which are
 // functions of parameters (and how to recompute them on the device)
 
-std::vector<DerivedOp> derived_ops(const rn_potgnn *h) {
+std::vector<DerivedOp> derived_ops(const rn_potgnn *h, int *first_stage = nullptr) {
   const PackedLayout &L = h->lay;
   const int FnP = h->d.FnP, FeP = h->d.FeP, Fe = h->d.Fe, HP = std::max(FeP, 32);
   std::vector<DerivedOp> ops;
@@ -1253,6 +1349,10 @@ std::vector<DerivedOp> derived_ops(const rn_potgnn *h) {
   transpose(L.W5T, HP, 32, L.t_W5);
   scaled(L.b0p, Fe, 1.0f, L.b0);  // the bias of readout Linear 0 lives twice (eval fold / training forward)
   for (const MfmaScaleOp &m : mfma_scale_ops(h)) ops.push_back({2, m.K, m.N, (float)m.ld, m.src, m.dst});
+  for (const CentreOp &c : centre_ops(h)) ops.push_back({3, c.K, c.N, 1.0f, c.src, c.dst, Fe, FeP});
+  if (first_stage) *first_stage = (int)ops.size();
+  // second launch: the prescales of the centred copies read what the first launch wrote
+  for (const MfmaScaleOp &m : centred_scale_ops(h)) ops.push_back({2, m.K, m.N, (float)m.ld, m.src, m.dst});
   return ops;
 }
 
@@ -1269,7 +1369,7 @@ std::vector<unsigned char> trainable_mask(rn_potgnn *h) {
   const int HP = std::max(h->d.FeP, 32);
   auto clear = [&](size_t o, size_t n) { std::fill(mask.begin() + o, mask.begin() + o + n, (unsigned char)0); };
   for (const DerivedOp &op : derived_ops(h))
-    clear(op.dst, op.kind == 2 ? 2 : (size_t)op.K * (op.kind == 0 ? op.N : 1));
+    clear(op.dst, op.kind == 2 ? 2 : (size_t)op.K * ((op.kind == 0 || op.kind == 3) ? op.N : 1));
   clear(L.ones, HP);
   clear(L.offsets, h->d.FeP);  // buffers of the state dict: Gaussian offsets, BatchNorm running statistics
   clear(L.bn_rm, h->d.Fe);
@@ -1865,6 +1965,52 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     HIP_TRY(hipEventCreateWithFlags(&hp->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&hp->ev_g[0], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&hp->ev_g[1], hipEventDisableTiming));
+    // node tiles of the role-specialised EdgeBlock (kernels_edge_ps.hip): ONE twelve-wave workgroup per CU, 16 destinations
+    // per round.  A launch runs floor(CUs / tiles) frame groups side by side, so the cost of a partition is (rounds of its
+    // slowest tile) / (frame groups); a partition is admissible when every tile passes the producers' schedule check and
+    // the kernel's LDS footprint fits the CU.
+    int pt_max_rows = 0, pt_max_in = 0;
+    const bool want_ps = getenv("RN_POTGNN_EDGE_PS") ? atoi(getenv("RN_POTGNN_EDGE_PS")) != 0 : true;
+    if (fused_mode && want_ps) {
+      int cus = 256;
+      {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+      }
+      double best = 0;
+      std::vector<int> tb, rb, re;
+      const int forced = getenv("RN_POTGNN_PS_TILE_ROWS") ? atoi(getenv("RN_POTGNN_PS_TILE_ROWS")) : 0;  // experiment knob
+      for (size_t budget = forced > 0 ? forced : 8; budget <= (size_t)(forced > 0 ? forced : 1024); budget += 2) {
+        const int mr = build_tiles(budget, tb);
+        const int ntiles = (int)tb.size() - 1;
+        int max_in = 0, max_rounds = 1;
+        bool ok = true;
+        for (int t = 0; t < ntiles && ok; ++t) {
+          const int eo0 = hp->out_ptr[tb[t]];
+          rb.clear();
+          re.clear();
+          for (int i = hp->in_ptr[tb[t]]; i < hp->in_ptr[tb[t + 1]]; ++i) {
+            const int bd = edge_b[hp->in_edge[i]];
+            rb.push_back(hp->out_ptr[bd] - eo0);
+            re.push_back(hp->out_ptr[bd + 1] - eo0);
+          }
+          const int din = (int)rb.size();
+          max_in = std::max(max_in, din);
+          max_rounds = std::max(max_rounds, (din + 15) / 16);
+          ok = edge_ps_tile_ok(rb.data(), re.data(), din);
+        }
+        if (!ok || edge_ps_lds_bytes(mr, max_in) > (size_t)160 * 1024) continue;
+        const double groups = ntiles <= cus ? (double)(cus / ntiles) : 1.0 / (double)((ntiles + cus - 1) / cus);
+        const double cost = (double)max_rounds / groups;
+        if (hp->pt_begin.empty() || cost < best * 0.999) {
+          best = cost;
+          hp->pt_begin = tb;
+          pt_max_rows = mr;
+          pt_max_in = max_in;
+        }
+        if (mr >= E) break;  // one tile holds everything: larger budgets change nothing
+      }
+    }
     // upload all int arrays in one allocation
     std::vector<int> ints;
     auto push = [&](const std::vector<int> &v) {
@@ -1876,7 +2022,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
                  o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge),
-                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin), o_bt = push(hp->bt_begin);
+                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin), o_bt = push(hp->bt_begin), o_pt = push(hp->pt_begin);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -1912,6 +2058,10 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.et_max_out_rows = et_max_rows;
     g.et_max_in_rows = et_max_in;
     g.et_max_nodes = et_max_nodes;
+    g.pt_num = hp->pt_begin.empty() ? 0 : (int)hp->pt_begin.size() - 1;
+    g.pt_begin = base + o_pt;
+    g.pt_max_out_rows = pt_max_rows;
+    g.pt_max_in_rows = pt_max_in;
     g.bt_num = hp->bt_begin.empty() ? 0 : (int)hp->bt_begin.size() - 1;
     g.bt_begin = base + o_bt;
     g.bt_max_out_rows = bt_max_rows;
@@ -1936,6 +2086,9 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
 #else
     (void)want_edge3;
 #endif
+    hp->use_ps = hp->use_fused && !hp->use_edge2 && !hp->use_edge3 && hp->g.pt_num > 0;
+    hp->ps_fail.ensure(1024);  // [0] the failure word; timing builds (RN_PS_TIMING) keep their cycle counters from byte 64 on
+    HIP_TRY(hipMemset(hp->ps_fail.p, 0, 1024));
     hp->split_projections = getenv("RN_POTGNN_SPLIT_PROJ") ? atoi(getenv("RN_POTGNN_SPLIT_PROJ")) != 0 : true;
     hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
@@ -2385,7 +2538,7 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
       const std::vector<unsigned char> mask = trainable_mask(h);
       h->trainable_mask.ensure(mask.size());
       HIP_TRY(hipMemcpy(h->trainable_mask.p, mask.data(), mask.size(), hipMemcpyHostToDevice));
-      const std::vector<DerivedOp> ops = derived_ops(h);
+      const std::vector<DerivedOp> ops = derived_ops(h, &h->derived_first_stage);
       h->derived_ops.ensure(ops.size() * sizeof(DerivedOp));
       HIP_TRY(hipMemcpy(h->derived_ops.p, ops.data(), ops.size() * sizeof(DerivedOp), hipMemcpyHostToDevice));
       h->num_derived_ops = (int)ops.size();
@@ -2393,7 +2546,8 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
     float *w = P.weights.as<float>();
     launch_adam(w, P.grad.as<float>(), h->adam_m.as<float>(), h->adam_v.as<float>(),
                 h->trainable_mask.as<unsigned char>(), n, lr, beta1, beta2, eps, weight_decay, step, st);
-    launch_refresh_derived(w, h->derived_ops.as<DerivedOp>(), h->num_derived_ops, st);
+    launch_refresh_derived(w, h->derived_ops.as<DerivedOp>(), h->derived_first_stage, st);
+    launch_refresh_derived(w, h->derived_ops.as<DerivedOp>() + h->derived_first_stage, h->num_derived_ops - h->derived_first_stage, st);
     launch_setup<float>(w + L.emb, w + L.W2, w + L.b2, w + L.W4, w + L.b4, h->cfg.num_atom_types, h->d,
                         w + L.node_table, w + L.b0, w + L.bn_w, w + L.bn_b, w + L.bn_rm, w + L.bn_rv,
                         w + L.scale0, w + L.shift0, st);
@@ -2479,6 +2633,11 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
               ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0) | (h->use_edge3 ? 64 : 0) | (RN_EXPERIMENTS ? 128 : 0);
+  {  // bit 8: every pass of a float32 evaluation takes the role-specialised EdgeBlock (kernels_edge_ps.hip)
+    bool ps = h->use_fused && h->use_ps && h->mfma_f16 && !h->f32.pass.empty();
+    for (const auto &p : h->f32.pass) ps = ps && (p.c3_fast & 1);
+    flags |= ps ? 256 : 0;
+  }
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));
   return flags | (fast ? 2 : 0);

@@ -33,6 +33,10 @@ struct Graph {
   int et_num;
   const int *et_begin;    // [et_num+1] node ranges
   int et_max_out_rows, et_max_in_rows, et_max_nodes;
+  // node tiles of the role-specialised EdgeBlock (kernels_edge_ps.hip: one twelve-wave workgroup per CU, 16 destinations a round)
+  int pt_num;
+  const int *pt_begin;    // [pt_num+1] node ranges
+  int pt_max_out_rows, pt_max_in_rows;
   // node tiles of the EdgeBlock reverse kernel (edge_bwd_tile2_kernel): small enough for TWO workgroups per CU
   int bt_num;
   const int *bt_begin;    // [bt_num+1] node ranges
@@ -66,6 +70,14 @@ struct PassW {
   Ln<T> c3_norm_2;   // [FeP]
   Ln<T> c3_norm_1s;  // [2FeP] c3_norm_1 times the gate's exp2 scales (-log2e on the filter half, 2 log2e on the core half)
   const T *mfma_scale;  // [8] split-f16 prescales (s, 1/s) of c1_WeT | c3_WeT[:, W4] | c3_WeT[:, W5] | c2_WT (mfma_prescale)
+  // c3_linear / c2_linear centred over their real output columns (LayerNorm(x) = LayerNorm(x - mean x), and the
+  // mean is linear in the inputs): projections with these come out with zero row mean (kernels_edge_ps.hip)
+  const T *c3_WeT_c;    // [FeP][4FeP]
+  const T *c3_WnT_c;    // [FnP][6FeP]
+  const T *c3_nshift_c; // [6FeP]
+  const T *c2_WT_c;     // [FnP][2FeP]
+  const T *c2_bias_c;   // [2FeP]
+  const T *mfma_scale_c;  // [6] split-f16 prescales (s, 1/s) of c3_WeT_c[:, W4] | c3_WeT_c[:, W5] | c2_WT_c
   int c3_fast;       // host-side decision: c3_norm_1 admits the folded-scale triplet loop
                      // (bit 0: in the fused EdgeBlock kernel, bit 1: in edge_agg_kernel)
 };
@@ -250,6 +262,15 @@ void launch_edge_fused(const float *edge_in, float *edge_out, const float *node,
                        float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
                        hipStream_t st);
 
+// Role-specialised fused EdgeBlock (kernels_edge_ps.hip): float32, FnP == FeP == 64, split-f16 products, folded gate
+// scale; needs the centred weight copies of PassW and np3 projected with c3_WnT_c / c3_nshift_c.
+size_t edge_ps_lds_bytes(int tile_out_rows, int tile_in_rows);
+// one tile's destinations (first and end source row of each, sorted by atom): does the producers' schedule hold?
+bool edge_ps_tile_ok(const int *rb, const int *re, int D);
+// `fail`: device int, set to a nonzero code if a bounded spin wait inside the kernel ran out (never in a correct run)
+void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
+                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st);
+
 // Opt-in experiment kernels (experiments/kernels_fused_experiments.hip): compiled and reachable only with
 // -DRN_EXPERIMENTS=1; the product build has neither the kernels nor the RN_POTGNN_EDGE2 / EDGE3 / NODE_WAVE knobs.
 #ifndef RN_EXPERIMENTS
@@ -284,10 +305,15 @@ void launch_edge2(const float *edge_in, float *edge_out, const float *np3, const
 struct DerivedOp {
   int kind;        // 0: transposed copy of a [K][N] block, 1: scaled copy of K values,
                    // 2: dst[0..1] = (s, 1/s), s = mfma_prescale(max |src[k * ld + n]|), ld = (int)scale
+                   // 3: dst[k][n] = src[k][n] - mean over the REAL columns of n's [filter | core] block (2 FeP wide, the
+                   //    first Fe of each half real; padded columns stay 0), rows of N = ld columns: the centred copies
+                   //    of c3_linear / c2_linear (kernels_edge_ps.hip)
   int K, N;
   float scale;
   size_t src, dst;
+  int Fe = 0, FeP = 0;  // kind 3
 };
+// (kind 2 entries that read a kind 3 result go into a second launch: blocks of one launch run concurrently)
 void launch_adam(float *w, const float *g, float *m, float *v, const unsigned char *trainable, size_t n,
                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                  hipStream_t st);

@@ -1,3 +1,704 @@
-// placeholder (filled in below in this round)
+// Fused EdgeBlock with ROLE-SPECIALISED waves (gfx950, float32 model, Fn and Fe padded to FP = 64, split-f16 MFMA).
+// The math is _EdgeBlock.forward (/root/reference/ramannoodle/pmodel/torch/_gnn.py:223-228, 270-291, 351) in the
+// factorised form of kernels_fused.hip; what changes is WHO does what.
+//
+// edge_block_fused_kernel runs four identical waves per workgroup, two workgroups per CU: every wave carries the
+// resident weight fragments (64 VGPRs) AND the ~100-register triplet loop, so only two waves fit a SIMD and its
+// VALU idles 37 % of the cycles (profiles/r03/perf_sq_counters.txt).  Here ONE 768-thread workgroup owns a CU:
+//
+//   waves 0-3  PRODUCERS (one per SIMD).  Wave p owns the 32 output columns 32p..32p+31 of every projection with
+//              W4, W5 and the c2 weight resident as split-f16 fragments (96 VGPRs).  Per step: retire the LDS-DMA
+//              of its operand rows, turn the slots it fetched into [hi|lo] halves, request the next step's rows,
+//              then by MFMA  P'_d = W4 edge_d + Wj node[b_d] + Wk node[a_d] + bias  and the c2 pre-activation
+//              for the round's 16 destination edges, and  Q'_e = W5 edge_e + Wi node[b_e]  for the 16-row source
+//              tiles the coming rounds need.  The node terms seed the accumulators, so an MFMA result IS the row.
+//   waves 4-11 CONSUMERS (two per SIMD).  A wave owns two destinations of the round, each split over two 16-lane
+//              groups (one half of its triplets each): triplet loop on LDS operands, both halves added by one
+//              cross-row swizzle, LayerNorms, c2 gate, residual tanh, store.  No weights: ~110 VGPRs.
+//
+// Three waves per SIMD, and no s_barrier after start-up: the roles meet through LDS words (an LDS atomic add to
+// signal, a relaxed poll with s_sleep to wait; a wave's LDS operations are performed in order):
+//   c_split / c_norm  the four producers among themselves (operand tiles split; projections written)
+//   c_ready           round g may be consumed (published by producer 0 once the rows' |q|^2 are complete)
+//   c_done[g & 1]     consumer waves that finished round g -- a producer overwrites the buffers of round g only
+//                     after all eight waves finished round g - 2.
+// Q' lives in a RING of source-row tiles (PS_NRT x 16 rows): destinations are sorted by their atom and so are the
+// source rows, so round g needs a sliding window of rows; a tile is overwritten when the rounds that read it are
+// done (the host checks, by running the same schedule, that "round g - 2 finished" implies that: ps_schedule_ok).
+//
+// No LayerNorm mean anywhere: c3_linear / c2_linear are centred over their output columns on the host
+// (api.hip: centred_ops), LN(x) = LN(x - mean x) and mean x is linear in the inputs, so the projections come out
+// with zero row mean and the statistics need |p|^2, |q|^2 and p.q only -- which is what lets a producer wave
+// finish its 32 columns of a row without seeing the other 96.
+#include <algorithm>
+#include <vector>
+
 #include "fused_common.hpp"
-namespace rn {}
+
+namespace rn {
+
+struct EdgePsArgs {
+  const float *edge_in;
+  float *edge_out;
+  const float *node;  // updated node embedding [S*N, FP]
+  const float *np3;   // [S*N, 6FP] = node * centred(Wi | Wj | Wk) + (0 | centred bias | 0)
+  float *agg_out;     // optional: the pre-LayerNorm triplet sums [S*E, FP]
+  int *fail;          // set when a bounded wait ran out (a protocol bug; the kernel still terminates)
+  int S;
+  Graph g;
+  Dims d;
+  PassW<float> w;
+};
+
+// Timing build (RN_BUILD_TAG=timing RN_EXTRA_FLAGS=-DRN_PS_TIMING=1): producer wave 0 and consumer wave 4 of workgroup 0
+// accumulate the shader-clock cycles of their phases into fail[16 + 2 i .. ] (int64 pairs: cycles, count); api.hip
+// prints them after a synchronising call.  The product build compiles none of it.
+#ifndef RN_PS_TIMING
+#define RN_PS_TIMING 0
+#endif
+#if RN_PS_TIMING
+#define PS_T0() long long _t = (long long)__builtin_readcyclecounter()
+#define PS_TICK(i)                                                                       \
+  do {                                                                                   \
+    const long long _n = (long long)__builtin_readcyclecounter();                        \
+    if (timed) {                                                                         \
+      tacc[2 * (i)] += _n - _t;                                                          \
+      tacc[2 * (i) + 1] += 1;                                                            \
+    }                                                                                    \
+    _t = (long long)__builtin_readcyclecounter();                                        \
+  } while (0)
+#else
+#define PS_T0() do {} while (0)
+#define PS_TICK(i) do {} while (0)
+#endif
+
+namespace {
+constexpr int PS_THREADS = 768;
+constexpr int PS_PROD = 4;   // producer waves
+constexpr int PS_CONS = 8;   // consumer waves
+constexpr int PS_ND = 16;    // destinations per round (two per consumer wave)
+constexpr int PS_NRT = 8;    // ring capacity, in 16-row source tiles
+constexpr int PS_RING = PS_NRT * 16;
+constexpr int PS_RINGF = PS_RING * LDQ;  // floats
+constexpr int PS_MAXNEW = 2;             // source tiles a step produces at most
+constexpr int PS_TILE = 16 * FP;         // floats of one operand tile
+constexpr int PS_BUF = (2 + PS_MAXNEW) * PS_TILE;  // one DMA buffer: edge_d | node[b] | PS_MAXNEW x edge_e
+
+enum { C_SPLIT = 0, C_NORM = 16, C_READY = 32, C_DONE0 = 48, C_DONE1 = 64 };  // byte offsets of the signalling words
+
+struct PsLds {
+  size_t ring, qnp, bufP, bufC, atile, lnp, ints, sync, total;
+};
+__host__ __device__ inline PsLds ps_lds(int maxR, int maxD) {
+  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
+  const size_t maxR16 = ((size_t)maxR + 15) & ~size_t(15), rounds = ((size_t)maxD + PS_ND - 1) / PS_ND;
+  PsLds L;
+  size_t off = 0;
+  L.ring = off; off += (size_t)PS_RINGF * 4;
+  L.qnp = off; off += (size_t)PS_RING * 4 * 4;
+  L.bufP = off; off += (size_t)2 * PS_ND * LDQ * 4;
+  L.bufC = off; off += (size_t)2 * PS_ND * LDQ * 4;
+  L.atile = off; off += ((size_t)2 * PS_BUF + PS_TILE) * 4;  // two buffers + the node[a] tile they share
+  L.lnp = off; off += (size_t)14 * FP * 4;
+  L.ints = off; off += up((maxR16 + 7 * (size_t)maxD + 2 * rounds + 8) * 4);
+  L.sync = off; off += 128;
+  L.total = off;
+  return L;
+}
+
+// ---- the production schedule (host and device run the same arithmetic) ------------------------------------
+// A workgroup serves one atom tile for the frames sg, sg + nsg, ... ("units").  A unit is `nrounds` rounds of 16
+// destinations and `nrt` source tiles; hi[r] = last source tile round r reads.  Source tiles are produced in order
+// (monotonic index j: unit j / nrt, tile j % nrt) at most PS_MAXNEW per step: a step produces what its own round
+// still misses and runs ahead into what the NEXT round needs; tiles round 0 of the first unit needs come from
+// destination-less prologue steps.
+struct PsStep {
+  int has_dest;  // the step serves round (unit u, local round r), global round index g
+  int u, r, g;
+  int ntiles, tile0;  // source tiles produced: monotonic indices tile0 .. tile0 + ntiles - 1
+};
+struct PsSched {
+  int nrounds, nrt, nunits;
+  int P;        // tiles scheduled so far
+  int u, r, g;  // next destination round
+};
+__host__ __device__ inline void ps_sched_init(PsSched &s, int nrounds, int nrt, int nunits) {
+  s.nrounds = nrounds;
+  s.nrt = nrt;
+  s.nunits = nunits;
+  s.P = s.u = s.r = s.g = 0;
+}
+// `hi` = the tile's hi[] table.  Returns false when the stream is exhausted.
+template <typename HiFn>
+__host__ __device__ inline bool ps_sched_next(PsSched &s, HiFn hi, PsStep &st) {
+  if (s.u >= s.nunits) return false;
+  if (s.g == 0 && s.u == 0 && s.r == 0 && s.P < hi(0) + 1) {  // prologue: what the very first round reads
+    const int miss = hi(0) + 1 - s.P;
+    st = {0, 0, 0, 0, miss < PS_MAXNEW ? miss : PS_MAXNEW, s.P};
+    s.P += st.ntiles;
+    return true;
+  }
+  const int need_now = s.u * s.nrt + hi(s.r) + 1;
+  int u2 = s.u, r2 = s.r + 1;
+  if (r2 == s.nrounds) { r2 = 0; ++u2; }
+  const int need_next = u2 < s.nunits ? u2 * s.nrt + hi(r2) + 1 : need_now;
+  int n = need_next - s.P;
+  n = n < 0 ? 0 : (n > PS_MAXNEW ? PS_MAXNEW : n);
+  if (n < need_now - s.P) n = need_now - s.P;  // (ps_schedule_ok: never more than PS_MAXNEW)
+  st = {1, s.u, s.r, s.g, n, s.P};
+  s.P += n;
+  s.u = u2;
+  s.r = r2;
+  ++s.g;
+  return true;
+}
+
+// ---- LDS signalling -------------------------------------------------------------------------------------
+// In inline assembly on purpose: around a compiler-visible atomic, volatile access or fence hipcc (ROCm 7.2) drains
+// vmcnt(0) whenever an LDS-DMA or a store may be outstanding -- for a producer that is the next step's operand rows
+// (a full HBM round trip per step), for a consumer the previous round's output stores.  LDS operations of a wave are
+// performed in order, and the waits below are on lgkmcnt only.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+// Bounded: a wait that has not been satisfied after ~2^21 polls (tens of milliseconds; a real one takes microseconds)
+// reports `code` through *fail and lets the wave go on, so a protocol bug produces an error instead of a hung GPU.
+__device__ __forceinline__ void ps_wait_ge(unsigned word, unsigned target, int *fail, int code) {
+  for (unsigned spins = 0;; ++spins) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(word) : "memory");
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+    if (spins > (1u << 21)) {
+      *fail = code;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// every LDS access of this wave is complete before the count moves
+__device__ __forceinline__ void ps_arrive(unsigned word, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(word), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void ps_publish(unsigned word, unsigned value, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(word), "v"(value) : "memory");
+}
+// hides a lane constant from loop-invariant code motion: what is derived from the result is recomputed where it is
+// used instead of occupying a register for the whole kernel (the producers hold 96 VGPRs of weights)
+__device__ __forceinline__ int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// LDS reads of a PRODUCER, in inline assembly for the same reason: with an LDS-DMA outstanding hipcc puts
+// s_waitcnt vmcnt(0) in front of every LDS read it can see (inside a loop it cannot prove that the read misses the
+// DMA's destination), which would turn the one-step-ahead requests into synchronous loads.  Reads and their
+// lgkmcnt wait form ONE statement, so no use of a result can be scheduled in between.
+__device__ __forceinline__ void lds_read4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, f32x4 &r0, f32x4 &r1,
+                                          f32x4 &r2, f32x4 &r3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+}
+__device__ __forceinline__ void lds_read2(unsigned a0, unsigned a1, f32x4 &r0, f32x4 &r1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1)
+               : "v"(a0), "v"(a1)
+               : "memory");
+}
+__device__ __forceinline__ void lds_write4(unsigned a0, float4 x) {  // (a write into an operand tile: same reason)
+  const f32x4 v = {x.x, x.y, x.z, x.w};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(a0), "v"(v) : "memory");
+}
+__device__ __forceinline__ int lds_read1(unsigned a0) {
+  int r;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a0) : "memory");
+  return r;
+}
+// A fragments of one operand tile whose slots were converted by split_slot (fused_common.hpp: load_split_a)
+__device__ __forceinline__ void ps_load_split_a(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2]) {
+  union { f32x4 v; struct { f16x4 hi, lo; } h; } u[4];
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  lds_read4(row + (((4 * quad + 0) ^ l15) & 15) * 16, row + (((4 * quad + 1) ^ l15) & 15) * 16,
+            row + (((4 * quad + 2) ^ l15) & 15) * 16, row + (((4 * quad + 3) ^ l15) & 15) * 16, u[0].v, u[1].v, u[2].v, u[3].v);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+}  // namespace
+
+template <bool PAD>
+__global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Graph &g = a.g;
+  const PsLds L = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows);
+  float *ring = reinterpret_cast<float *>(smem_raw + L.ring);   // [PS_RING][LDQ] folded source rows, |q|^2 in the pad
+  float *qnp = reinterpret_cast<float *>(smem_raw + L.qnp);     // [PS_RING][4] per-producer parts of |q|^2 / 2Fe
+  float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);   // [2][16][LDQ] P' rows of a round
+  float *bufC = reinterpret_cast<float *>(smem_raw + L.bufC);   // [2][16][LDQ] c2 pre-activations of a round
+  float *atile = reinterpret_cast<float *>(smem_raw + L.atile); // 2 x PS_BUF operand tiles + node[a] tile
+  float *na_tile = atile + 2 * PS_BUF;
+  float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
+  float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
+        *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP, *s_g3 = lnp + 8 * FP, *s_ig3 = lnp + 10 * FP, *s_c2b = lnp + 12 * FP;
+  int *ints = reinterpret_cast<int *>(smem_raw + L.ints);
+  unsigned *sync = reinterpret_cast<unsigned *>(smem_raw + L.sync);
+  const unsigned sync_a = lds_addr(sync);  // LDS byte address of the signalling words
+  const unsigned atile_a = lds_addr(atile), lnp_a = lds_addr(lnp), qnp_a = lds_addr(qnp), ints_a = lds_addr(ints);
+  const int maxD = g.pt_max_in_rows, maxR16 = (g.pt_max_out_rows + 15) & ~15;
+  int *qb = ints;  // [maxR16] b_e of the tile's source rows
+  int *d_edge = qb + maxR16, *d_a = d_edge + maxD, *d_b = d_a + maxD, *d_rb = d_b + maxD, *d_cnt = d_rb + maxD,
+      *d_skip = d_cnt + maxD, *d_re = d_skip + maxD;
+  int *hi_t = d_re + maxD;                          // [rounds] last source tile a round reads
+  int *misc = hi_t + (maxD + PS_ND - 1) / PS_ND;    // [0] nrt
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+
+  // Workgroups of one frame group share node / np3 rows: keep them on one XCD (its L2).
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = logical % g.pt_num;
+  const int sg = logical / g.pt_num, nsg = gridDim.x / g.pt_num;
+  const int j0 = g.pt_begin[tile], j1 = g.pt_begin[tile + 1];
+  const int eo0 = g.out_ptr[j0], R = g.out_ptr[j1] - eo0;
+  const int di0 = g.in_ptr[j0], D = g.in_ptr[j1] - di0;
+  const int nrounds = (D + PS_ND - 1) / PS_ND;
+
+  // ---- once per launch: LayerNorm parameters, the tile topology, the round -> source tile table
+  for (int c = tid; c < 2 * FP; c += PS_THREADS) {
+    s_c2n1g[c] = a.w.c2_norm_1.g[c];
+    s_c2n1b[c] = a.w.c2_norm_1.b[c];
+    s_c2b[c] = a.w.c2_bias_c[c];
+    const float gam = a.w.c3_norm_1s.g[c];  // c3_norm_1's scale times the gate's exp2 factor (-log2e | 2 log2e)
+    s_g3[c] = gam;
+    s_ig3[c] = ((c % FP) < a.d.Fe) ? 1.0f / gam : 0.0f;
+    if (c < FP) {
+      s_c3n2g[c] = a.w.c3_norm_2.g[c];
+      s_c3n2b[c] = a.w.c3_norm_2.b[c];
+      s_c2n2g[c] = a.w.c2_norm_2.g[c];
+      s_c2n2b[c] = a.w.c2_norm_2.b[c];
+    }
+  }
+  for (int r = tid; r < maxR16; r += PS_THREADS) qb[r] = g.edge_b[eo0 + min(r, max(R - 1, 0))];
+  for (int i = tid; i < D; i += PS_THREADS) {
+    const int dst = g.in_edge[di0 + i];
+    const int ad = g.edge_a[dst], bd = g.edge_b[dst];
+    const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
+    const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
+    d_edge[i] = dst;
+    d_a[i] = ad;
+    d_b[i] = bd;
+    d_rb[i] = rb;
+    d_cnt[i] = (re - rb) - (rev >= 0 ? 1 : 0);
+    d_skip[i] = rev >= 0 ? rev - eo0 : re;
+    d_re[i] = re;
+  }
+  if (tid < 32) sync[tid] = 0u;
+  __syncthreads();
+  if (tid < nrounds) {  // destinations are sorted by atom, so the rows a round reads end where its last atom's do
+    int top = 0;
+    const int last = min((tid + 1) * PS_ND, D);
+    for (int i = 0; i < last; ++i) top = max(top, d_re[i]);
+    hi_t[tid] = (top + 15) / 16 - 1;
+  }
+  __syncthreads();
+  if (tid == 0) misc[0] = max(hi_t[nrounds > 0 ? nrounds - 1 : 0] + 1, 1);
+  __syncthreads();
+  if (D == 0 || sg >= a.S) return;
+  const int nrt = __builtin_amdgcn_readfirstlane(misc[0]);
+  const int nunits = (a.S - sg + nsg - 1) / nsg;
+
+  if (wave < PS_PROD) {
+    // =========================================================================================== PRODUCER
+    __builtin_amdgcn_s_setprio(2);
+    const int colbase = wave * 32;  // this wave's 32 of the 128 pre-activation columns
+    // (uniform values: kept in SGPRs -- as VGPR operands of packed multiplies each would cost a register pair)
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float s4 = uni(a.w.mfma_scale_c[0]), inv4 = uni(a.w.mfma_scale_c[1]);
+    const float s5 = uni(a.w.mfma_scale_c[2]), inv5 = uni(a.w.mfma_scale_c[3]);
+    const float sc2 = uni(a.w.mfma_scale_c[4]), invc2 = uni(a.w.mfma_scale_c[5]);
+    WaveB<true> bW4, bW5, bWc;
+    bW4.load(a.w.c3_WeT_c, 4 * FP, colbase, l15, quad, s4);
+    bW5.load(a.w.c3_WeT_c + 2 * FP, 4 * FP, colbase, l15, quad, s5);
+    bWc.load(a.w.c2_WT_c, 2 * FP, colbase, l15, quad, sc2);
+    const float inv2n = uni(1.0f / (float)(2 * a.d.Fe));
+    auto hi = [&](int r) { return __builtin_amdgcn_readfirstlane(hi_t[r]); };  // (uniform: keeps the schedule in SGPRs)
+
+    // LDS-DMA of a step's operand rows: wave w brings rows 4w..4w+3 of every tile; slot (row, piece p) receives
+    // global piece p ^ row (the XOR swizzle load_split_a undoes).  Always the same five requests -- a step without
+    // destinations or with fewer source tiles re-fetches a valid row into a tile nobody reads -- so that every
+    // step is one instruction sequence.
+    auto request = [&](const PsStep &st, int buf, int ln) {
+      const int row = 4 * wave + (ln >> 4);
+      const int piece = ((ln & 15) ^ row) & 15;
+      float *dst = atile + buf * PS_BUF + wave * 256;
+      // (indices first, through the assembly reads: an LDS read the compiler can see between two requests would
+      //  get a vmcnt(0) in front of it and serialise them)
+      const unsigned ia = ints_a + (unsigned)(maxR16 + min(st.r * PS_ND + row, D - 1)) * 4u;  // &d_edge[i]
+      const unsigned de = (unsigned)lds_read1(ia), da = (unsigned)lds_read1(ia + (unsigned)maxD * 4u),
+                     db = (unsigned)lds_read1(ia + 2u * (unsigned)maxD * 4u);
+      const int s = sg + st.u * nsg;
+      const float *eb = a.edge_in + (int64_t)s * g.E * FP, *nb = a.node + (int64_t)s * g.N * FP;  // (uniform)
+      const int j0t = st.tile0, j1t = st.tile0 + max(st.ntiles - 1, 0);
+      const int u0 = j0t / nrt, u1 = j1t / nrt;
+      const float *eb0 = a.edge_in + (int64_t)(sg + min(u0, nunits - 1) * nsg) * g.E * FP;
+      const float *eb1 = a.edge_in + (int64_t)(sg + min(u1, nunits - 1) * nsg) * g.E * FP;
+      const unsigned r0 = (unsigned)(eo0 + min((j0t - u0 * nrt) * 16 + row, R - 1)), r1 = (unsigned)(eo0 + min((j1t - u1 * nrt) * 16 + row, R - 1));
+      dma16(eb + (de * FP + 4 * piece), dst);
+      dma16(nb + (db * FP + 4 * piece), dst + PS_TILE);
+      dma16(nb + (da * FP + 4 * piece), na_tile + wave * 256);
+      dma16(eb0 + (r0 * FP + 4 * piece), dst + 2 * PS_TILE);
+      dma16(eb1 + (r1 * FP + 4 * piece), dst + 3 * PS_TILE);
+    };
+    // every lane turns the 16-byte slots IT fetched into [hi x4 | lo x4] halves in place: the edge rows, and
+    // node[b] * node[a] (the c2 operand) in the node[b] tile
+    auto split_landed = [&](int buf, int ln) {
+      const unsigned sa = atile_a + (unsigned)(buf * PS_BUF + wave * 256 + ln * 4) * 4u;
+      auto f4 = [](const f32x4 &v) { return float4{v[0], v[1], v[2], v[3]}; };
+      f32x4 u, v;  // two slots at a time: the weights leave few registers
+      lds_read2(sa, sa + 2 * PS_TILE * 4, u, v);
+      lds_write4(sa, split_slot(f4(u)));
+      lds_write4(sa + 2 * PS_TILE * 4, split_slot(f4(v)));
+      lds_read2(sa + PS_TILE * 4, atile_a + (unsigned)(2 * PS_BUF + wave * 256 + ln * 4) * 4u, u, v);
+      lds_write4(sa + PS_TILE * 4, split_slot(f4(u * v)));
+      lds_read2(sa + 3 * PS_TILE * 4, sa + 3 * PS_TILE * 4, u, v);
+      lds_write4(sa + 3 * PS_TILE * 4, split_slot(f4(u)));
+    };
+    static_assert(PS_MAXNEW == 2, "split_landed / request are written for two source tiles per step");
+
+    PsSched sched;
+    ps_sched_init(sched, nrounds, nrt, nunits);
+    PsStep cur, nxt;
+    bool have = ps_sched_next(sched, hi, cur);
+    if (have) request(cur, 0, lane);
+#if RN_PS_TIMING
+    long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
+    const bool timed = blockIdx.x == 0 && wave == 0 && lane == 0;
+#endif
+    for (unsigned k = 0; have; ++k) {
+      PS_T0();
+      const int buf = (int)(k & 1u);
+      const bool have_next = ps_sched_next(sched, hi, nxt);
+      int ln = launder(lane);
+      // ---- A: this step's operand rows have landed (requested one step ago)
+      dma_wait();
+      PS_TICK(0);
+      // node terms of this step's rows (they seed the accumulators): in flight while the tiles are split
+      f32x4 accP[2], accQ[2];
+      int ringrow0;
+      {
+        const int l15 = ln & 15, mycol = colbase + 4 * (ln >> 4);
+        const float *np3_s = a.np3 + (int64_t)(sg + cur.u * nsg) * g.N * (6 * FP);  // (uniform) this step's frame
+        const int i = min(cur.r * PS_ND + l15, D - 1);
+        const unsigned ok = (unsigned)d_a[i] * (6 * FP) + 4 * FP + mycol, oj = (unsigned)d_b[i] * (6 * FP) + 2 * FP + mycol;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          accP[t] = *reinterpret_cast<const f32x4 *>(np3_s + ok + 16 * t) + *reinterpret_cast<const f32x4 *>(np3_s + oj + 16 * t);
+        const int j = cur.tile0, uj = min(j / nrt, nunits - 1), tj = j - (j / nrt) * nrt;
+        const float *np3_q = a.np3 + (int64_t)(sg + uj * nsg) * g.N * (6 * FP);
+        const unsigned oq = (unsigned)qb[min(tj * 16 + l15, R - 1)] * (6 * FP) + mycol;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
+        ringrow0 = (j & (PS_NRT - 1)) * 16 + l15;
+      }
+      split_landed(buf, ln);
+      PS_TICK(1);
+      ps_arrive(sync_a + C_SPLIT, ln);
+      ps_wait_ge(sync_a + C_SPLIT, 4u * (k + 1u), a.fail, 1);
+      PS_TICK(2);
+      // the seeds are complete before the next requests go out: nothing below waits on vmcnt, so the LDS-DMA
+      // stays in flight across the whole step
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        accP[t] *= s4;
+        accQ[t] *= s5;
+      }
+      // (the operands pin the seeds' arithmetic -- the last use of the loaded values -- above this point)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(accP[0]), "+v"(accP[1]), "+v"(accQ[0]), "+v"(accQ[1])::"memory");
+      // ---- B: request the next step's rows (its buffer and the node[a] tile are free: every producer is past step k - 1)
+      PS_TICK(3);
+      ln = launder(ln);
+      if (have_next) request(nxt, buf ^ 1, ln);
+      PS_TICK(4);
+      // ---- the buffers of round g were last read by round g - 2
+      if (cur.has_dest) ps_wait_ge(sync_a + ((cur.g & 1) ? C_DONE1 : C_DONE0), (unsigned)PS_CONS * (unsigned)(cur.g >> 1), a.fail, 2);
+      PS_TICK(5);
+      ln = launder(ln);
+      const int l15 = ln & 15, quad = ln >> 4, mycol = colbase + 4 * quad;  // + 16 t: the four columns of tile t this lane ends up with
+      const unsigned tb_a = atile_a + (unsigned)(buf * PS_BUF) * 4u;
+      if (cur.has_dest) {
+        const int slot0 = (cur.g & 1) * PS_ND;
+        f16x8 ah[2], al[2];
+        ps_load_split_a(tb_a, l15, quad, ah, al);
+        bW4.product_split(ah, al, accP);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3
+          *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t] * inv4;
+        f32x4 accC[2];
+        lds_read2(lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4, accC[0], accC[1]);  // centred c2 bias
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accC[t] *= sc2;
+        ps_load_split_a(tb_a + PS_TILE * 4, l15, quad, ah, al);
+        bWc.product_split(ah, al, accC);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t] * invc2;
+      }
+      PS_TICK(6);
+      for (int n = 0; n < cur.ntiles; ++n) {
+        int ringrow = ringrow0;
+        if (n > 0) {  // a second tile in one step is rare (once per unit): its node terms are fetched here
+          const int j = cur.tile0 + n, uj = min(j / nrt, nunits - 1), tj = j - (j / nrt) * nrt;
+          const float *np3_q = a.np3 + (int64_t)(sg + uj * nsg) * g.N * (6 * FP);
+          const unsigned oq = (unsigned)lds_read1(ints_a + (unsigned)min(tj * 16 + l15, R - 1) * 4u) * (6 * FP) + mycol;  // qb[]
+#pragma unroll
+          for (int t = 0; t < 2; ++t) accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t) * s5;
+          ringrow = (j & (PS_NRT - 1)) * 16 + l15;
+        }
+        f16x8 ah[2], al[2];
+        ps_load_split_a(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al);
+        bW5.product_split(ah, al, accQ);
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          accQ[t] *= inv5;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ss = fmaf(accQ[t][e], accQ[t][e], ss);
+        }
+        ss += swizzle_xor16(ss);  // the row's four lanes l15 + 16 quad
+        ss += xor32(ss);
+        f32x4 g3v[2];
+        lds_read2(lnp_a + (8 * FP + mycol) * 4, lnp_a + (8 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // s_g3
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(ring + ringrow * LDQ + mycol + 16 * t) = accQ[t] * g3v[t];
+        if (quad == 0) qnp[ringrow * 4 + wave] = ss * inv2n;
+      }
+      PS_TICK(7);
+      ps_arrive(sync_a + C_NORM, ln);
+      if (wave == 0) {
+        // ---- every producer's part of this step is in LDS: complete |q|^2 of the new rows, publish the round
+        ps_wait_ge(sync_a + C_NORM, 4u * (k + 1u), a.fail, 3);
+        if (ln < 16 * cur.ntiles) {
+          const int rrow = ((cur.tile0 + (ln >> 4)) & (PS_NRT - 1)) * 16 + l15;
+          f32x4 v, v2;
+          lds_read2(qnp_a + (unsigned)rrow * 16u, qnp_a + (unsigned)rrow * 16u, v, v2);
+          ring[rrow * LDQ + 2 * FP] = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        if (cur.has_dest) ps_publish(sync_a + C_READY, (unsigned)cur.g + 1u, ln);
+      }
+      PS_TICK(8);
+      cur = nxt;
+      have = have_next;
+    }
+    return;
+  }
+
+  // ============================================================================================= CONSUMER
+  const int cw = wave - PS_PROD;            // 0..7: destinations 2 cw, 2 cw + 1 of every round
+  const int q4 = l15, c0 = 4 * q4;          // lane q4 of a group owns columns 4 q4 .. + 3 (+ FP)
+  const int dsel = quad >> 1, part = quad & 1;  // which of the wave's two destinations, which half of its triplets
+  const int slot = 2 * cw + dsel;
+  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
+  const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
+  f32x2 bf2[2], bc2[2];  // c3_norm_1's shift with the exp2 scale of the gate folded in
+  {
+    const Vec4<float> bf = load4<float>(a.w.c3_norm_1s.b + c0), bc = load4<float>(a.w.c3_norm_1s.b + FP + c0);
+    bf2[0] = f32x2{bf.v[0], bf.v[1]};
+    bf2[1] = f32x2{bf.v[2], bf.v[3]};
+    bc2[0] = f32x2{bc.v[0], bc.v[1]};
+    bc2[1] = f32x2{bc.v[2], bc.v[3]};
+  }
+  const float *ringc = ring + c0;
+  const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
+  int ub = 0;                      // ring row of the unit's first source row
+  unsigned gr = 0;                 // global round
+#if RN_PS_TIMING
+  long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
+  const bool timed = blockIdx.x == 0 && wave == PS_PROD && lane == 0;
+#endif
+  for (int s = sg; s < a.S; s += nsg) {
+    const int64_t erow0 = (int64_t)s * g.E;
+    for (int r = 0; r < nrounds; ++r, ++gr) {
+      PS_T0();
+      ps_wait_ge(sync_a + C_READY, gr + 1u, a.fail, 4);
+      PS_TICK(10);
+      const int i = r * PS_ND + slot;
+      const bool active = i < D;
+      const int64_t drow = active ? erow0 + d_edge[i] : 0;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      Vec4<float> old;
+      if (active) {
+        old = load4<float>(a.edge_in + drow * FP + c0);
+        const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
+        const Vec4<float> xf = load4<float>(prow + c0), xc = load4<float>(prow + FP + c0);
+        float sp = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sp += xf.v[k] * xf.v[k] + xc.v[k] * xc.v[k];  // zero-mean by construction
+        sp = lg_sum<LG>(sp);
+        // pd = p / gamma * (2 / 2Fe), pg = p * gamma;  var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
+        f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2];
+        {
+          const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);
+          const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
+          const float two_inv = 2.0f * inv2n;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh] * two_inv, xf.v[2 * hh + 1] * igf.v[2 * hh + 1] * two_inv};
+            pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh] * two_inv, xc.v[2 * hh + 1] * igc.v[2 * hh + 1] * two_inv};
+            pf2[hh] = f32x2{xf.v[2 * hh] * g3f.v[2 * hh], xf.v[2 * hh + 1] * g3f.v[2 * hh + 1]};
+            pc2[hh] = f32x2{xc.v[2 * hh] * g3c.v[2 * hh], xc.v[2 * hh + 1] * g3c.v[2 * hh + 1]};
+          }
+        }
+        const float spe = sp * inv2n + 1e-5f;
+        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+        const int half = (cnt + 1) >> 1;
+        const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's half of the triplets
+        auto triplet = [&](const float *qr, float (&sumk)[4]) {
+          const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
+          const float qs = qr[sdelta];
+          const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
+          f32x2 d2 = pdf2[0] * qf2[0];
+          f32x2 d3 = pdc2[0] * qc2[0];
+          d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
+          d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
+          d2 += d3;
+          const float dot = lg_sum<LG>(d2.x + d2.y);
+          float ve = dot + (spe + qs);
+          ve = ve > 1e-5f ? ve : 1e-5f;
+          const float rstd = fast_rsq(ve);
+          const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 xf2 = __builtin_elementwise_fma(pf2[hh] + qf2[hh], rstd2, bf2[hh]);
+            const f32x2 xc2 = __builtin_elementwise_fma(pc2[hh] + qc2[hh], rstd2, bc2[hh]);
+            const f32x2 e1 = {fast_exp2(xf2.x), fast_exp2(xf2.y)}, e2 = {fast_exp2(xc2.x), fast_exp2(xc2.y)};
+            const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+            const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
+            const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
+            f32x2 sk = {sumk[2 * hh], sumk[2 * hh + 1]};
+            sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
+            sumk[2 * hh] = sk.x;
+            sumk[2 * hh + 1] = sk.y;
+          }
+        };
+        PS_TICK(11);
+        // two independent triplets per iteration; one ring offset per lane steps from row to row (two rows where
+        // the numbering jumps over the reverse edge) and wraps at the end of the ring
+        float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+        const int tskip = rskip - rb;
+        auto step = [&](int qo, int tnext) {
+          qo += (tnext == tskip) ? 2 * LDQ : LDQ;
+          return qo >= PS_RINGF ? qo - PS_RINGF : qo;
+        };
+        int qo = ((ub + rb + t0 + (t0 >= tskip ? 1 : 0)) & (PS_RING - 1)) * LDQ;
+        int t = t0;
+        for (; t + 1 < t1; t += 2) {
+          const int qn = step(qo, t + 1);
+          triplet(ringc + qo, acc);
+          triplet(ringc + qn, acc2);
+          qo = step(qn, t + 2);
+        }
+        if (t < t1) triplet(ringc + qo, acc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
+      }
+      PS_TICK(12);
+      // the two halves of a destination sit in lane groups 16 apart: both end up with the whole sum
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += swizzle_xor16(acc[k]);
+      if (active) {
+        if (a.agg_out && part == 0) store4(a.agg_out + drow * FP + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
+        const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
+        const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
+        // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
+        const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
+        const LnParams<float> p2f{load4<float>(s_c2n1g + c0), load4<float>(s_c2n1b + c0)};
+        const LnParams<float> p2c{load4<float>(s_c2n1g + FP + c0), load4<float>(s_c2n1b + FP + c0)};
+        const Vec4<float> c2f = load4<float>(crow + c0), c2c = load4<float>(crow + FP + c0);
+        const Vec4<float> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
+        const LnParams<float> p2n{load4<float>(s_c2n2g + c0), load4<float>(s_c2n2b + c0)};
+        const Vec4<float> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
+        Vec4<float> out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2.v[k] + c3.v[k]);
+        if (part == 0) store4(a.edge_out + drow * FP + c0, out);
+      }
+      ps_arrive(sync_a + ((gr & 1u) ? C_DONE1 : C_DONE0), lane);  // this wave no longer reads round gr's buffers
+      PS_TICK(13);
+    }
+    ub = (ub + nrt * 16) & (PS_RING - 1);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+size_t edge_ps_lds_bytes(int rows, int in_rows) { return ps_lds(rows, in_rows).total; }
+
+// Runs the producers' schedule for one tile (first destination index and end row per destination, sorted by atom)
+// and checks what the kernel takes for granted: never more than PS_MAXNEW source tiles in one step, and the ring
+// never holds a tile that a round still in flight reads when its slot is rewritten.
+bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
+  if (D <= 0) return true;
+  const int nrounds = (D + PS_ND - 1) / PS_ND;
+  std::vector<int> hi(nrounds), lo(nrounds);
+  int top = 0;
+  for (int r = 0; r < nrounds; ++r) {
+    const int last = std::min((r + 1) * PS_ND, D);
+    int first_row = 1 << 30;
+    for (int i = r * PS_ND; i < last; ++i) {
+      top = std::max(top, re[i]);
+      if (re[i] > rb[i]) first_row = std::min(first_row, rb[i]);
+    }
+    hi[r] = (top + 15) / 16 - 1;
+    lo[r] = first_row == (1 << 30) ? (hi[r] + 1) : first_row / 16;
+  }
+  const int nrt = std::max(hi[nrounds - 1] + 1, 1);
+  const int units = 3;
+  PsSched s;
+  ps_sched_init(s, nrounds, nrt, units);
+  PsStep st;
+  auto hif = [&](int r) { return hi[r]; };
+  while (ps_sched_next(s, hif, st)) {
+    if (st.ntiles > PS_MAXNEW) return false;
+    if (!st.has_dest) {
+      if (st.tile0 + st.ntiles > PS_NRT) return false;
+      continue;
+    }
+    // consumers may still be reading round g - 1: its first tile and everything after it must survive this step
+    int u1 = st.u, r1 = st.r - 1;
+    if (r1 < 0) { r1 = nrounds - 1; --u1; }
+    const int oldest = u1 >= 0 ? u1 * nrt + std::min(lo[r1], hi[r1] + 1) : 0;
+    if (st.tile0 + st.ntiles - oldest > PS_NRT) return false;
+    if (st.u * nrt + hi[st.r] + 1 > st.tile0 + st.ntiles) return false;  // the round's own rows exist
+  }
+  return true;
+}
+
+void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
+                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st) {
+  if (S == 0 || g.E == 0) return;
+  EdgePsArgs a{edge_in, edge_out, node, np3, agg_out, fail, S, g, d, w};
+  const size_t lds = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows).total;
+  const bool pad = d.Fe != d.FeP;
+  auto kern = pad ? &edge_block_ps_kernel<true> : &edge_block_ps_kernel<false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int nsg = cus / g.pt_num;  // one workgroup per CU
+  nsg = nsg < 1 ? 1 : (nsg > S ? S : nsg);
+  kern<<<(unsigned)nsg * (unsigned)g.pt_num, PS_THREADS, lds, st>>>(a);
+}
+
+}  // namespace rn

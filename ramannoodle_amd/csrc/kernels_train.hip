@@ -45,6 +45,7 @@ void launch_adam(float *w, const float *g, float *m, float *v, const unsigned ch
 //   kind 1: dst[i] = src[i] * scale       (count = K: copies with scale 1, folded LayerNorm halves)
 //   kind 2: dst[0..1] = (s, 1/s), s = mfma_prescale(max |src[k * ld + n]|, k < K, n < N), ld = (int)scale:
 //           the power-of-two prescale of a weight block for the split-f16 matrix products
+//   kind 3: row-centred copy of a [K][N] matrix of [filter | core] column blocks (kernels.hpp)
 __global__ void refresh_derived_kernel(float *__restrict__ w, const DerivedOp *__restrict__ ops, int num_ops) {
   __shared__ float s_max[256];
   for (int o = blockIdx.x; o < num_ops; o += gridDim.x) {
@@ -66,6 +67,20 @@ __global__ void refresh_derived_kernel(float *__restrict__ w, const DerivedOp *_
         w[op.dst + 1] = 1.0f / sc;
       }
       __syncthreads();
+      continue;
+    }
+    if (op.kind == 3) {  // one thread per row and [filter | core] block
+      const int bw = 2 * op.FeP, nblk = op.N / bw;
+      for (int i = threadIdx.x; i < op.K * nblk; i += blockDim.x) {
+        const size_t base = (size_t)(i / nblk) * op.N + (size_t)(i % nblk) * bw;
+        float sum = 0.0f;
+        for (int h = 0; h < 2; ++h)
+          for (int c = 0; c < op.Fe; ++c) sum += w[op.src + base + h * op.FeP + c];
+        const float mean = sum / (float)(2 * op.Fe);
+        for (int h = 0; h < 2; ++h)
+          for (int c = 0; c < op.FeP; ++c)
+            w[op.dst + base + h * op.FeP + c] = c < op.Fe ? w[op.src + base + h * op.FeP + c] - mean : 0.0f;
+      }
       continue;
     }
     const size_t total = (size_t)op.K * (op.kind == 0 ? op.N : 1);

@@ -724,7 +724,8 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         return {"fused_edge_block": bool(flags & 1), "folded_gate_scale": bool(flags & 2),
                 "split_f16_mfma": bool(flags & 4), "narrow_kernels": bool(flags & 8),
                 "mfma_range_fallback": bool(flags & 16), "pipelined_edge_block": bool(flags & 32),
-                "twelve_wave_edge_block": bool(flags & 64), "experiment_kernels": bool(flags & 128)}
+                "twelve_wave_edge_block": bool(flags & 64), "experiment_kernels": bool(flags & 128),
+                "role_split_edge_block": bool(flags & 256)}
 
     def set_profiling(self, mode: int) -> None:
         """0 = off, 1 = HIP-event timing of every kernel launch, 100+k = kernel k only."""
