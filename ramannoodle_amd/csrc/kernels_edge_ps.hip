@@ -56,6 +56,12 @@ struct EdgePsArgs {
 #ifndef RN_PS_TIMING
 #define RN_PS_TIMING 0
 #endif
+#ifndef RN_PS_PRIO
+#define RN_PS_PRIO 2   // s_setprio of the producer waves (consumers: 0 in the triplet loop)
+#endif
+#ifndef RN_PS_CPRIO
+#define RN_PS_CPRIO 1  // s_setprio of a consumer wave outside its triplet loop (+0.6 %: profiles/r04/edge_ps_experiments.txt)
+#endif
 #if RN_PS_TIMING
 #define PS_T0() long long _t = (long long)__builtin_readcyclecounter()
 #define PS_TICK(i)                                                                       \
@@ -116,39 +122,65 @@ struct PsStep {
   int has_dest;  // the step serves round (unit u, local round r), global round index g
   int u, r, g;
   int ntiles, tile0;  // source tiles produced: monotonic indices tile0 .. tile0 + ntiles - 1
+  int tu0, tt0, tu1, tt1;  // their units and local tile indices (the second pair repeats the first when there is one tile)
 };
 struct PsSched {
   int nrounds, nrt, nunits;
-  int P;        // tiles scheduled so far
-  int u, r, g;  // next destination round
+  int P, pu, pt;  // tiles scheduled so far; unit and local index of the next one (P = pu nrt + pt)
+  int u, r, g;    // next destination round
+  int h0, hc;     // hi[0]; hi[r] of the next destination round
 };
-__host__ __device__ inline void ps_sched_init(PsSched &s, int nrounds, int nrt, int nunits) {
+__host__ __device__ inline void ps_sched_init(PsSched &s, int nrounds, int nrt, int nunits, int hi0) {
   s.nrounds = nrounds;
   s.nrt = nrt;
   s.nunits = nunits;
-  s.P = s.u = s.r = s.g = 0;
+  s.P = s.pu = s.pt = s.u = s.r = s.g = 0;
+  s.h0 = s.hc = hi0;
 }
-// `hi` = the tile's hi[] table.  Returns false when the stream is exhausted.
+__host__ __device__ inline void ps_sched_take(PsSched &s, PsStep &st, int n) {  // the next n (<= 2) tiles go to this step
+  st.ntiles = n;
+  st.tile0 = s.P;
+  st.tu0 = st.tu1 = s.pu;
+  st.tt0 = st.tt1 = s.pt;
+  if (n >= 1) {
+    ++s.P;
+    if (++s.pt == s.nrt) { s.pt = 0; ++s.pu; }
+  }
+  if (n >= 2) {
+    st.tu1 = s.pu;
+    st.tt1 = s.pt;
+    ++s.P;
+    if (++s.pt == s.nrt) { s.pt = 0; ++s.pu; }
+  }
+}
+// `hi` = the tile's hi[] table (called at most once, for the round after the one scheduled).  Returns false when the
+// stream is exhausted.
 template <typename HiFn>
 __host__ __device__ inline bool ps_sched_next(PsSched &s, HiFn hi, PsStep &st) {
   if (s.u >= s.nunits) return false;
-  if (s.g == 0 && s.u == 0 && s.r == 0 && s.P < hi(0) + 1) {  // prologue: what the very first round reads
-    const int miss = hi(0) + 1 - s.P;
-    st = {0, 0, 0, 0, miss < PS_MAXNEW ? miss : PS_MAXNEW, s.P};
-    s.P += st.ntiles;
+  if (s.g == 0 && s.P < s.h0 + 1) {  // prologue: what the very first round reads
+    const int miss = s.h0 + 1 - s.P;
+    st.has_dest = 0;
+    st.u = st.r = st.g = 0;
+    ps_sched_take(s, st, miss < PS_MAXNEW ? miss : PS_MAXNEW);
     return true;
   }
-  const int need_now = s.u * s.nrt + hi(s.r) + 1;
+  const int need_now = s.u * s.nrt + s.hc + 1;
   int u2 = s.u, r2 = s.r + 1;
   if (r2 == s.nrounds) { r2 = 0; ++u2; }
-  const int need_next = u2 < s.nunits ? u2 * s.nrt + hi(r2) + 1 : need_now;
+  const int h2 = r2 == 0 ? s.h0 : hi(r2);
+  const int need_next = u2 < s.nunits ? u2 * s.nrt + h2 + 1 : need_now;
   int n = need_next - s.P;
   n = n < 0 ? 0 : (n > PS_MAXNEW ? PS_MAXNEW : n);
-  if (n < need_now - s.P) n = need_now - s.P;  // (ps_schedule_ok: never more than PS_MAXNEW)
-  st = {1, s.u, s.r, s.g, n, s.P};
-  s.P += n;
+  if (n < need_now - s.P) n = need_now - s.P;  // (edge_ps_tile_ok: never more than PS_MAXNEW)
+  st.has_dest = 1;
+  st.u = s.u;
+  st.r = s.r;
+  st.g = s.g;
+  ps_sched_take(s, st, n);
   s.u = u2;
   s.r = r2;
+  s.hc = h2;
   ++s.g;
   return true;
 }
@@ -212,6 +244,18 @@ __device__ __forceinline__ void lds_write4(unsigned a0, float4 x) {  // (a write
   const f32x4 v = {x.x, x.y, x.z, x.w};
   asm volatile("ds_write_b128 %0, %1" ::"v"(a0), "v"(v) : "memory");
 }
+__device__ __forceinline__ void lds_read1x3(unsigned a0, unsigned a1, unsigned a2, int &r0, int &r1, int &r2) {
+  asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+               : "v"(a0), "v"(a1), "v"(a2)
+               : "memory");
+}
+__device__ __forceinline__ void lds_read3(unsigned a0, unsigned a1, unsigned a2, f32x4 &r0, f32x4 &r1, f32x4 &r2) {
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+               : "v"(a0), "v"(a1), "v"(a2)
+               : "memory");
+}
 __device__ __forceinline__ int lds_read1(unsigned a0) {
   int r;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a0) : "memory");
@@ -228,6 +272,38 @@ __device__ __forceinline__ void ps_load_split_a(unsigned tile_addr, int l15, int
     ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
     al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
   }
+}
+// the same plus two more 16-byte reads (a bias / scale pair) under the one wait
+__device__ __forceinline__ void ps_load_split_a2(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2],
+                                                 unsigned x0, unsigned x1, f32x4 &e0, f32x4 &e1) {
+  union { f32x4 v; struct { f16x4 hi, lo; } h; } u[4];
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  asm volatile(
+      "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+      "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(u[0].v), "=&v"(u[1].v), "=&v"(u[2].v), "=&v"(u[3].v), "=&v"(e0), "=&v"(e1)
+      : "v"(row + (((4 * quad + 0) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 1) ^ l15) & 15) * 16),
+        "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16), "v"(x0), "v"(x1)
+      : "memory");
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+// LayerNorm of a row of logical width F spread over THIRTY-TWO lanes, two columns per lane (the two 16-lane halves
+// of a destination share the epilogue: each finishes half of the columns instead of both finishing all of them)
+template <bool PAD>
+__device__ __forceinline__ f32x2 ln_row2(f32x2 x, f32x2 g, f32x2 b, float inv_n, int nvalid) {
+  const float mean = lg_sum<32>(x.x + x.y) * inv_n;
+  f32x2 d = {x.x - mean, x.y - mean};
+  if (PAD) {
+    if (nvalid < 1) d.x = 0.f;
+    if (nvalid < 2) d.y = 0.f;
+  }
+  const float q = lg_sum<32>(d.x * d.x + d.y * d.y);
+  const float rstd = fast_rsq(q * inv_n + 1e-5f);
+  return f32x2{d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y};
 }
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 }  // namespace
@@ -256,6 +332,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       *d_skip = d_cnt + maxD, *d_re = d_skip + maxD;
   int *hi_t = d_re + maxD;                          // [rounds] last source tile a round reads
   int *misc = hi_t + (maxD + PS_ND - 1) / PS_ND;    // [0] nrt
+  const int hi_off = maxR16 + 7 * maxD;             // index of hi_t[0] in ints
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,7 +394,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 
   if (wave < PS_PROD) {
     // =========================================================================================== PRODUCER
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(RN_PS_PRIO);
     const int colbase = wave * 32;  // this wave's 32 of the 128 pre-activation columns
     // (uniform values: kept in SGPRs -- as VGPR operands of packed multiplies each would cost a register pair)
     auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -329,7 +406,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     bW5.load(a.w.c3_WeT_c + 2 * FP, 4 * FP, colbase, l15, quad, s5);
     bWc.load(a.w.c2_WT_c, 2 * FP, colbase, l15, quad, sc2);
     const float inv2n = uni(1.0f / (float)(2 * a.d.Fe));
-    auto hi = [&](int r) { return __builtin_amdgcn_readfirstlane(hi_t[r]); };  // (uniform: keeps the schedule in SGPRs)
 
     // LDS-DMA of a step's operand rows: wave w brings rows 4w..4w+3 of every tile; slot (row, piece p) receives
     // global piece p ^ row (the XOR swizzle load_split_a undoes).  Always the same five requests -- a step without
@@ -339,21 +415,19 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       const int row = 4 * wave + (ln >> 4);
       const int piece = ((ln & 15) ^ row) & 15;
       float *dst = atile + buf * PS_BUF + wave * 256;
-      // (indices first, through the assembly reads: an LDS read the compiler can see between two requests would
-      //  get a vmcnt(0) in front of it and serialise them)
+      // (indices first, through ONE assembly read: an LDS read the compiler can see between two requests would get a
+      //  vmcnt(0) in front of it and serialise them)
       const unsigned ia = ints_a + (unsigned)(maxR16 + min(st.r * PS_ND + row, D - 1)) * 4u;  // &d_edge[i]
-      const unsigned de = (unsigned)lds_read1(ia), da = (unsigned)lds_read1(ia + (unsigned)maxD * 4u),
-                     db = (unsigned)lds_read1(ia + 2u * (unsigned)maxD * 4u);
+      int de, da, db;
+      lds_read1x3(ia, ia + (unsigned)maxD * 4u, ia + 2u * (unsigned)maxD * 4u, de, da, db);
       const int s = sg + st.u * nsg;
       const float *eb = a.edge_in + (int64_t)s * g.E * FP, *nb = a.node + (int64_t)s * g.N * FP;  // (uniform)
-      const int j0t = st.tile0, j1t = st.tile0 + max(st.ntiles - 1, 0);
-      const int u0 = j0t / nrt, u1 = j1t / nrt;
-      const float *eb0 = a.edge_in + (int64_t)(sg + min(u0, nunits - 1) * nsg) * g.E * FP;
-      const float *eb1 = a.edge_in + (int64_t)(sg + min(u1, nunits - 1) * nsg) * g.E * FP;
-      const unsigned r0 = (unsigned)(eo0 + min((j0t - u0 * nrt) * 16 + row, R - 1)), r1 = (unsigned)(eo0 + min((j1t - u1 * nrt) * 16 + row, R - 1));
-      dma16(eb + (de * FP + 4 * piece), dst);
-      dma16(nb + (db * FP + 4 * piece), dst + PS_TILE);
-      dma16(nb + (da * FP + 4 * piece), na_tile + wave * 256);
+      const float *eb0 = a.edge_in + (int64_t)(sg + min(st.tu0, nunits - 1) * nsg) * g.E * FP;
+      const float *eb1 = a.edge_in + (int64_t)(sg + min(st.tu1, nunits - 1) * nsg) * g.E * FP;
+      const unsigned r0 = (unsigned)(eo0 + min(st.tt0 * 16 + row, R - 1)), r1 = (unsigned)(eo0 + min(st.tt1 * 16 + row, R - 1));
+      dma16(eb + ((unsigned)de * FP + 4 * piece), dst);
+      dma16(nb + ((unsigned)db * FP + 4 * piece), dst + PS_TILE);
+      dma16(nb + ((unsigned)da * FP + 4 * piece), na_tile + wave * 256);
       dma16(eb0 + (r0 * FP + 4 * piece), dst + 2 * PS_TILE);
       dma16(eb1 + (r1 * FP + 4 * piece), dst + 3 * PS_TILE);
     };
@@ -362,19 +436,19 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     auto split_landed = [&](int buf, int ln) {
       const unsigned sa = atile_a + (unsigned)(buf * PS_BUF + wave * 256 + ln * 4) * 4u;
       auto f4 = [](const f32x4 &v) { return float4{v[0], v[1], v[2], v[3]}; };
-      f32x4 u, v;  // two slots at a time: the weights leave few registers
-      lds_read2(sa, sa + 2 * PS_TILE * 4, u, v);
+      f32x4 u, v, w;
+      lds_read3(sa, sa + 2 * PS_TILE * 4, sa + 3 * PS_TILE * 4, u, v, w);
       lds_write4(sa, split_slot(f4(u)));
       lds_write4(sa + 2 * PS_TILE * 4, split_slot(f4(v)));
+      lds_write4(sa + 3 * PS_TILE * 4, split_slot(f4(w)));
       lds_read2(sa + PS_TILE * 4, atile_a + (unsigned)(2 * PS_BUF + wave * 256 + ln * 4) * 4u, u, v);
       lds_write4(sa + PS_TILE * 4, split_slot(f4(u * v)));
-      lds_read2(sa + 3 * PS_TILE * 4, sa + 3 * PS_TILE * 4, u, v);
-      lds_write4(sa + 3 * PS_TILE * 4, split_slot(f4(u)));
     };
     static_assert(PS_MAXNEW == 2, "split_landed / request are written for two source tiles per step");
 
+    auto hi = [&](int r) { return __builtin_amdgcn_readfirstlane(lds_read1(ints_a + (unsigned)(hi_off + r) * 4u)); };  // hi_t[r]
     PsSched sched;
-    ps_sched_init(sched, nrounds, nrt, nunits);
+    ps_sched_init(sched, nrounds, nrt, nunits, __builtin_amdgcn_readfirstlane(hi_t[0]));
     PsStep cur, nxt;
     bool have = ps_sched_next(sched, hi, cur);
     if (have) request(cur, 0, lane);
@@ -385,7 +459,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     for (unsigned k = 0; have; ++k) {
       PS_T0();
       const int buf = (int)(k & 1u);
-      const bool have_next = ps_sched_next(sched, hi, nxt);
       int ln = launder(lane);
       // ---- A: this step's operand rows have landed (requested one step ago)
       dma_wait();
@@ -401,13 +474,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           accP[t] = *reinterpret_cast<const f32x4 *>(np3_s + ok + 16 * t) + *reinterpret_cast<const f32x4 *>(np3_s + oj + 16 * t);
-        const int j = cur.tile0, uj = min(j / nrt, nunits - 1), tj = j - (j / nrt) * nrt;
-        const float *np3_q = a.np3 + (int64_t)(sg + uj * nsg) * g.N * (6 * FP);
-        const unsigned oq = (unsigned)qb[min(tj * 16 + l15, R - 1)] * (6 * FP) + mycol;
+        const float *np3_q = a.np3 + (int64_t)(sg + min(cur.tu0, nunits - 1) * nsg) * g.N * (6 * FP);
+        const unsigned oq = (unsigned)qb[min(cur.tt0 * 16 + l15, R - 1)] * (6 * FP) + mycol;
 #pragma unroll
         for (int t = 0; t < 2; ++t) accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
-        ringrow0 = (j & (PS_NRT - 1)) * 16 + l15;
+        ringrow0 = (cur.tile0 & (PS_NRT - 1)) * 16 + l15;
       }
+      const bool have_next = ps_sched_next(sched, hi, nxt);  // (its one table read hides under the loads above)
       split_landed(buf, ln);
       PS_TICK(1);
       ps_arrive(sync_a + C_SPLIT, ln);
@@ -442,10 +515,10 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3
           *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t] * inv4;
         f32x4 accC[2];
-        lds_read2(lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4, accC[0], accC[1]);  // centred c2 bias
+        ps_load_split_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
+                         accC[0], accC[1]);  // + the centred c2 bias
 #pragma unroll
         for (int t = 0; t < 2; ++t) accC[t] *= sc2;
-        ps_load_split_a(tb_a + PS_TILE * 4, l15, quad, ah, al);
         bWc.product_split(ah, al, accC);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -455,15 +528,16 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       for (int n = 0; n < cur.ntiles; ++n) {
         int ringrow = ringrow0;
         if (n > 0) {  // a second tile in one step is rare (once per unit): its node terms are fetched here
-          const int j = cur.tile0 + n, uj = min(j / nrt, nunits - 1), tj = j - (j / nrt) * nrt;
-          const float *np3_q = a.np3 + (int64_t)(sg + uj * nsg) * g.N * (6 * FP);
-          const unsigned oq = (unsigned)lds_read1(ints_a + (unsigned)min(tj * 16 + l15, R - 1) * 4u) * (6 * FP) + mycol;  // qb[]
+          const float *np3_q = a.np3 + (int64_t)(sg + min(cur.tu1, nunits - 1) * nsg) * g.N * (6 * FP);
+          const unsigned oq = (unsigned)lds_read1(ints_a + (unsigned)min(cur.tt1 * 16 + l15, R - 1) * 4u) * (6 * FP) + mycol;  // qb[]
 #pragma unroll
           for (int t = 0; t < 2; ++t) accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t) * s5;
-          ringrow = (j & (PS_NRT - 1)) * 16 + l15;
+          ringrow = ((cur.tile0 + 1) & (PS_NRT - 1)) * 16 + l15;
         }
         f16x8 ah[2], al[2];
-        ps_load_split_a(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al);
+        f32x4 g3v[2];
+        ps_load_split_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (8 * FP + mycol) * 4,
+                         lnp_a + (8 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3
         bW5.product_split(ah, al, accQ);
         float ss = 0.f;
 #pragma unroll
@@ -474,8 +548,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         }
         ss += swizzle_xor16(ss);  // the row's four lanes l15 + 16 quad
         ss += xor32(ss);
-        f32x4 g3v[2];
-        lds_read2(lnp_a + (8 * FP + mycol) * 4, lnp_a + (8 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // s_g3
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(ring + ringrow * LDQ + mycol + 16 * t) = accQ[t] * g3v[t];
         if (quad == 0) qnp[ringrow * 4 + wave] = ss * inv2n;
@@ -505,7 +577,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   const int q4 = l15, c0 = 4 * q4;          // lane q4 of a group owns columns 4 q4 .. + 3 (+ FP)
   const int dsel = quad >> 1, part = quad & 1;  // which of the wave's two destinations, which half of its triplets
   const int slot = 2 * cw + dsel;
-  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
+  const int cc = c0 + 2 * part;             // the two columns this lane finishes in the epilogue
+  const int nvalid2 = min(max(a.d.Fe - cc, 0), 2);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
   f32x2 bf2[2], bc2[2];  // c3_norm_1's shift with the exp2 scale of the gate folded in
   {
@@ -533,9 +606,9 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       const bool active = i < D;
       const int64_t drow = active ? erow0 + d_edge[i] : 0;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      Vec4<float> old;
+      f32x2 old2;
       if (active) {
-        old = load4<float>(a.edge_in + drow * FP + c0);
+        old2 = *reinterpret_cast<const f32x2 *>(a.edge_in + drow * FP + cc);
         const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
         const Vec4<float> xf = load4<float>(prow + c0), xc = load4<float>(prow + FP + c0);
         float sp = 0.f;
@@ -589,6 +662,9 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
           }
         };
         PS_TICK(11);
+#if RN_PS_CPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // two independent triplets per iteration; one ring offset per lane steps from row to row (two rows where
         // the numbering jumps over the reverse edge) and wraps at the end of the ring
         float acc2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -610,25 +686,27 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
       }
       PS_TICK(12);
+#if RN_PS_CPRIO
+      __builtin_amdgcn_s_setprio(RN_PS_CPRIO);
+#endif
       // the two halves of a destination sit in lane groups 16 apart: both end up with the whole sum
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] += swizzle_xor16(acc[k]);
       if (active) {
-        if (a.agg_out && part == 0) store4(a.agg_out + drow * FP + c0, Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}});
-        const LnParams<float> p3n{load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
-        const Vec4<float> c3 = ln_row<LG, PAD>(Vec4<float>{{acc[0], acc[1], acc[2], acc[3]}}, p3n, invn, nvalid);
-        // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228)
+        // from here on the two halves split the COLUMNS: this lane finishes columns cc, cc + 1
+        const f32x2 a2 = part ? f32x2{acc[2], acc[3]} : f32x2{acc[0], acc[1]};
+        if (a.agg_out) *reinterpret_cast<f32x2 *>(a.agg_out + drow * FP + cc) = a2;
+        const f32x2 c3 = ln_row2<PAD>(a2, *reinterpret_cast<const f32x2 *>(s_c3n2g + cc), *reinterpret_cast<const f32x2 *>(s_c3n2b + cc), invn, nvalid2);
+        // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228); the pre-activation row has
+        // zero mean (centred weights) and exact zeros in its padded columns, so its variance is the plain sum of squares
         const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
-        const LnParams<float> p2f{load4<float>(s_c2n1g + c0), load4<float>(s_c2n1b + c0)};
-        const LnParams<float> p2c{load4<float>(s_c2n1g + FP + c0), load4<float>(s_c2n1b + FP + c0)};
-        const Vec4<float> c2f = load4<float>(crow + c0), c2c = load4<float>(crow + FP + c0);
-        const Vec4<float> g2 = ln_gate<LG, PAD>(c2f, c2c, p2f, p2c, inv2n, nvalid);
-        const LnParams<float> p2n{load4<float>(s_c2n2g + c0), load4<float>(s_c2n2b + c0)};
-        const Vec4<float> c2 = ln_row<LG, PAD>(g2, p2n, invn, nvalid);
-        Vec4<float> out;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out.v[k] = fast_tanh(old.v[k] + c2.v[k] + c3.v[k]);
-        if (part == 0) store4(a.edge_out + drow * FP + c0, out);
+        const f32x2 xf = *reinterpret_cast<const f32x2 *>(crow + cc), xc = *reinterpret_cast<const f32x2 *>(crow + FP + cc);
+        const float rstd2 = fast_rsq(lg_sum<32>(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + 1e-5f);
+        const f32x2 gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
+        const f32x2 gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
+        const f32x2 g2 = {gate(xf.x * rstd2 * gf.x + bf.x, xc.x * rstd2 * gc.x + bc.x), gate(xf.y * rstd2 * gf.y + bf.y, xc.y * rstd2 * gc.y + bc.y)};
+        const f32x2 c2 = ln_row2<PAD>(g2, *reinterpret_cast<const f32x2 *>(s_c2n2g + cc), *reinterpret_cast<const f32x2 *>(s_c2n2b + cc), invn, nvalid2);
+        *reinterpret_cast<f32x2 *>(a.edge_out + drow * FP + cc) = f32x2{fast_tanh(old2.x + c2.x + c3.x), fast_tanh(old2.y + c2.y + c3.y)};
       }
       ps_arrive(sync_a + ((gr & 1u) ? C_DONE1 : C_DONE0), lane);  // this wave no longer reads round gr's buffers
       PS_TICK(13);
@@ -661,7 +739,7 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
   const int nrt = std::max(hi[nrounds - 1] + 1, 1);
   const int units = 3;
   PsSched s;
-  ps_sched_init(s, nrounds, nrt, units);
+  ps_sched_init(s, nrounds, nrt, units, hi[0]);
   PsStep st;
   auto hif = [&](int r) { return hi[r]; };
   while (ps_sched_next(s, hif, st)) {
