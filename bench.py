@@ -148,7 +148,7 @@ CONFIGS = {
     3: dict(cells=(4, 4, 2), frames=10_000, seed=33, scaling="strong"),
     2: dict(cells=(4, 2, 2), frames=1_000, seed=22, scaling="weak"),
 }
-PROFILE_ROUNDS = ("r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
 
 
 def algorithmic_bytes_edge_block(n, e, fn, fe):
@@ -171,6 +171,8 @@ def committed_profile(name, n, e, fn, fe):
             rec = json.load(open(path))
             shape = rec.get("workload_shape", [128, 2304, 64, 64])  # r01 files: config 2
             if list(shape) == [n, e, fn, fe]:
+                rec = dict(rec)
+                rec["_path"] = os.path.join("profiles", rnd, name)  # named in the bench line next to what it supplies
                 return rec
     return None
 
@@ -193,7 +195,8 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow
             else "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
             else "node_agg_kernel (NodeBlock scatter-aggregate; its c1 projection is a separate launch)",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": traffic, "launches": launches, "avg_launch_ms": ms / launches,
+            "traffic": traffic, "traffic_source": rec["_path"] if rec else None,
+            "launches": launches, "avg_launch_ms": ms / launches,
             "algorithmic_bytes_per_structure_pass": per}
 
 
@@ -248,6 +251,7 @@ def measure_case(wl, device, steps, warmup, label):
                      "frac": achieved / 8000.0 if achieved else None,
                      "traffic": (rec["hbm_bytes_per_structure_pass"] * frames * passes * steps / agg_launches
                                  if rec and agg_launches else None),
+                     "traffic_source": rec["_path"] if rec else None,
                      "launches": agg_launches, "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
                      "algorithmic_bytes_per_structure_pass": per_pass},
         "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow),
@@ -318,7 +322,10 @@ def cpu_baseline(workload, sample, reps=3):
     return {"value": sample / median, "unit": "structures/s", "cores": threads, "kind": "port",
             "sample": f"{sample} frames of the same workload (one reference sub-batch), oracle faithful "
                       f"variant (N^2 geometry, materialised concat, O(S^2 E) readout), 1 warm-up + "
-                      f"{reps} repetitions of {median:.1f} s (median)",
+                      f"{reps} repetitions of {median:.1f} s (median); deviation from SURVEY.md 8(d), which asked for "
+                      f"1000 frames scaled linearly: the faithful variant walks the reference's 100-frame sub-batches, "
+                      f"so its cost is linear in the sub-batch count and one sub-batch x (1 + {reps}) runs already "
+                      f"takes {median * (1 + reps):.0f} s of the bench's few minutes",
             "repetitions_s": [round(t, 3) for t in faithful],
             "best_structures_per_s": sample / min(faithful),
             "linear_variant_structures_per_s": sample / sane[0],
@@ -415,6 +422,9 @@ def main():
                     help="skip the N = 1 extras: pipelined host-buffer rate, exact-fp32 comparison run, documented "
                          "widths, the reference's published TiO2 workload (profiling passes: the timed steps only)")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="time the steps without the HIP-event pairs around the EdgeBlock / NodeBlock launches "
+                         "(the A/B that prices them: profiles/r04/bench_event_overhead.txt); roofline is then empty")
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP-event timing of every kernel (perturbs the timed region)")
     args = ap.parse_args()
@@ -478,8 +488,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    model.set_profiling(1 if args.profile_all
-                        else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID) + (1 << NODE_AGG_KERNEL_ID))
+    if not args.no_kernel_events:
+        model.set_profiling(1 if args.profile_all
+                            else 1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << PROJ_C3_KERNEL_ID) + (1 << NODE_AGG_KERNEL_ID))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -536,14 +547,18 @@ def main():
         total_bytes = per_pass * mine * passes * args.steps
         achieved = total_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         peak = 8000.0
-        traffic_rec = committed_profile("edge_narrow_traffic.json" if narrow else "edge_fused_traffic.json" if fused
-                                        else "edge_agg_traffic.json", n, e, fn, fe)
-        issue_rec = committed_profile("edge_narrow_issue.json" if narrow else "edge_fused_issue.json", n, e, fn, fe) \
-            if (fused or narrow) else None
+        role_split = bool(fused and flags.get("role_split_edge_block"))
+        traffic_rec = committed_profile("edge_narrow_traffic.json" if narrow else "edge_ps_traffic.json" if role_split
+                                        else "edge_fused_traffic.json" if fused else "edge_agg_traffic.json", n, e, fn, fe)
+        issue_rec = committed_profile("edge_narrow_issue.json" if narrow else "edge_ps_issue.json" if role_split
+                                      else "edge_fused_issue.json", n, e, fn, fe) if (fused or narrow) else None
         frames_per_launch = mine * passes * args.steps / agg_launches if agg_launches else None
         roofline = {
             "kernel": ("edge_narrow_kernel (EdgeBlock: projections + triplet scatter-aggregate, one lane per "
                        "destination edge)" if narrow
+                       else "edge_block_ps_kernel (EdgeBlock: MFMA projections by producer waves + triplet "
+                            "scatter-aggregate by consumer waves, one 12-wave workgroup per CU)"
+                       if fused and flags.get("role_split_edge_block")
                        else "edge_block_fused_kernel (EdgeBlock: MFMA projections + triplet scatter-aggregate)"
                        if fused else "edge_agg_kernel (EdgeBlock triplet scatter-aggregate)"),
             "bound": "hbm",
@@ -551,8 +566,11 @@ def main():
             "peak": peak,
             "unit": "GB/s",
             "frac": achieved / peak if achieved else None,
+            # traffic and issue_frac are NOT measured in this run: they replay the committed rocprofv3 PMC / SQ passes of
+            # this kernel on this workload shape (the files named in *_source; None when no record matches)
             "traffic": (traffic_rec["hbm_bytes_per_structure_pass"] * frames_per_launch
                         if traffic_rec and frames_per_launch else None),
+            "traffic_source": traffic_rec["_path"] if traffic_rec else None,
             "launches": agg_launches,
             "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
             "algorithmic_bytes_per_structure_pass": per_pass,
@@ -561,6 +579,7 @@ def main():
             # counter pass of this kernel on this workload; mfma_frac = its fp32 MFMA FLOP/s, measured
             # live, over the 157.3 TFLOP/s fp32 peak.
             "issue_frac": issue_rec["valu_plus_mfma_busy"] if issue_rec else None,
+            "issue_source": issue_rec["_path"] if issue_rec else None,
             # matrix work of the kernel (three [E,64]x[64,128] products per pass, as 3 split-f16 products
             # each on the f16 MFMA) in fp32-equivalent FLOP/s over the 157.3 TFLOP/s fp32 peak
             "mfma_frac": (edge_block_mfma_flops(e, fn, fe) * mine * passes * args.steps / (agg_ms * 1e-3) / 157.3e12
@@ -576,6 +595,9 @@ def main():
             "value": total * args.steps / elapsed,
             "unit": "structures/s",
             "n_gpus": world,
+            # what torch.distributed reported after init_process_group("nccl") (= RCCL on ROCm); 1 without a group
+            "rccl_ranks_seen": (dist.get_world_size() if world > 1 else 1),
+            "collective_backend": (dist.get_backend() if world > 1 else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -11,8 +11,15 @@
  *   - every function returns RN_OK (0) or a negative rn_status; rn_potgnn_last_error()
  *     gives a human-readable message for the most recent failure on that handle
  *     (or the most recent rn_potgnn_create failure when the handle is NULL).
- *   - a handle is immutable after create; evaluation calls on one handle must be
- *     serialised by the caller (they share the handle's device workspace).
+ *   - Threading: a handle owns mutable state (device workspaces, streams, the forward tape, the
+ *     last error string), so it is NOT re-entrant; every entry point that takes a handle holds the
+ *     handle's own lock for the duration of the call, i.e. calls on ONE handle from several threads
+ *     are serialised by the library, and calls on DISTINCT handles (also on one device) run
+ *     concurrently.  The asynchronous pair rn_potgnn_calc_polarizabilities_async / rn_potgnn_wait
+ *     keeps its ordering guarantees per handle.  rn_potgnn_last_error() returns a pointer into the
+ *     handle: read it before the next call on that handle from another thread.  The reference's
+ *     PolarizabilityModel is single-threaded and synchronous (abstract.py:10-29).
+ *   - no C++ exception crosses this boundary: every failure is a negative rn_status.
  *   - "host" entry points take host buffers and include PCIe transfers;
  *     "device" entry points take device (HBM) pointers and a hipStream_t (as void*).
  */
@@ -315,7 +322,10 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * bit 7 = the library was built with -DRN_EXPERIMENTS=1 and carries the opt-in round-3 experiment kernels
  * (csrc/experiments/); only then can bit 5 (RN_POTGNN_EDGE2=1 at create time: frame-pipelined EdgeBlock,
  * edge_block2_kernel + edge_c2_kernel) or bit 6 (RN_POTGNN_EDGE3=1: twelve-wave EdgeBlock, edge_block3_kernel +
- * edge_c2_kernel) be set.  The product build ignores those knobs. */
+ * edge_c2_kernel) be set.  The product build ignores those knobs.
+ * bit 8 = every pass of a float32 evaluation takes the role-specialised fused EdgeBlock (edge_block_ps_kernel,
+ * csrc/kernels_edge_ps.hip: producer waves + consumer waves in one 768-thread workgroup per CU; needs bits 0-2;
+ * RN_POTGNN_EDGE_PS=0 at create time keeps the per-frame kernel of bit 0). */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

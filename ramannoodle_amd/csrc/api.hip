@@ -151,6 +151,7 @@ struct TimedLaunch {
 }  // namespace
 
 struct rn_potgnn {
+  std::recursive_mutex lock;  // serialises the calls on this handle (guarded())
   rn_potgnn_config cfg{};
   Dims d{};
   int chunk = 1;
@@ -507,9 +508,17 @@ void pack_weights(rn_potgnn *h, const float *w) {
 
 // Frames per device work chunk in precision T.  The workspace budget is counted in bytes, so
 // the float64 lanes (created on first use, next to the float32 ones) take half the frames.
+bool lean_workspace(const rn_potgnn *h);
+size_t per_structure_elems(const rn_potgnn *h, bool lean);
+// The float32 chunk may have been sized from the LEAN workspace of the fused / narrow pipelines; float64 always runs the
+// unfused chain on the full-width buffers, so its chunk is counted from that layout (8 bytes per element) against the
+// same bytes the float32 lanes were given.
 template <typename T>
 int chunk_frames(const rn_potgnn *h) {
-  return sizeof(T) == 8 ? std::max(1, h->chunk / 2) : h->chunk;
+  if (sizeof(T) == 4) return h->chunk;
+  const size_t budget = (size_t)h->chunk * per_structure_elems(h, lean_workspace(h)) * sizeof(float);
+  const size_t per64 = per_structure_elems(h, false) * sizeof(double);
+  return (int)std::max<size_t>(1, std::min<size_t>((size_t)h->chunk, budget / std::max<size_t>(per64, 1)));
 }
 
 template <typename T>
@@ -539,10 +548,9 @@ bool lean_workspace(const rn_potgnn *h) {
 size_t bufA_width(const rn_potgnn *h, bool lean) {
   return lean ? 32 : std::max<size_t>(std::max(2 * h->d.FnP, 2 * h->d.FeP), 32);
 }
-size_t per_structure_elems(const rn_potgnn *h) {
+size_t per_structure_elems(const rn_potgnn *h, bool lean) {
   const size_t N = h->cfg.num_atoms, E = h->cfg.num_edges;
   const size_t FnP = h->d.FnP, FeP = h->d.FeP;
-  const bool lean = lean_workspace(h);
   return E * 4 + 2 * N * FnP + 2 * E * FeP + N * 2 * FnP + N * 6 * FeP + E * bufA_width(h, lean) +
          (lean ? 0 : E * 4 * FeP) + ((h->use_edge2 || h->use_edge3) ? E * FeP : 0);
 }
@@ -559,10 +567,18 @@ bool mfma_f16_range_ok(const rn_potgnn *h) {
   const PackedLayout &L = h->lay;
   const float *o = h->packed.data();
   const int Fe = h->d.Fe, HP = std::max(h->d.FeP, 32);
-  for (const MfmaScaleOp &m : mfma_scale_ops(h))
+  // While the device weights are ahead of `packed` (device-resident training) only the readout block, c3_norm_1 and the
+  // prescale pairs have been fetched: the finiteness of the weight blocks is then read off the pairs, which the device
+  // refresh sets to NaN for a block with a non-finite entry (kernels_train.hip, kind 2)
+  for (const MfmaScaleOp &m : mfma_scale_ops(h)) {
+    if (!std::isfinite(o[m.dst]) || !std::isfinite(o[m.dst + 1])) return false;
+    if (h->host_stale) continue;
     for (int k = 0; k < m.K; ++k)
       for (int n = 0; n < m.N; ++n)
         if (!std::isfinite(o[m.src + (size_t)k * m.ld + n])) return false;
+  }
+  for (const MfmaScaleOp &m : centred_scale_ops(h))
+    if (!std::isfinite(o[m.dst]) || !std::isfinite(o[m.dst + 1])) return false;
   const double ln2 = 0.6931471805599453;
   double b1 = ln2, b2 = ln2;
   for (int n = 0; n < Fe; ++n) {  // BatchNorm(eval) folded as setup_kernel does
@@ -1570,7 +1586,12 @@ void unpack_grads(const rn_potgnn *h, const T *gp, T *out, bool buffers /* true:
   copy(L.b5, 12);
 }
 
+// Every entry point that touches a handle runs inside guarded(): calls on ONE handle are serialised by the handle's own
+// lock (they share its workspaces, streams and tape), so a handle may be used from several threads; distinct handles are
+// independent.  No exception leaves the C ABI.
 int guarded(rn_potgnn *h, const std::function<void()> &fn) {
+  std::unique_lock<std::recursive_mutex> lock;
+  if (h) lock = std::unique_lock<std::recursive_mutex>(h->lock);
   try {
     if (h) HIP_TRY(hipSetDevice(h->cfg.device));
     fn();
@@ -1581,6 +1602,12 @@ int guarded(rn_potgnn *h, const std::function<void()> &fn) {
   } catch (const std::bad_alloc &) {
     set_error(h, "host allocation failed");
     return RN_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception &e) {
+    set_error(h, "internal error: %s", e.what());
+    return RN_ERR_HIP;
+  } catch (...) {
+    set_error(h, "internal error: unknown exception");
+    return RN_ERR_HIP;
   }
 }
 }  // namespace
@@ -2106,7 +2133,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     int chunk = cfg->max_chunk_structures;
     if (const char *e = getenv("RN_POTGNN_CHUNK")) chunk = atoi(e);
     if (chunk <= 0) {
-      const size_t per = per_structure_elems(hp) * sizeof(float);
+      const size_t per = per_structure_elems(hp, lean_workspace(hp)) * sizeof(float);
       size_t budget = (hp->use_fused || hp->use_narrow) ? ((size_t)8192 << 20) : ((size_t)1536 << 20);
       size_t free_b = 0, total_b = 0;  // on a shared GPU: at most 1/8 of what is free right now
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
@@ -2553,17 +2580,21 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
                         w + L.scale0, w + L.shift0, st);
     HIP_TRY(hipGetLastError());
     // the triplet loop's folded-scale variant is chosen on the host from c3_norm_1: fetch those 4 P FeP floats
-    for (const auto &q : L.pass)  // (scale then shift, adjacent in the packed layout: one copy per pass)
+    for (const auto &q : L.pass) {  // (scale then shift, adjacent in the packed layout: one copy per pass)
       HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 4 * (size_t)h->d.FeP * sizeof(float),
                              hipMemcpyDeviceToHost, st));
+      // ... and the prescale pairs, which double as the finiteness flags of the weight blocks (mfma_f16_range_ok)
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.mfma_scale, w + q.mfma_scale, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.mfma_scale_c, w + q.mfma_scale_c, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     {  // ... and the split-f16 range guard reads the readout block (W0T .. b5, contiguous in the layout)
       const size_t lo = L.W0T, hi = L.b5 + 32;
       HIP_TRY(hipMemcpyAsync(h->packed.data() + lo, w + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    h->host_stale = true;
     refresh_pass_flags<float>(h);
     refresh_mfma_mode(h);
-    h->host_stale = true;
     h->grads_on_device = false;
   });
 }

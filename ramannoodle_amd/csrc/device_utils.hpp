@@ -65,7 +65,7 @@ __device__ __forceinline__ float gate(float f, float c) {
 // float64: the same identity with one division, sigmoid(f) tanh(c) = expm1(2c) / ((1 + e^-f)(expm1(2c) + 2));
 // expm1 keeps tanh's relative accuracy near c = 0, and beyond |c| = 20 tanh is +-1 to 17 digits.
 __device__ __forceinline__ double gate(double f, double c) {
-  c = fmin(fmax(c, -20.0), 20.0);
+  c = c > 20.0 ? 20.0 : (c < -20.0 ? -20.0 : c);  // (comparisons, not fmin / fmax: a NaN input stays a NaN)
   const double em = expm1(2.0 * c);
   return em / ((1.0 + exp(-f)) * (em + 2.0));
 }

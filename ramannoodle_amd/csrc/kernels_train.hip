@@ -53,16 +53,24 @@ __global__ void refresh_derived_kernel(float *__restrict__ w, const DerivedOp *_
     if (op.kind == 2) {  // (uniform over the block)
       const int ld = (int)op.scale;
       float mx = 0.0f;
-      for (size_t i = threadIdx.x; i < (size_t)op.K * op.N; i += blockDim.x)
-        mx = fmaxf(mx, fabsf(w[op.src + (i / op.N) * ld + i % op.N]));
+      for (size_t i = threadIdx.x; i < (size_t)op.K * op.N; i += blockDim.x) {
+        const float v = fabsf(w[op.src + (i / op.N) * ld + i % op.N]);
+        mx = (v <= 3.0e38f) ? fmaxf(mx, v) : __builtin_nanf("");  // a non-finite weight poisons the maximum
+      }
       s_max[threadIdx.x] = mx;
       __syncthreads();
       for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + st]);
+        if ((int)threadIdx.x < st) {
+          const float a = s_max[threadIdx.x], b = s_max[threadIdx.x + st];
+          s_max[threadIdx.x] = (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b);
+        }
         __syncthreads();
       }
       if (threadIdx.x == 0) {
-        const float sc = mfma_prescale(s_max[0]);
+        // (s, 1/s) = (NaN, NaN) marks a block with a non-finite entry: the host's range guard (api.hip:
+        // mfma_f16_range_ok) reads the pairs back after a device-resident step and falls back to exact f32
+        const float m = s_max[0];
+        const float sc = (m != m) ? m : mfma_prescale(m);
         w[op.dst] = sc;
         w[op.dst + 1] = 1.0f / sc;
       }

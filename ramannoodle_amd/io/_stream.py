@@ -13,6 +13,7 @@ import ctypes as C
 import threading
 
 import numpy as np
+import torch
 
 from ramannoodle_amd import _lib
 
@@ -49,7 +50,9 @@ def stream_polarizabilities(model, reader, chunk_frames: int = 2000) -> np.ndarr
     ``VasprunReader``) holds, wrapped into the cell as ``Trajectory`` does."""
     total, atoms = reader.num_frames, reader.num_atoms
     bounds = [(lo, min(lo + chunk_frames, total)) for lo in range(0, total, chunk_frames)]
-    pipelined = hasattr(model, "calc_polarizabilities_async")
+    # the pipelined entry evaluates in float32; under torch.set_default_dtype(float64) the evaluation follows the
+    # default dtype as calc_polarizabilities does (_gnn.py:705-710), block by block through the synchronous call
+    pipelined = hasattr(model, "calc_polarizabilities_async") and torch.get_default_dtype() != torch.float64
     pinned = []
     if pipelined:
         device = model.device_index

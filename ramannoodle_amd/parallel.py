@@ -83,6 +83,10 @@ def calc_raman_tensors_sharded(model, ref_positions: np.ndarray, displacements: 
     block's ``2 M_local`` displaced cells, so the block goes into the all-gather without leaving HBM."""
     if not (dist.is_available() and dist.is_initialized()):
         return model.calc_raman_tensors(ref_positions, displacements, **kwargs)
+    # the same checks as the host entry, on EVERY rank and before any rank-dependent branch: a bad argument raises
+    # everywhere instead of on the ranks that own a block while the others wait in the all-gather
+    if hasattr(model, "_check_raman_arguments"):
+        model._check_raman_arguments(ref_positions, displacements, **kwargs)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = displacements.shape[0]
     lo, hi, _ = shard_bounds(total, world, rank)

@@ -413,10 +413,12 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             _lib.check(rc, self._handle, "rn_potgnn_wait")
 
     def calc_polarizabilities_device(self, positions: torch.Tensor, out: torch.Tensor | None = None,
-                                     synchronize: bool = False, dtype=torch.float32) -> torch.Tensor:
+                                     synchronize: bool = False, dtype=None) -> torch.Tensor:
         """Same computation on a device-resident ``float64[S,N,3]`` tensor; returns a device
         ``float64[S,3,3]`` tensor.  Work is enqueued on torch's current stream.  ``dtype`` is the
-        arithmetic of the evaluation (``torch.float64``: the kernels instantiated for ``double``)."""
+        arithmetic of the evaluation, resolved exactly as ``calc_polarizabilities`` does: ``None`` follows
+        ``torch.get_default_dtype()`` (``_gnn.py:705-710``), ``torch.float64`` runs the kernels instantiated
+        for ``double`` -- so the host, gloo and RCCL paths of ``ramannoodle_amd.parallel`` agree."""
         if not (positions.is_cuda and positions.dtype == torch.float64 and positions.is_contiguous()):
             raise ValueError("positions must be a contiguous float64 device tensor")
         if positions.dim() != 3 or tuple(positions.shape[1:]) != (self.num_atoms, 3):
@@ -645,8 +647,7 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         ``method="analytic"``: ``2 (d alpha / d r) . d_m`` from one forward and one reverse
         pass (equal up to ``O(delta^2)``).
         """
-        verify_ndarray_shape("ref_positions", ref_positions, (self.num_atoms, 3))
-        verify_ndarray_shape("displacements", displacements, (None, self.num_atoms, 3))
+        self._check_raman_arguments(ref_positions, displacements, delta=delta, method=method)
         ref = np.ascontiguousarray(ref_positions, dtype=np.float64)
         disp = np.ascontiguousarray(displacements, dtype=np.float64)
         out = np.empty((disp.shape[0], 3, 3), dtype=np.float64)
@@ -663,6 +664,19 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         else:
             raise ValueError(f"unsupported method: {method}")
         return out
+
+    def _check_raman_arguments(self, ref_positions, displacements, delta: float = RAMAN_TENSOR_CENTRAL_DIFFERENCE,
+                               method: str = "finite-difference", **unknown) -> None:
+        """Argument checks of ``calc_raman_tensors`` (also run by ``parallel.calc_raman_tensors_sharded`` on every
+        rank before it branches, so that all ranks raise together)."""
+        if unknown:
+            raise TypeError(f"calc_raman_tensors() got unexpected keyword arguments: {sorted(unknown)}")
+        verify_ndarray_shape("ref_positions", ref_positions, (self.num_atoms, 3))
+        verify_ndarray_shape("displacements", displacements, (None, self.num_atoms, 3))
+        if method not in ("finite-difference", "analytic"):
+            raise ValueError(f"unsupported method: {method}")
+        if method == "finite-difference" and not (np.isfinite(delta) and float(delta) != 0.0):
+            raise ValueError(f"delta must be finite and non-zero, not {delta}")
 
     def alpha_jacobian(self, positions, float64: bool = True) -> NDArray[np.float64]:
         """``d vec6_k / d x_{n,c}`` of the standardised 6-vector at one structure,

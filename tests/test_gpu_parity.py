@@ -1300,3 +1300,107 @@ def test_bench_starts_its_own_ranks():
                          env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root, capture_output=True, text=True,
                          timeout=300)
     assert bad.returncode != 0 and "does not match WORLD_SIZE" in bad.stderr
+
+
+# ----------------------------------------------------------------------------- round 4
+@pytest.mark.parametrize("case, cutoff, fn, fe, passes, frames", [
+    ("rocksalt64_parity", 3.2, 64, 64, 2, 23),   # regular graph, several frames per workgroup, ragged last unit
+    ("triclinic20", 3.4, 64, 64, 2, 5),          # ragged graph: tiles and rounds of unequal size
+    ("triclinic20", 3.0, 40, 50, 2, 3),          # padded columns in both embeddings (PAD instantiation)
+    ("triclinic20", 2.2, 64, 33, 1, 2),          # atoms with very few neighbours: rounds of a handful of destinations
+])
+def test_role_split_edge_block_against_oracle_and_per_frame_kernel(monkeypatch, case, cutoff, fn, fe, passes, frames):
+    """The role-specialised fused EdgeBlock (producer + consumer waves, ``csrc/kernels_edge_ps.hip``) is what a 64-wide
+    float32 evaluation runs on; it agrees with the pinned oracle and with the per-frame kernel it replaces
+    (``RN_POTGNN_EDGE_PS=0``), and repeats bit for bit."""
+    from oracle import potgnn_oracle as O
+    g = load_golden(case)
+    rng = np.random.default_rng(5)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=frames)] + rng.normal(scale=2e-3, size=(frames,) + base.shape[1:])
+    model, oracle = _random_model(g, cutoff, fn, fe, passes, seed=fn * 13 + fe)
+    got = model.calc_polarizabilities(pos)
+    assert model.config_flags()["role_split_edge_block"]
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    assert _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos), got)
+    monkeypatch.setenv("RN_POTGNN_EDGE_PS", "0")
+    per_frame, _ = _random_model(g, cutoff, fn, fe, passes, seed=fn * 13 + fe)
+    old = per_frame.calc_polarizabilities(pos)
+    assert not per_frame.config_flags()["role_split_edge_block"]
+    assert _rel_err((got - oracle.mean) / oracle.std, (old - oracle.mean) / oracle.std) < REL
+
+
+def test_centred_weight_copies_follow_a_device_resident_step():
+    """The role-specialised EdgeBlock multiplies with copies of c3_linear / c2_linear centred over their output columns.
+    After a device-resident Adam step those copies are recomputed on the device (``refresh_derived_kernel`` kind 3):
+    an evaluation right after the steps equals the one of a fresh model built from the stepped ``state_dict()``."""
+    from ramannoodle_amd.pmodel import DeviceAdam
+    g = load_golden("triclinic20")
+    model, _ = _random_model(g, 3.0, 64, 64, 2, seed=77)
+    s = 4
+    pos = torch.tensor(g["pos_batch"][:s])
+    lat = torch.tensor(g["lattice"]).expand(s, 3, 3)
+    zs = torch.tensor(g["atomic_numbers"]).expand(s, -1)
+    targets = torch.tensor(np.random.default_rng(3).normal(size=(s, 6)), dtype=torch.float32)
+    _adam_run(model, DeviceAdam(model, lr=5e-3), lat, zs, pos, targets, 3)
+    after = model.calc_polarizabilities(g["pos_batch"][:6])   # device weights, device-centred copies
+    assert model.config_flags()["role_split_edge_block"]
+    fresh, _ = _random_model(g, 3.0, 64, 64, 2, seed=77)
+    fresh.load_state_dict(model.state_dict())                  # host-packed, host-centred copies
+    want = fresh.calc_polarizabilities(g["pos_batch"][:6])
+    np.testing.assert_allclose(after, want, rtol=0, atol=REL * np.abs(want).max())
+
+
+def test_device_entry_follows_the_default_dtype():
+    """``calc_polarizabilities_device(dtype=None)`` resolves the arithmetic as ``calc_polarizabilities`` does
+    (``torch.get_default_dtype()``, ``_gnn.py:705-710``), so the RCCL path of ``parallel.calc_polarizabilities_sharded``
+    returns what the host and gloo paths return under ``set_default_dtype(float64)``."""
+    g = load_golden("rocksalt64_parity")
+    model = product_model_from_golden(g)
+    pos = g["pos_batch"][:6]
+    dev = torch.tensor(pos, device="cuda")
+    host32 = model.calc_polarizabilities(pos)
+    np.testing.assert_array_equal(model.calc_polarizabilities_device(dev, synchronize=True).cpu().numpy(), host32)
+    torch.set_default_dtype(torch.float64)
+    try:
+        host64 = model.calc_polarizabilities(pos)
+        dev64 = model.calc_polarizabilities_device(dev, synchronize=True).cpu().numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    np.testing.assert_array_equal(dev64, host64)
+    assert np.abs(host64 - host32).max() > 0  # (the two arithmetics do differ: the test can tell them apart)
+    if "f64/alpha" in g.files:
+        assert _rel_err(dev64, g["f64/alpha"][:6]) < 1e-9
+
+
+def test_two_threads_on_two_handles_and_on_one():
+    """C-ABI threading contract (``include/rn_potgnn.h``): distinct handles run concurrently from distinct threads; calls
+    on ONE handle from several threads are serialised by the handle's lock.  Either way every thread gets the
+    single-threaded result."""
+    import threading
+    g = load_golden("rocksalt64_parity")
+    a, _ = _random_model(g, 3.2, 64, 64, 2, seed=1)
+    b, _ = _random_model(g, 3.2, 64, 64, 2, seed=2)
+    pos = np.concatenate([g["pos_batch"]] * 8)
+    want = {"a": a.calc_polarizabilities(pos), "b": b.calc_polarizabilities(pos)}
+    assert np.abs(want["a"] - want["b"]).max() > 0
+    results, errors = {}, []
+
+    def run(key, model, reps):
+        try:
+            for r in range(reps):
+                results[(key, threading.get_ident(), r)] = (key, model.calc_polarizabilities(pos))
+        except BaseException as exc:  # pylint: disable=broad-except
+            errors.append(exc)
+
+    threads = [threading.Thread(target=run, args=("a", a, 3)), threading.Thread(target=run, args=("b", b, 3)),
+               threading.Thread(target=run, args=("a", a, 3))]   # the third shares handle `a` with the first
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 9
+    for key, got in results.values():
+        np.testing.assert_array_equal(got, want[key])

@@ -171,3 +171,49 @@ def test_data_parallel_epoch_equals_single_process(tmp_path, world, items):
             torch.testing.assert_close(got["state"][k], v, rtol=1e-5, atol=1e-6)
         assert got["losses"][0] == pytest.approx(want[0], rel=1e-5)
         assert got["losses"][1] == pytest.approx(want[1], rel=1e-5)
+
+
+class _CheckedModel(_Model):
+    """Stand-in with the argument checks the device model runs (``PotGNN._check_raman_arguments``)."""
+
+    def _check_raman_arguments(self, ref_positions, displacements, delta=1e-3, method="finite-difference", **unknown):
+        if unknown:
+            raise TypeError(f"unexpected keyword arguments: {sorted(unknown)}")
+        if displacements.ndim != 3 or displacements.shape[1:] != ref_positions.shape:
+            raise ValueError("displacements has wrong shape")
+        if delta == 0:
+            raise ValueError("delta must be non-zero")
+
+
+def _bad_argument_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, total = 5, 1  # ONE mode over two ranks: rank 1 owns an empty block
+        pos = np.random.default_rng(1).uniform(size=(n, 3))
+        disp = np.random.default_rng(2).normal(size=(total, n, 3))
+        raised = []
+        for kwargs, bad_disp in (({"delta": 0.0}, disp), ({"delat": 1e-3}, disp), ({}, disp[:, :-1])):
+            try:
+                calc_raman_tensors_sharded(_CheckedModel(n), pos, bad_disp, **kwargs)
+                raised.append("none")
+            except (ValueError, TypeError) as exc:
+                raised.append(type(exc).__name__)
+        # and a good call still works afterwards (nobody is stuck in a collective)
+        good = calc_raman_tensors_sharded(_CheckedModel(n), pos, disp, delta=1e-2)
+        assert good.shape == (total, 3, 3)
+        with open(os.path.join(out_dir, f"bad{rank}.txt"), "w") as f:
+            f.write(",".join(raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bad_arguments_raise_on_every_rank(tmp_path):
+    """the sharded phonon entry validates on EVERY rank before it branches on the rank's block, so a bad
+    ``delta``, shape or keyword raises everywhere -- also on a rank whose block is empty -- instead of leaving the
+    other ranks waiting in the all-gather."""
+    port = _free_port()
+    mp.spawn(_bad_argument_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"bad{r}.txt").read_text() == "ValueError,TypeError,ValueError"
