@@ -37,6 +37,10 @@ HPARAMS = {
     # name: (Fn, Fe, P)
     "perf": (64, 64, 4),
     "parity": (5, 14, 4),  # the only documented set (machine-learning.ipynb:187-192)
+    # rows of exactly one 64-byte line (16 floats): the narrow kernels' algorithmic bytes ARE their HBM lines, so this is
+    # the set on which the NodeBlock scatter-aggregate shows what it streams (north star: >= 40 % of the HBM peak)
+    "line16": (16, 16, 4),
+    "n8e16": (8, 16, 4),
 }
 EDGE_AGG_KERNEL_ID = 7  # index of "edge_agg" in rn_potgnn_kernel_times / csrc/api.hip
 PROJ_C3_KERNEL_ID = 5   # "proj_edge_c3": the [E,64]x[64,256] projection (HBM-bound; unfused pipeline)

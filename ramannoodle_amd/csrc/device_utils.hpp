@@ -209,33 +209,43 @@ __device__ __forceinline__ void split_f16x8(const float *x, f16x8 &hi, f16x8 &lo
   }
 }
 // acc += A * B over one K = 32 slice (8 k per lane), smallest terms first.
-// Each product is issued as TWO v_mfma_f32_16x16x16_f16 (the halves of the 8-element fragments; A
-// and B use the same lane-local element order, so the k pairing is consistent), not as one
-// v_mfma_f32_16x16x32_f16: with the K = 32 instruction (new on gfx950) the fused EdgeBlock was not
-// reproducible under hipcc / ROCm 7.2 -- repeated evaluations of one trajectory differed in 0.03-3 %
-// of the frames (one destination row slightly off), whatever staged the operands (LDS-DMA or
-// registers) and whichever conversion instructions built the fragments; with the K = 16 instruction
-// 60 000 frames repeat bit for bit (profiles/r02/determinism.txt).  The matrix pipe is a few percent
-// of these kernels' time either way.
+// K32 = true: one v_mfma_f32_16x16x32_f16 (new on gfx950) per product.  K32 = false: each product as TWO
+// v_mfma_f32_16x16x16_f16 (the halves of the 8-element fragments; A and B use the same lane-local element order, so the k
+// pairing is consistent) at half the matrix-pipe rate.
+//
+// History (profiles/r02/determinism.txt, r03/determinism.txt, r04/mfma_k32.txt): with the K = 32 instruction the per-frame
+// fused EdgeBlock (edge_block_fused_kernel: two 4-wave workgroups per CU, every wave both multiplies and runs the triplet
+// loop) is not reproducible under hipcc / ROCm 7.2 -- ~80 % of the frames of a 10 000-frame trajectory differ between two
+// evaluations -- while every other kernel of the library is: round 4 re-ran the probe on the K = 32 build with the
+// role-specialised EdgeBlock (one workgroup per CU, MFMAs only in the producer waves) and found 0 differing frames in
+// 5 x 4 x 10 000 evaluations (fused NodeBlock at four workgroups per CU, fused readout, split projections, unfused chain).
+// So K = 32 is the default everywhere EXCEPT in edge_block_fused_kernel, which keeps the two-instruction form
+// (WaveB::product_split16) and stays bit-reproducible; -DRN_MFMA_K32=0 builds the whole library on K = 16.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef RN_MFMA_K32
-#define RN_MFMA_K32 0
+#define RN_MFMA_K32 1
 #endif
-__device__ __forceinline__ f32x4_t mfma_split3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh,
-                                               const f16x8 &bl, f32x4_t acc) {
-#if RN_MFMA_K32  // experiment only (see above): one K = 32 instruction per product
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-#endif
-  const f16x4 ah0 = ah.lo, ah1 = ah.hi, al0 = al.lo, al1 = al.hi;
-  const f16x4 bh0 = bh.lo, bh1 = bh.hi, bl0 = bl.lo, bl1 = bl.hi;
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al0, bh0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al1, bh1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah0, bl0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah1, bl1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah0, bh0, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah1, bh1, acc, 0, 0, 0);
+template <bool K32>
+__device__ __forceinline__ f32x4_t mfma_split3_t(const f16x8 &ah, const f16x8 &al, const f16x8 &bh, const f16x8 &bl,
+                                                 f32x4_t acc) {
+  if constexpr (K32) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  } else {
+    const f16x4 ah0 = ah.lo, ah1 = ah.hi, al0 = al.lo, al1 = al.hi;
+    const f16x4 bh0 = bh.lo, bh1 = bh.hi, bl0 = bl.lo, bl1 = bl.hi;
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al0, bh0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al1, bh1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah0, bl0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah1, bl1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah0, bh0, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(ah1, bh1, acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ f32x4_t mfma_split3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh, const f16x8 &bl,
+                                               f32x4_t acc) {
+  return mfma_split3_t<(RN_MFMA_K32 != 0)>(ah, al, bh, bl, acc);
 }
 
 }  // namespace rn

@@ -88,6 +88,7 @@ struct WaveB<false> {  // exact f32: v_mfma_f32_16x16x4_f32, k = 16 quad + step
 #pragma unroll
       for (int k = 0; k < KS; ++k) w[t][k] = W[(size_t)(quad * KS + k) * ld + colbase + 16 * t + l15];
   }
+  template <bool K32_unused = false>  // (same call syntax as the split-f16 form)
   __device__ __forceinline__ void product(const float (&af)[KS], f32x4 (&acc)[2]) const {
 #pragma unroll
     for (int k = 0; k < KS; ++k)
@@ -111,18 +112,21 @@ struct WaveB<true> {  // split f16 (device_utils.hpp: mfma_split3), K = 32 slice
         split_f16x8(tmp, h[t][s], l[t][s]);
       }
   }
+  template <bool K32 = (RN_MFMA_K32 != 0)>
   __device__ __forceinline__ void product(const float (&af)[KS], f32x4 (&acc)[2]) const {
     f16x8 ah[2], al[2];
     split_f16x8(af, ah[0], al[0]);
     split_f16x8(af + 8, ah[1], al[1]);
-    product_split(ah, al, acc);
+    product_split<K32>(ah, al, acc);
   }
   // the same with an A operand that is already split (slice s = k 16 quad + 8 s .. + 7)
+  // (K32 = false: the two-instruction form, device_utils.hpp -- what edge_block_fused_kernel must use)
+  template <bool K32 = (RN_MFMA_K32 != 0)>
   __device__ __forceinline__ void product_split(const f16x8 (&ah)[2], const f16x8 (&al)[2], f32x4 (&acc)[2]) const {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t] = mfma_split3(h[t][s], l[t][s], ah[s], al[s], acc[t]);
+      for (int t = 0; t < 2; ++t) acc[t] = mfma_split3_t<K32>(h[t][s], l[t][s], ah[s], al[s], acc[t]);
   }
 };
 

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
           af[s4] = v.x; af[s4 + 1] = v.y; af[s4 + 2] = v.z; af[s4 + 3] = v.w;
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        bW5.product(af, acc);
+        bW5.template product<false>(af, acc);  // K = 16 MFMAs in this kernel: device_utils.hpp
         if (const int r = mt * 16 + l15; r < rows) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -278,9 +278,9 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
         if constexpr (F16) {
           f16x8 ah[2], al[2];
           load_split_a(atile, l15, quad, ah, al);
-          bW4.product_split(ah, al, accP);
+          bW4.template product_split<false>(ah, al, accP);
           load_split_a(atile + NG * FP, l15, quad, ah, al);
-          bWc.product_split(ah, al, accC);
+          bWc.template product_split<false>(ah, al, accC);
         } else {
           float af[KS];
 #pragma unroll

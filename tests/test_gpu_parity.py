@@ -514,14 +514,20 @@ def test_fused_edge_block_equals_unfused(monkeypatch):
     np.testing.assert_array_equal(seq, unfused)
 
 
-def test_repeated_evaluation_is_bit_identical():
+@pytest.mark.parametrize("edge_ps", ["1", "0"])
+def test_repeated_evaluation_is_bit_identical(monkeypatch, edge_ps):
     """No kernel uses atomics: evaluating the same frames again must give the same bits, whichever
-    workgroup a frame lands in.  (The first split-f16 build of round 2 -- on the K = 32 f16 MFMA --
-    failed this in ~0.5 % of the frames; profiles/r02/determinism.txt.)  Perf and parity widths."""
+    workgroup a frame lands in.  Perf and parity widths; with the role-specialised EdgeBlock (the default, split
+    products on the K = 32 f16 MFMA like every other kernel) and with the per-frame EdgeBlock kernel
+    (``RN_POTGNN_EDGE_PS=0``), the one kernel that is NOT reproducible on the K = 32 instruction and therefore keeps
+    the two-instruction K = 16 form (``device_utils.hpp``; profiles/r02-r04)."""
     from bench import make_workload
+    monkeypatch.setenv("RN_POTGNN_EDGE_PS", edge_ps)
     for hparams, frames in (("perf", 3000), ("parity", 3000)):
         wl = make_workload(num_cells=(4, 4, 2), frames=frames, hparams=hparams, seed=33)
         model = wl["model"]()
+        if hparams == "perf":
+            assert model.config_flags()["role_split_edge_block"] == (edge_ps == "1")
         first = model.calc_polarizabilities(wl["positions"])
         for _ in range(2):
             np.testing.assert_array_equal(model.calc_polarizabilities(wl["positions"]), first)
