@@ -188,6 +188,15 @@ int rn_potgnn_forward_samples(rn_potgnn *h, const double *lattices, const int32_
                               const double *positions, int64_t S, float *vec6);
 
 /*
+ * The same on DEVICE buffers (PotGNN.forward with CUDA tensors: the reference returns its result on the device its
+ * inputs live on, _gnn.py:617-665, test/tests/torch/test_gnn.py:130-160): d_lattices device f32[S*9] or NULL,
+ * d_atom_types device int32[S*N] or NULL (already validated by the caller: entries in [0, num_atom_types)),
+ * d_positions device f64[S*N*3] -> d_vec6 device f32[S*6]; work is enqueued on `stream`.
+ */
+int rn_potgnn_forward_samples_device(rn_potgnn *h, const float *d_lattices, const int32_t *d_atom_types,
+                                     const double *d_positions, int64_t S, float *d_vec6, void *stream, int synchronize);
+
+/*
  * Replaces the finite-difference loop of Phonons.get_raman_spectrum
  * (ramannoodle/dynamics/_phonon.py:93-106) with ONE batched evaluation of the 2M
  * displaced cells in double precision on the device:
@@ -243,6 +252,18 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
  * (Gaussian offsets, running statistics) are zero.
  */
 int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads);
+
+/*
+ * rn_potgnn_train_forward with a lattice and / or atom types PER SAMPLE (training-mode PotGNN.forward accepts any
+ * lattice[S,3,3] and atomic_numbers[S,N], _gnn.py:603-611, 541-557): `lattices` host f64[S*9] or NULL, `atom_types` host
+ * int32[S*N] or NULL, as for rn_potgnn_forward_samples.  The following rn_potgnn_train_backward(_device) differentiates
+ * that forward (the embedding gradient is summed per sample's atom types).  _f64: the float64 validation leg.
+ */
+int rn_potgnn_train_forward_samples(rn_potgnn *h, const double *lattices, const int32_t *atom_types, const double *positions,
+                                    int64_t S, float *vec6, float *batch_mean, float *batch_var);
+int rn_potgnn_train_forward_samples_f64(rn_potgnn *h, const double *lattices, const int32_t *atom_types,
+                                        const double *positions, int64_t S, double *vec6, double *batch_mean,
+                                        double *batch_var);
 
 /*
  * Device-resident optimisation (_train.py:63-76 without host round trips).  With device training

@@ -287,11 +287,15 @@ def geometry(model: OracleModel, positions: torch.Tensor, faithful: bool, lattic
     return unit, dist
 
 
-def node_embedding(model: OracleModel, s: int):
+def node_embedding(model: OracleModel, s: int, atomic_numbers=None):
     """Embedding -> ssp -> Linear -> ssp -> Linear (ramannoodle/pmodel/torch/_gnn.py:508-514,
-    541-557, 642-643)."""
+    541-557, 642-643).  ``atomic_numbers`` ``[S,N]``: the species of every sample, flattened as
+    ``_convert_to_atom_type`` does (``_gnn.py:541-557``); ``None`` = the reference structure's."""
     sd = model.sd
-    z = torch.from_numpy(model.atomic_numbers.astype(np.int64)).repeat(s)
+    if atomic_numbers is None:
+        z = torch.from_numpy(model.atomic_numbers.astype(np.int64)).repeat(s)
+    else:
+        z = torch.as_tensor(np.asarray(atomic_numbers)).long().reshape(-1)
     types = model.atom_type_map[z].long()
     x = sd["_node_embedding.0.weight"][types]
     x = lin(sd, "_node_embedding.2", ssp(x))
@@ -344,7 +348,7 @@ def readout_mlp(sd, edge, train: bool = False):
 
 
 def forward(model: OracleModel, positions, faithful: bool = True, stages: dict | None = None,
-            grad: bool = False, train: bool = False, lattices=None):
+            grad: bool = False, train: bool = False, lattices=None, atomic_numbers=None):
     """Standardised polarizability 6-vectors ``[S,6]``
     (ramannoodle/pmodel/torch/_gnn.py:617-665).  ``grad=True`` keeps the autograd graph (used
     to check the device's reverse-mode Jacobian d alpha / d r)."""
@@ -354,7 +358,7 @@ def forward(model: OracleModel, positions, faithful: bool = True, stages: dict |
     sd = model.sd
     with torch.set_grad_enabled(grad):
         unit, dist = geometry(model, positions, faithful, lattices)
-        node = node_embedding(model, s)
+        node = node_embedding(model, s, atomic_numbers)
         edge = gaussian_rbf(model, dist)
         trip, off_e = batch_indices(model, s)
         if stages is not None:
@@ -418,15 +422,16 @@ def jacobian(model: OracleModel, positions_one: np.ndarray) -> np.ndarray:
     return np.array(rows)
 
 
-def train_gradients(model: OracleModel, positions: np.ndarray, targets: np.ndarray):
+def train_gradients(model: OracleModel, positions: np.ndarray, targets: np.ndarray, lattices=None, atomic_numbers=None):
     """One training step's forward/backward (``_train.py:63-73`` with ``MSELoss``): returns
-    ``(out [S,6], loss, {parameter name: gradient})`` by torch autograd."""
+    ``(out [S,6], loss, {parameter name: gradient})`` by torch autograd.  ``lattices`` ``[S,3,3]`` /
+    ``atomic_numbers`` ``[S,N]``: per-sample inputs of ``forward`` (``_gnn.py:603-611, 541-557``)."""
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(
         ("offset", "running_mean", "running_var")) else v) for k, v in model.sd.items()}
     m = OracleModel(model.lattice, model.atomic_numbers, model.edges, model.trip, model.atom_type_map,
                     sd, model.coefficient, model.fn, model.fe, model.passes, model.mean, model.std,
                     model.dtype)
-    out = forward(m, positions, faithful=False, grad=True, train=True)
+    out = forward(m, positions, faithful=False, grad=True, train=True, lattices=lattices, atomic_numbers=atomic_numbers)
     loss = F.mse_loss(out, torch.as_tensor(targets).type(out.dtype))
     loss.backward()
     grads = {k: v.grad.detach().numpy().copy() for k, v in sd.items()

@@ -71,6 +71,9 @@ SIGNATURES = {
     "rn_potgnn_adam_step": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]),
     "rn_potgnn_get_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "rn_potgnn_train_forward_f64": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
+    "rn_potgnn_train_forward_samples": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "rn_potgnn_train_forward_samples_f64": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "rn_potgnn_forward_samples_device": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int]),
     "rn_potgnn_train_backward_f64": (C.c_int, [_P, _P, _P]),
     "rn_potgnn_num_triplets": (C.c_int64, [_P]),
     "rn_potgnn_debug_triplets": (C.c_int, [_P, _P, _P, _P, _P, _P]),

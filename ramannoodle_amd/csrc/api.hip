@@ -193,6 +193,7 @@ struct rn_potgnn {
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
   int train_prec = 4;  // sizeof of the precision it ran in
+  bool train_lat = false, train_types = false;  // it ran with per-sample lattices / atom types (io_lat / io_types)
   bool tape_fused = true;
   // device-resident optimisation (rn_potgnn_adam_step): gradients stay in f32.grad, Adam moments and
   // the trainable mask live next to the weights; the host copy `packed` is refreshed on demand
@@ -1265,7 +1266,7 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     P.type_sums.ensure((size_t)h->cfg.num_atom_types * d.Fn * sizeof(T));
     launch_node_embed_bwd<T>(b[DN0 + cur], S, g, d, h->cfg.num_atom_types, Wd + L.emb, Wd + L.W2, Wd + L.b2,
                              Wd + L.W4, G + L.emb, G + L.W2, G + L.b2, G + L.W4, G + L.b4,
-                             P.type_sums.template as<T>(), st);
+                             P.type_sums.template as<T>(), c.d_types, st);
   }
   if (rv.d_dpos)
     launch_geom_bwd<T>(b[DE0 + cur], b[DUNIT], unit4, P.lattice.template as<T>(), P.offsets,
@@ -1293,11 +1294,13 @@ void ensure_tape(rn_potgnn *h, int S) {
 
 // forward of S frames on lane 0 with the per-pass embeddings recorded
 template <typename T>
-ChunkRun<T> taped_forward(rn_potgnn *h, const double *d_pos, int S) {
+ChunkRun<T> taped_forward(rn_potgnn *h, const double *d_pos, int S, const T *d_lat = nullptr, const int *d_types = nullptr) {
   Precision<T> &P = prec<T>(h);
   ensure_tape<T>(h, S);
   P.tape_on = true;
   ChunkRun<T> c(h, P.lanes[0], d_pos, S, nullptr, nullptr, nullptr);
+  c.d_lat = d_lat;      // [S][9] per-sample lattices or null (the reference structure's)
+  c.d_types = d_types;  // [S][N] per-sample atom types or null
   try {
     c.begin();
     for (int p = 0; p < h->cfg.num_message_passes; ++p) {
@@ -1405,7 +1408,8 @@ void sync_host(rn_potgnn *h) {
 // ---- training: forward with batch-statistics BatchNorm, then parameter gradients (float32 for
 // the product path; float64 for validating the reverse pass against float64 autograd)
 template <typename T>
-void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batch_mean, T *batch_var) {
+void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batch_mean, T *batch_var,
+                   const double *host_lat = nullptr /* [S][9] or null */, const int32_t *host_types = nullptr /* [S][N] or null */) {
   ensure_precision<T>(h);
   Precision<T> &P = prec<T>(h);
   const PackedLayout &L = h->lay;
@@ -1415,7 +1419,22 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
   const size_t pb = (size_t)S * g.N * 3 * sizeof(double);
   h->io_pos.ensure(pb);
   HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, pb, hipMemcpyHostToDevice));
-  ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), S);
+  // per-sample lattices (in the arithmetic of the run, as the reference's forward casts them) and atom types: the graph
+  // topology stays the reference structure's (_gnn.py:603-611, 541-557)
+  if (host_lat) {
+    std::vector<T> lat((size_t)S * 9);
+    for (size_t i = 0; i < lat.size(); ++i) lat[i] = (T)host_lat[i];
+    h->io_lat.ensure(lat.size() * sizeof(T));
+    HIP_TRY(hipMemcpy(h->io_lat.p, lat.data(), lat.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  if (host_types) {
+    h->io_types.ensure((size_t)S * g.N * sizeof(int32_t));
+    HIP_TRY(hipMemcpy(h->io_types.p, host_types, (size_t)S * g.N * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  h->train_lat = host_lat != nullptr;
+  h->train_types = host_types != nullptr;
+  ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), S, host_lat ? h->io_lat.as<T>() : nullptr,
+                                   host_types ? h->io_types.as<int>() : nullptr);
   hipStream_t st = c.st();
   const int64_t R = (int64_t)S * g.E;
   T *Wd = P.weights.template as<T>();
@@ -1491,6 +1510,8 @@ void train_backward(rn_potgnn *h, const T *dvec6, T *grads /* null: leave the gr
   if (S <= 0 || h->train_prec != (int)sizeof(T))
     throw HipError{hipErrorInvalidValue, "train_backward without a train_forward of the same precision"};
   ChunkRun<T> c(h, P.lanes[0], h->io_pos.as<double>(), S, nullptr, nullptr, nullptr);
+  c.d_lat = h->train_lat ? h->io_lat.as<T>() : nullptr;      // what the pending train_forward ran with
+  c.d_types = h->train_types ? h->io_types.as<int>() : nullptr;
   hipStream_t st = c.st();
   DeviceBuf &seeds = P.seeds;
   seeds.ensure((size_t)S * 6 * sizeof(T));
@@ -2482,6 +2503,64 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
     return RN_ERR_INVALID_ARGUMENT;
   }
   return guarded(h, [&]() { train_forward<float>(h, positions, (int)S, vec6, batch_mean, batch_var); });
+}
+
+static int check_types(rn_potgnn *h, const int32_t *atom_types, int64_t S) {
+  if (!atom_types) return RN_OK;
+  const size_t SN = (size_t)S * h->cfg.num_atoms;
+  for (size_t i = 0; i < SN; ++i)
+    if (atom_types[i] < 0 || atom_types[i] >= h->cfg.num_atom_types) {
+      set_error(h, "atom type %d of sample %zu, atom %zu is outside [0,%d)", atom_types[i], i / h->cfg.num_atoms,
+                i % h->cfg.num_atoms, h->cfg.num_atom_types);
+      return RN_ERR_INVALID_ARGUMENT;
+    }
+  return RN_OK;
+}
+
+int rn_potgnn_train_forward_samples(rn_potgnn *h, const double *lattices, const int32_t *atom_types, const double *positions,
+                                    int64_t S, float *vec6, float *batch_mean, float *batch_var) {
+  if (!h || S <= 0 || !positions || !vec6 || !batch_mean || !batch_var) {
+    set_error(h, "invalid arguments to train_forward_samples");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S > h->chunk) {
+    set_error(h, "training batch of %lld frames exceeds max_chunk_structures = %d", (long long)S, h->chunk);
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (const int rc = check_types(h, atom_types, S); rc != RN_OK) return rc;
+  return guarded(h, [&]() { train_forward<float>(h, positions, (int)S, vec6, batch_mean, batch_var, lattices, atom_types); });
+}
+
+int rn_potgnn_train_forward_samples_f64(rn_potgnn *h, const double *lattices, const int32_t *atom_types,
+                                        const double *positions, int64_t S, double *vec6, double *batch_mean,
+                                        double *batch_var) {
+  if (!h || S <= 0 || !positions || !vec6 || !batch_mean || !batch_var) {
+    set_error(h, "invalid arguments to train_forward_samples_f64");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S > chunk_frames<double>(h)) {
+    set_error(h, "training batch of %lld frames exceeds the float64 chunk of %d frames", (long long)S, chunk_frames<double>(h));
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (const int rc = check_types(h, atom_types, S); rc != RN_OK) return rc;
+  return guarded(h, [&]() {
+    sync_host(h);
+    train_forward<double>(h, positions, (int)S, vec6, batch_mean, batch_var, lattices, atom_types);
+  });
+}
+
+int rn_potgnn_forward_samples_device(rn_potgnn *h, const float *d_lattices, const int32_t *d_atom_types,
+                                     const double *d_positions, int64_t S, float *d_vec6, void *stream, int synchronize) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!d_positions || !d_vec6))) {
+    set_error(h, "invalid positions / vec6 / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    forward_device<float>(h, d_positions, S, nullptr, d_vec6, nullptr, (hipStream_t)stream, synchronize != 0, d_lattices,
+                          d_atom_types);
+  });
 }
 
 int rn_potgnn_train_forward_f64(rn_potgnn *h, const double *positions, int64_t S, double *vec6,

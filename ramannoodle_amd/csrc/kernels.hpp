@@ -239,7 +239,8 @@ void launch_bn_bwd_apply(T *d, const T *z, int64_t R, int W, int F, const double
 template <typename T>
 void launch_node_embed_bwd(const T *dnode0, int S, const Graph &g, Dims d, int K, const T *emb,
                            const T *W2, const T *b2, const T *W4, T *demb, T *dW2, T *db2, T *dW4,
-                           T *db4, T *type_sums_scratch, hipStream_t st);
+                           T *db4, T *type_sums_scratch,
+                           const int *types /* [S*N] atom type per (sample, atom), or null: g.atom_type */, hipStream_t st);
 template <typename T>
 void launch_geom_bwd(const T *dedge0, const T *dunit, const T *unit4, const T *lat, const T *offs,
                      T coef, int C, int B, const Graph &g, Dims d, double *dpos, hipStream_t st);

@@ -2251,8 +2251,8 @@ RN_BN_INST(double)
 // then one atomic per (type, column) and block.
 template <typename T>
 __global__ void type_col_sums_kernel(const T *__restrict__ dnode0, int64_t R, int N, int FnP, int Fn, int K,
-                                     const int *__restrict__ atom_type, T *__restrict__ sums,
-                                     int rows_per_block) {
+                                     const int *__restrict__ atom_type /* [N], or [R] when per_sample */, int per_sample,
+                                     T *__restrict__ sums, int rows_per_block) {
   extern __shared__ unsigned char smem_raw[];
   T *acc = reinterpret_cast<T *>(smem_raw);  // [K][Fn]
   const int o = threadIdx.x;
@@ -2261,7 +2261,7 @@ __global__ void type_col_sums_kernel(const T *__restrict__ dnode0, int64_t R, in
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
   for (int64_t r = r0; r < r1; ++r) {
-    const int k = atom_type[r % N];
+    const int k = per_sample ? atom_type[r] : atom_type[r % N];
     if (k >= 0 && k < K) acc[k * Fn + o] += dnode0[r * FnP + o];
   }
   for (int k = 0; k < K; ++k) atomicAdd(sums + k * Fn + o, acc[k * Fn + o]);
@@ -2331,23 +2331,24 @@ __global__ void node_embed_bwd_kernel(const T *__restrict__ type_sums, int S, Gr
 template <typename T>
 void launch_node_embed_bwd(const T *dnode0, int S, const Graph &g, Dims d, int K, const T *emb,
                            const T *W2, const T *b2, const T *W4, T *demb, T *dW2, T *db2, T *dW4,
-                           T *db4, T *sums /* scratch [K * Fn] */, hipStream_t st) {
+                           T *db4, T *sums /* scratch [K * Fn] */,
+                           const int *types /* [S*N] atom type per (sample, atom), or null: g.atom_type */, hipStream_t st) {
   const size_t lds = (size_t)4 * K * d.Fn * sizeof(T);
   const size_t need = (size_t)K * d.Fn * sizeof(T);
   (void)hipMemsetAsync(sums, 0, need, st);
   const int64_t R = (int64_t)S * g.N;
   const int rpb = 64, threads = (d.Fn + 63) / 64 * 64;
   type_col_sums_kernel<T><<<(unsigned)((R + rpb - 1) / rpb), threads, need, st>>>(
-      dnode0, R, g.N, d.FnP, d.Fn, K, g.atom_type, sums, rpb);
+      dnode0, R, g.N, d.FnP, d.Fn, K, types ? types : g.atom_type, types ? 1 : 0, sums, rpb);
   node_embed_bwd_kernel<T><<<1, 256, lds, st>>>(sums, S, g, d, K, emb, W2, b2, W4, demb, dW2, db2, dW4,
                                                 db4);
 }
 template void launch_node_embed_bwd<float>(const float *, int, const Graph &, Dims, int, const float *,
                                            const float *, const float *, const float *, float *,
-                                           float *, float *, float *, float *, float *, hipStream_t);
+                                           float *, float *, float *, float *, float *, const int *, hipStream_t);
 template void launch_node_embed_bwd<double>(const double *, int, const Graph &, Dims, int,
                                             const double *, const double *, const double *,
                                             const double *, double *, double *, double *, double *,
-                                            double *, double *, hipStream_t);
+                                            double *, double *, const int *, hipStream_t);
 
 }  // namespace rn

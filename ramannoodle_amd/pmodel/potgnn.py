@@ -445,46 +445,96 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         """Standardised 6-vectors ``[S,6]`` (``_gnn.py:617-665``).  ``lattice`` ``[S,3,3]`` is
         used per sample in the geometry, as the reference does (``_gnn.py:603-611``), and
         ``atomic_numbers`` ``[S,N]`` per sample for the node embedding
-        (``_convert_to_atom_type``, ``_gnn.py:541-557,642-643``); the graph topology is the
-        reference structure's.  An atomic number the model has no atom type for raises
-        ``IndexError``, as the reference's ``Embedding`` does."""
-        pos = np.ascontiguousarray(torch.as_tensor(positions).detach().cpu().numpy(), dtype=np.float64)
-        verify_ndarray_shape("positions", pos, (None, self.num_atoms, 3))
-        lat = np.ascontiguousarray(torch.as_tensor(lattice).detach().cpu().numpy(), dtype=np.float64)
-        zs = torch.as_tensor(atomic_numbers).detach().cpu().numpy()
-        if lat.shape != (pos.shape[0], 3, 3) or zs.shape != (pos.shape[0], self.num_atoms):
+        (``_convert_to_atom_type``, ``_gnn.py:541-557,642-643``), in evaluation AND in training mode; the graph
+        topology is the reference structure's.  An atomic number the model has no atom type for raises
+        ``IndexError``, as the reference's ``Embedding`` does.
+
+        The result lives where the inputs live, as the reference's does (``_train.py:51-75`` moves a batch to the
+        device and takes the loss there; ``test/tests/torch/test_gnn.py:130-160``): CUDA tensors are evaluated in
+        place in HBM (``rn_potgnn_forward_samples_device``: no copy through the host) and a CUDA tensor comes back;
+        host tensors / arrays give a host tensor."""
+        pos_t, lat_t, zs_t = torch.as_tensor(positions), torch.as_tensor(lattice), torch.as_tensor(atomic_numbers)
+        s = pos_t.shape[0] if pos_t.dim() == 3 else -1
+        if pos_t.dim() != 3 or tuple(pos_t.shape[1:]) != (self.num_atoms, 3):
+            verify_ndarray_shape("positions", pos_t.detach().cpu().numpy(), (None, self.num_atoms, 3))
+        if tuple(lat_t.shape) != (s, 3, 3) or tuple(zs_t.shape) != (s, self.num_atoms):
             raise ValueError("lattice / atomic_numbers do not match positions")
-        same_species = (not pos.shape[0]) or np.array_equal(zs, np.broadcast_to(
+        on_device = pos_t.is_cuda or lat_t.is_cuda or zs_t.is_cuda
+        if on_device and not self.training:
+            return self._forward_on_device(lat_t, zs_t, pos_t)
+        out_device = next((t.device for t in (pos_t, lat_t, zs_t) if t.is_cuda), None)
+        pos = np.ascontiguousarray(pos_t.detach().cpu().numpy(), dtype=np.float64)
+        lat = np.ascontiguousarray(lat_t.detach().cpu().numpy(), dtype=np.float64)
+        zs = zs_t.detach().cpu().numpy()
+        same_species = (not s) or np.array_equal(zs, np.broadcast_to(
             np.asarray(self._ref_structure.atomic_numbers), zs.shape))
-        same_lattice = (not pos.shape[0]) or np.allclose(lat, self._ref_structure.lattice[None],
-                                                         rtol=1e-6, atol=1e-9)
+        same_lattice = (not s) or np.allclose(lat, self._ref_structure.lattice[None], rtol=1e-6, atol=1e-9)
+        types = None
+        if not same_species:
+            zi = zs.astype(np.int64)
+            if zi.min() < -self._atom_type_map.size or zi.max() >= self._atom_type_map.size:
+                raise IndexError("atomic number outside the atom type map")
+            types = np.ascontiguousarray(self._atom_type_map[zi], dtype=np.int32)
+            if types.min() < 0:
+                raise IndexError("index out of range in self: atomic_numbers holds a species the "
+                                 "model has no atom type for")
         if self.training:
-            if not same_lattice or not same_species:
-                raise NotImplementedError("training mode supports only the reference structure's lattice "
-                                          "and species (PolarizabilityDataset holds a single structure)")
+            extra = (None if same_lattice else lat, types)
             if self._device_training:  # gradients stay in HBM: nothing for autograd to route
-                return _TrainStep.apply(self, pos, self._device_anchor)
-            return _TrainStep.apply(self, pos, *self.parameters())
-        out = np.empty((pos.shape[0], 6), dtype=np.float32)
+                out = _TrainStep.apply(self, pos, extra, self._device_anchor)
+            else:
+                out = _TrainStep.apply(self, pos, extra, *self.parameters())
+            return out.to(out_device) if out_device is not None else out
+        out = np.empty((s, 6), dtype=np.float32)
         handle = self._ensure_handle()
         if same_lattice and same_species:
-            rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), pos.shape[0], _ptr(out))
+            rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), s, _ptr(out))
             _lib.check(rc, handle, "rn_potgnn_forward")
         else:
-            types = None
-            if not same_species:
-                zi = zs.astype(np.int64)
-                if zi.min() < -self._atom_type_map.size or zi.max() >= self._atom_type_map.size:
-                    raise IndexError("atomic number outside the atom type map")
-                types = np.ascontiguousarray(self._atom_type_map[zi], dtype=np.int32)
-                if types.min() < 0:
-                    raise IndexError("index out of range in self: atomic_numbers holds a species the "
-                                     "model has no atom type for")
             rc = _lib.load().rn_potgnn_forward_samples(
                 handle, None if same_lattice else _ptr(lat), None if types is None else _ptr(types),
-                _ptr(pos), pos.shape[0], _ptr(out))
+                _ptr(pos), s, _ptr(out))
             _lib.check(rc, handle, "rn_potgnn_forward_samples")
         return torch.from_numpy(out)
+
+    def _forward_on_device(self, lat_t: torch.Tensor, zs_t: torch.Tensor, pos_t: torch.Tensor) -> torch.Tensor:
+        """Evaluation-mode ``forward`` on device-resident inputs: every check and conversion is a torch operation on
+        the device, the kernels read the tensors where they are, the ``[S,6]`` result is a device tensor."""
+        device = next(t.device for t in (pos_t, lat_t, zs_t) if t.is_cuda)
+        if device.index is not None and self._device is not None and device.index != int(self._device):
+            raise ValueError(f"inputs live on {device}, the model evaluates on cuda:{int(self._device)}")
+        s = pos_t.shape[0]
+        pos = pos_t.detach().to(device=device, dtype=torch.float64).contiguous()
+        lat = lat_t.detach().to(device=device, dtype=torch.float64)
+        zs = zs_t.detach().to(device=device)
+        out = torch.empty((s, 6), dtype=torch.float32, device=device)
+        if s == 0:
+            return out
+        ref_lat = torch.as_tensor(np.asarray(self._ref_structure.lattice, dtype=np.float64), device=device)
+        ref_zs = torch.as_tensor(np.asarray(self._ref_structure.atomic_numbers), device=device).to(zs.dtype)
+        same_lattice = bool(torch.allclose(lat, ref_lat.expand_as(lat), rtol=1e-6, atol=1e-9))
+        same_species = bool(torch.equal(zs, ref_zs.expand_as(zs)))
+        lat32 = types = None
+        if not same_lattice:
+            lat32 = lat.to(torch.float32).reshape(s, 9).contiguous()  # the reference's forward computes in float32
+        if not same_species:
+            zi = zs.to(torch.int64)
+            size = self._atom_type_map.size
+            if int(zi.min()) < -size or int(zi.max()) >= size:
+                raise IndexError("atomic number outside the atom type map")
+            tmap = torch.as_tensor(np.asarray(self._atom_type_map, dtype=np.int32), device=device)
+            types = tmap[zi].contiguous()  # (negative atomic numbers index from the end, as numpy does on the host path)
+            if int(types.min()) < 0:
+                raise IndexError("index out of range in self: atomic_numbers holds a species the "
+                                 "model has no atom type for")
+        handle = self._ensure_handle()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = _lib.load().rn_potgnn_forward_samples_device(
+            handle, None if lat32 is None else C.c_void_p(lat32.data_ptr()),
+            None if types is None else C.c_void_p(types.data_ptr()), C.c_void_p(pos.data_ptr()), s,
+            C.c_void_p(out.data_ptr()), C.c_void_p(stream), 1)
+        _lib.check(rc, handle, "rn_potgnn_forward_samples_device")
+        return out
 
     # -- training step pieces used by _TrainStep ------------------------------------------
     def enable_data_parallel(self, group=None) -> None:
@@ -529,15 +579,21 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         _lib.check(rc, handle, "rn_potgnn_set_stat_reducer")
         self._dp_installed_on = (handle, id(callback))
 
-    def _train_forward(self, pos: np.ndarray) -> np.ndarray:
+    def _train_forward(self, pos: np.ndarray, lat: np.ndarray | None = None, types: np.ndarray | None = None) -> np.ndarray:
         handle = self._ensure_handle()
         self._install_reducer(handle)
         out = np.empty((pos.shape[0], 6), dtype=np.float32)
         mean = np.empty(self._fe, dtype=np.float32)
         var = np.empty(self._fe, dtype=np.float32)
-        rc = _lib.load().rn_potgnn_train_forward(handle, _ptr(pos), pos.shape[0], _ptr(out),
-                                                 _ptr(mean), _ptr(var))
-        _lib.check(rc, handle, "rn_potgnn_train_forward")
+        if lat is None and types is None:
+            rc = _lib.load().rn_potgnn_train_forward(handle, _ptr(pos), pos.shape[0], _ptr(out),
+                                                     _ptr(mean), _ptr(var))
+            _lib.check(rc, handle, "rn_potgnn_train_forward")
+        else:  # a lattice and / or atom types per sample (_gnn.py:603-611, 541-557)
+            rc = _lib.load().rn_potgnn_train_forward_samples(
+                handle, None if lat is None else _ptr(lat), None if types is None else _ptr(types), _ptr(pos),
+                pos.shape[0], _ptr(out), _ptr(mean), _ptr(var))
+            _lib.check(rc, handle, "rn_potgnn_train_forward_samples")
         if self._device_training:  # the library updated the running statistics where they live
             self._device_batches_tracked += 1
             self._device_ahead = True
@@ -602,10 +658,11 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         _lib.check(rc, self._handle, "rn_potgnn_adam_step")
         self._device_ahead = True
 
-    def train_gradients_f64(self, positions, targets):
+    def train_gradients_f64(self, positions, targets, lattice=None, atomic_numbers=None):
         """One training step's forward and backward in float64 on the device
         (``rn_potgnn_train_forward_f64`` / ``_backward_f64``) for an MSE loss against ``targets``
         ``[S,6]``: returns ``(out [S,6] float64, loss, {parameter name: gradient float64})``.
+        ``lattice`` ``[S,3,3]`` / ``atomic_numbers`` ``[S,N]``: per-sample inputs as ``forward`` takes them.
         Validation aid: what the float32 step is measured against; running statistics are not
         updated."""
         pos = np.ascontiguousarray(positions, dtype=np.float64)
@@ -617,8 +674,18 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         lib = _lib.load()
         out = np.empty((s, 6), dtype=np.float64)
         mean, var = np.empty(self._fe), np.empty(self._fe)
-        rc = lib.rn_potgnn_train_forward_f64(handle, _ptr(pos), s, _ptr(out), _ptr(mean), _ptr(var))
-        _lib.check(rc, handle, "rn_potgnn_train_forward_f64")
+        lat = None if lattice is None else np.ascontiguousarray(lattice, dtype=np.float64).reshape(s, 3, 3)
+        types = None
+        if atomic_numbers is not None:
+            types = np.ascontiguousarray(self._atom_type_map[np.asarray(atomic_numbers, dtype=np.int64)], dtype=np.int32)
+        if lat is None and types is None:
+            rc = lib.rn_potgnn_train_forward_f64(handle, _ptr(pos), s, _ptr(out), _ptr(mean), _ptr(var))
+            _lib.check(rc, handle, "rn_potgnn_train_forward_f64")
+        else:
+            rc = lib.rn_potgnn_train_forward_samples_f64(handle, None if lat is None else _ptr(lat),
+                                                         None if types is None else _ptr(types), _ptr(pos), s, _ptr(out),
+                                                         _ptr(mean), _ptr(var))
+            _lib.check(rc, handle, "rn_potgnn_train_forward_samples_f64")
         loss = float(np.mean((out - tgt) ** 2))
         dvec6 = np.ascontiguousarray(2.0 * (out - tgt) / out.size)
         blob = np.empty(sum(v.numel() for v in self._state.values() if v.is_floating_point()), dtype=np.float64)
@@ -779,18 +846,18 @@ class _TrainStep(torch.autograd.Function):
     parameter gradients."""
 
     @staticmethod
-    def forward(ctx, model, pos, *params):  # pylint: disable=arguments-differ
+    def forward(ctx, model, pos, extra, *params):  # pylint: disable=arguments-differ
         ctx.model = model
-        return torch.from_numpy(model._train_forward(pos))
+        return torch.from_numpy(model._train_forward(pos, *extra))
 
     @staticmethod
     def backward(ctx, grad_out):  # pylint: disable=arguments-differ
         dvec6 = np.ascontiguousarray(grad_out.detach().cpu().numpy(), dtype=np.float32)
         if ctx.model._device_training:
             ctx.model._train_backward_device(dvec6)
-            return (None, None, None)
+            return (None, None, None, None)
         grads = ctx.model._train_backward(dvec6)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class _DeviceSpan:  # pylint: disable=too-few-public-methods

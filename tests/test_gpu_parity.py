@@ -127,9 +127,6 @@ def test_forward_with_per_sample_lattices():
     same = model.forward(torch.tensor(g["lattice"]).expand(s, 3, 3), zs, torch.tensor(r["lat/positions"])).numpy()
     np.testing.assert_array_equal(same[0], out[0])          # sample 0 carries the reference lattice
     assert np.abs(same[1:] - out[1:]).max() > 1e3 * REL * scale  # the others really differ
-    model.train()
-    with pytest.raises(NotImplementedError, match="training mode supports only"):
-        model.forward(torch.tensor(r["lat/lattices"]), zs, torch.tensor(r["lat/positions"]))
 
 
 def test_forward_with_per_sample_atomic_numbers():
@@ -155,9 +152,6 @@ def test_forward_with_per_sample_atomic_numbers():
     unknown[2, 5] = 79  # the model has no atom type for gold: the reference's Embedding raises IndexError
     with pytest.raises(IndexError):
         model.forward(torch.tensor(lat), torch.tensor(unknown), torch.tensor(pos))
-    model.train()
-    with pytest.raises(NotImplementedError, match="training mode supports only"):
-        model.forward(torch.tensor(g["lattice"]).expand(len(zs), 3, 3), torch.tensor(zs), torch.tensor(pos))
 
 
 def test_calc_polarizabilities_in_float64(golden):
@@ -1410,3 +1404,74 @@ def test_two_threads_on_two_handles_and_on_one():
     assert len(results) == 9
     for key, got in results.values():
         np.testing.assert_array_equal(got, want[key])
+
+
+def test_forward_with_cuda_tensors_stays_on_the_device():
+    """``forward`` on CUDA tensors (the reference's ``test_gnn.py:130-160`` runs under ``set_default_device``; its
+    ``train_single_epoch`` moves every batch to the device, ``_train.py:51-75``): the inputs are read where they are, the
+    result is a CUDA tensor, and it equals the host path bit for bit -- reference lattice and species, per-sample
+    lattices, per-sample species."""
+    g, r2, r3 = load_golden("triclinic20"), load_golden("triclinic20_r2"), load_golden("triclinic20_r3")
+    model = product_model_from_golden(g).eval()
+    pos0 = g["pos_batch"][:6]
+    cases = [(np.broadcast_to(g["lattice"], (len(pos0), 3, 3)).copy(),
+              np.broadcast_to(g["atomic_numbers"], (len(pos0), len(g["atomic_numbers"]))).copy(), pos0),
+             (r2["lat/lattices"], np.broadcast_to(g["atomic_numbers"], (len(r2["lat/positions"]), len(g["atomic_numbers"]))).copy(),
+              r2["lat/positions"]),
+             (r3["zs/lattices"], r3["zs/atomic_numbers"], r3["zs/positions"])]
+    for lat, zs, pos in cases:
+        host = model.forward(torch.tensor(lat), torch.tensor(zs), torch.tensor(pos))
+        assert not host.is_cuda
+        dev = model.forward(torch.tensor(lat, device="cuda"), torch.tensor(zs, device="cuda"), torch.tensor(pos, device="cuda"))
+        assert dev.is_cuda and dev.dtype == torch.float32 and tuple(dev.shape) == (len(pos), 6)
+        np.testing.assert_array_equal(dev.cpu().numpy(), host.numpy())
+        # float32 device tensors (what a DataLoader of the reference's dataset yields) work as well
+        dev32 = model.forward(torch.tensor(lat, device="cuda", dtype=torch.float32), torch.tensor(zs, device="cuda"),
+                              torch.tensor(pos, device="cuda", dtype=torch.float32))
+        assert dev32.is_cuda
+    unknown = r3["zs/atomic_numbers"].copy()
+    unknown[1, 3] = 79
+    with pytest.raises(IndexError):
+        model.forward(torch.tensor(r3["zs/lattices"], device="cuda"), torch.tensor(unknown, device="cuda"),
+                      torch.tensor(r3["zs/positions"], device="cuda"))
+    # training mode: the loss can be taken on the device the batch lives on
+    model.train()
+    out = model.forward(torch.tensor(cases[0][0], device="cuda"), torch.tensor(cases[0][1], device="cuda"),
+                        torch.tensor(cases[0][2], device="cuda"))
+    assert out.is_cuda and out.requires_grad
+    torch.nn.MSELoss()(out, torch.zeros_like(out)).backward()
+    assert all(p.grad is not None for p in model.parameters())
+
+
+def test_training_gradients_with_per_sample_lattices_and_species():
+    """Training-mode ``forward`` takes any ``lattice[S,3,3]`` and ``atomic_numbers[S,N]`` (``_gnn.py:603-611, 541-557``):
+    float64 device step against float64 autograd through the oracle (which is pinned to the reference's outputs for these
+    very inputs, ``tests/test_oracle_golden.py``), and the float32 product step against the float64 one."""
+    from oracle import potgnn_oracle as O
+    g, r3 = load_golden("triclinic20"), load_golden("triclinic20_r3")
+    model = product_model_from_golden(g)
+    oracle = O.model_from_arrays(g).to(torch.float64)
+    oracle.coefficient = model.gauss_coefficient  # (the device model keeps the coefficient it was created with)
+    lat, zs, pos = r3["zs/lattices"], r3["zs/atomic_numbers"], r3["zs/positions"]
+    targets = np.random.default_rng(11).normal(size=(len(pos), 6))
+    out64, loss64, grads64 = model.train_gradients_f64(pos, targets, lattice=lat, atomic_numbers=zs)
+    o_out, o_loss, o_grads = O.train_gradients(oracle, pos, targets, lattices=lat, atomic_numbers=zs)
+    np.testing.assert_allclose(out64, o_out, rtol=0, atol=1e-9 * np.abs(o_out).max())
+    assert loss64 == pytest.approx(o_loss, rel=1e-9)
+    for name, ref in o_grads.items():
+        scale = np.abs(ref).max()
+        assert np.abs(grads64[name] - ref).max() < 1e-8 * scale + 1e-12, name
+    # ... and they are not the gradients of the reference lattice / species
+    plain = model.train_gradients_f64(pos, targets)[2]
+    assert max(np.abs(plain[k] - grads64[k]).max() / (np.abs(grads64[k]).max() + 1e-30) for k in grads64) > 1e-3
+    model.train()
+    out = model.forward(torch.tensor(lat), torch.tensor(zs), torch.tensor(pos))
+    torch.nn.MSELoss()(out, torch.tensor(targets, dtype=torch.float32)).backward()
+    np.testing.assert_allclose(out.detach().numpy(), out64, rtol=0, atol=2e-5 * np.abs(out64).max())
+    worst = 0.0
+    for name, p in model.named_parameters():
+        scale = np.abs(grads64[name]).max()
+        if scale < 1e-12:
+            continue
+        worst = max(worst, np.abs(p.grad.numpy() - grads64[name]).max() / scale)
+    assert worst < 1.5e-4, worst

@@ -87,6 +87,23 @@ def test_forward_with_per_sample_lattices_matches_reference():
     np.testing.assert_array_equal(plain[0], r["lat/forward"][0])
 
 
+def test_forward_with_per_sample_species_matches_reference():
+    """``forward(lattice, atomic_numbers[S,N], positions)`` with species that differ between samples
+    (``_convert_to_atom_type``, ``_gnn.py:541-557``): the oracle's ``atomic_numbers`` argument against the reference's
+    float32 and float64 outputs (fixture ``triclinic20_r3``: atoms swapped, one species replaced, strained lattices).
+    This pins what the training-gradient test with per-sample inputs differentiates."""
+    from tests.conftest import load_golden
+    g, r = load_golden("triclinic20"), load_golden("triclinic20_r3")
+    m = O.model_from_arrays(g)
+    out = O.forward(m, r["zs/positions"], faithful=True, lattices=r["zs/lattices"], atomic_numbers=r["zs/atomic_numbers"]).numpy()
+    np.testing.assert_allclose(out, r["zs/forward"], rtol=0, atol=3e-7)
+    m64 = O.model_from_arrays(g).to(torch.float64)
+    m64.coefficient = -0.5 / ((float(g["hp"][5]) - float(g["hp"][4])) / (int(g["hp"][2]) - 1)) ** 2
+    out64 = O.forward(m64, r["zs/positions"], faithful=False, lattices=r["zs/lattices"],
+                      atomic_numbers=r["zs/atomic_numbers"]).numpy()
+    np.testing.assert_allclose(out64, r["zs/forward64"], rtol=0, atol=1e-12)
+
+
 def test_forward_on_positions_far_outside_the_unit_cell():
     """The reference's own batch test feeds ``forward`` positions drawn from N(0,1)
     (``test/tests/torch/test_gnn.py:83-113``): fractional coordinates up to +-3, negative ones
