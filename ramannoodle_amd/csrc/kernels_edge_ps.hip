@@ -19,7 +19,8 @@
 // Three waves per SIMD, and no s_barrier after start-up: the roles meet through LDS words (an LDS atomic add to
 // signal, a relaxed poll with s_sleep to wait; a wave's LDS operations are performed in order):
 //   c_split / c_norm  the four producers among themselves (operand tiles split; projections written)
-//   c_ready           round g may be consumed (published by producer 0 once the rows' |q|^2 are complete)
+//   c_ready           round g may be consumed (published by the LAST producer to finish the step, once it has
+//                     completed the new rows' |q|^2 from the four producers' parts)
 //   c_done[g & 1]     consumer waves that finished round g -- a producer overwrites the buffers of round g only
 //                     after all eight waves finished round g - 2.
 // Q' lives in a RING of source-row tiles (PS_NRT x 16 rows): destinations are sorted by their atom and so are the
@@ -55,6 +56,11 @@ struct EdgePsArgs {
 // prints them after a synchronising call.  The product build compiles none of it.
 #ifndef RN_PS_TIMING
 #define RN_PS_TIMING 0
+#endif
+// Timing-only probe builds (results wrong by construction): -DRN_PS_PROBE=1 consumers skip the triplet loop (what is left is
+// the producers' pace), 2 producers skip their MFMA products, 4 consumers skip the epilogue arithmetic.
+#ifndef RN_PS_PROBE
+#define RN_PS_PROBE 0
 #endif
 #ifndef RN_PS_PRIO
 #define RN_PS_PRIO 2   // s_setprio of the producer waves (consumers: 0 in the triplet loop)
@@ -212,6 +218,13 @@ __device__ __forceinline__ void ps_arrive(unsigned word, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(word), "v"(1u) : "memory");
 }
+// the same, returning the count BEFORE this wave's arrival (wave-uniform): the last arriver knows it is the last
+__device__ __forceinline__ unsigned ps_arrive_ticket(unsigned word, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  unsigned old = 0;
+  if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(word), "v"(1u) : "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+}
 __device__ __forceinline__ void ps_publish(unsigned word, unsigned value, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(word), "v"(value) : "memory");
@@ -291,21 +304,34 @@ __device__ __forceinline__ void ps_load_split_a2(unsigned tile_addr, int l15, in
     al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
+// v[lane] + v[lane ^ 16] / v[lane] + v[lane ^ 32] on the VALU (v_permlane16_swap / v_permlane32_swap, new on gfx950): the
+// swap of a register with itself leaves (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3) -- resp. the two
+// halves -- in the result pair.  ds_swizzle / ds_bpermute do the same through the LDS crossbar at ~100 cycles of latency
+// per step, which is what the consumers' epilogue (five dependent reductions) and the producers' row norms were waiting on.
+__device__ __forceinline__ float sum_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over an aligned run of 32 lanes
+__device__ __forceinline__ float lg_sum32(float v) { return sum_xor16(lg_sum<16>(v)); }
 // LayerNorm of a row of logical width F spread over THIRTY-TWO lanes, two columns per lane (the two 16-lane halves
 // of a destination share the epilogue: each finishes half of the columns instead of both finishing all of them)
 template <bool PAD>
 __device__ __forceinline__ f32x2 ln_row2(f32x2 x, f32x2 g, f32x2 b, float inv_n, int nvalid) {
-  const float mean = lg_sum<32>(x.x + x.y) * inv_n;
+  const float mean = lg_sum32(x.x + x.y) * inv_n;
   f32x2 d = {x.x - mean, x.y - mean};
   if (PAD) {
     if (nvalid < 1) d.x = 0.f;
     if (nvalid < 2) d.y = 0.f;
   }
-  const float q = lg_sum<32>(d.x * d.x + d.y * d.y);
+  const float q = lg_sum32(d.x * d.x + d.y * d.y);
   const float rstd = fast_rsq(q * inv_n + 1e-5f);
   return f32x2{d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y};
 }
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 }  // namespace
 
 template <bool PAD>
@@ -510,7 +536,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         const int slot0 = (cur.g & 1) * PS_ND;
         f16x8 ah[2], al[2];
         ps_load_split_a(tb_a, l15, quad, ah, al);
-        bW4.product_split(ah, al, accP);
+        if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
 #pragma unroll
         for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3
           *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t] * inv4;
@@ -519,7 +545,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
                          accC[0], accC[1]);  // + the centred c2 bias
 #pragma unroll
         for (int t = 0; t < 2; ++t) accC[t] *= sc2;
-        bWc.product_split(ah, al, accC);
+        if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t] * invc2;
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         f32x4 g3v[2];
         ps_load_split_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (8 * FP + mycol) * 4,
                          lnp_a + (8 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3
-        bW5.product_split(ah, al, accQ);
+        if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -546,17 +572,15 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #pragma unroll
           for (int e = 0; e < 4; ++e) ss = fmaf(accQ[t][e], accQ[t][e], ss);
         }
-        ss += swizzle_xor16(ss);  // the row's four lanes l15 + 16 quad
-        ss += xor32(ss);
+        ss = sum_xor32(sum_xor16(ss));  // the row's four lanes l15 + 16 quad
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(ring + ringrow * LDQ + mycol + 16 * t) = accQ[t] * g3v[t];
         if (quad == 0) qnp[ringrow * 4 + wave] = ss * inv2n;
       }
       PS_TICK(7);
-      ps_arrive(sync_a + C_NORM, ln);
-      if (wave == 0) {
-        // ---- every producer's part of this step is in LDS: complete |q|^2 of the new rows, publish the round
-        ps_wait_ge(sync_a + C_NORM, 4u * (k + 1u), a.fail, 3);
+      // ---- the LAST producer to get here completes |q|^2 of the step's new rows (every producer's part is in LDS by then)
+      // and publishes the round; the others go straight on to the next step
+      if (ps_arrive_ticket(sync_a + C_NORM, ln) == 4u * k + 3u) {
         if (ln < 16 * cur.ntiles) {
           const int rrow = ((cur.tile0 + (ln >> 4)) & (PS_NRT - 1)) * 16 + l15;
           f32x4 v, v2;
@@ -665,23 +689,22 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #if RN_PS_CPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
-        // two independent triplets per iteration; one ring offset per lane steps from row to row (two rows where
-        // the numbering jumps over the reverse edge) and wraps at the end of the ring
+        // two independent triplets per iteration.  Source row of triplet t: rb + t, plus one from the reverse edge on
+        // (the numbering jumps over it); its ring slot is (that + the unit's ring base) mod PS_RING -- a compare, an
+        // add-with-carry, an AND and one 24-bit multiply per triplet, no branches and no running pointer to wrap
         float acc2[4] = {0.f, 0.f, 0.f, 0.f};
         const int tskip = rskip - rb;
-        auto step = [&](int qo, int tnext) {
-          qo += (tnext == tskip) ? 2 * LDQ : LDQ;
-          return qo >= PS_RINGF ? qo - PS_RINGF : qo;
+        const int rbase = ub + rb;
+        auto row_of = [&](int t) {
+          const unsigned slot = (unsigned)(rbase + t + (t >= tskip ? 1 : 0)) & (unsigned)(PS_RING - 1);
+          return ringc + __umul24(slot, (unsigned)LDQ);
         };
-        int qo = ((ub + rb + t0 + (t0 >= tskip ? 1 : 0)) & (PS_RING - 1)) * LDQ;
-        int t = t0;
+        int t = (RN_PS_PROBE & 1) ? t1 : t0;
         for (; t + 1 < t1; t += 2) {
-          const int qn = step(qo, t + 1);
-          triplet(ringc + qo, acc);
-          triplet(ringc + qn, acc2);
-          qo = step(qn, t + 2);
+          triplet(row_of(t), acc);
+          triplet(row_of(t + 1), acc2);
         }
-        if (t < t1) triplet(ringc + qo, acc);
+        if (t < t1) triplet(row_of(t), acc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
       }
@@ -691,8 +714,9 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #endif
       // the two halves of a destination sit in lane groups 16 apart: both end up with the whole sum
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += swizzle_xor16(acc[k]);
-      if (active) {
+      for (int k = 0; k < 4; ++k) acc[k] = sum_xor16(acc[k]);
+      if (active && (RN_PS_PROBE & 4)) *reinterpret_cast<f32x2 *>(a.edge_out + drow * FP + cc) = f32x2{acc[0] + old2.x, acc[1] + old2.y};
+      if (active && !(RN_PS_PROBE & 4)) {
         // from here on the two halves split the COLUMNS: this lane finishes columns cc, cc + 1
         const f32x2 a2 = part ? f32x2{acc[2], acc[3]} : f32x2{acc[0], acc[1]};
         if (a.agg_out) *reinterpret_cast<f32x2 *>(a.agg_out + drow * FP + cc) = a2;
@@ -701,7 +725,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         // zero mean (centred weights) and exact zeros in its padded columns, so its variance is the plain sum of squares
         const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
         const f32x2 xf = *reinterpret_cast<const f32x2 *>(crow + cc), xc = *reinterpret_cast<const f32x2 *>(crow + FP + cc);
-        const float rstd2 = fast_rsq(lg_sum<32>(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + 1e-5f);
+        const float rstd2 = fast_rsq(lg_sum32(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + 1e-5f);
         const f32x2 gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
         const f32x2 gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
         const f32x2 g2 = {gate(xf.x * rstd2 * gf.x + bf.x, xc.x * rstd2 * gc.x + bc.x), gate(xf.y * rstd2 * gf.y + bf.y, xc.y * rstd2 * gc.y + bc.y)};
