@@ -58,9 +58,13 @@ struct EdgePsArgs {
 #define RN_PS_TIMING 0
 #endif
 // Timing-only probe builds (results wrong by construction): -DRN_PS_PROBE=1 consumers skip the triplet loop (what is left is
-// the producers' pace), 2 producers skip their MFMA products, 4 consumers skip the epilogue arithmetic.
+// the producers' pace), 2 producers skip their MFMA products, 4 consumers skip the epilogue arithmetic, 8 producers skip the
+// node-term loads, 16 the operand split, 32 the LDS-DMA requests, 64 the wait of the split sync, 128 the Q' tiles.
 #ifndef RN_PS_PROBE
 #define RN_PS_PROBE 0
+#endif
+#ifndef RN_PS_SLEEP
+#define RN_PS_SLEEP 1  // s_sleep between two polls of a signalling word (0: poll back to back)
 #endif
 #ifndef RN_PS_PRIO
 #define RN_PS_PRIO 2   // s_setprio of the producer waves (consumers: 0 in the triplet loop)
@@ -210,7 +214,9 @@ __device__ __forceinline__ void ps_wait_ge(unsigned word, unsigned target, int *
       *fail = code;
       break;
     }
-    __builtin_amdgcn_s_sleep(1);
+#if RN_PS_SLEEP
+    __builtin_amdgcn_s_sleep(RN_PS_SLEEP);
+#endif
   }
 }
 // every LDS access of this wave is complete before the count moves
@@ -497,20 +503,25 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         const float *np3_s = a.np3 + (int64_t)(sg + cur.u * nsg) * g.N * (6 * FP);  // (uniform) this step's frame
         const int i = min(cur.r * PS_ND + l15, D - 1);
         const unsigned ok = (unsigned)d_a[i] * (6 * FP) + 4 * FP + mycol, oj = (unsigned)d_b[i] * (6 * FP) + 2 * FP + mycol;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          accP[t] = *reinterpret_cast<const f32x4 *>(np3_s + ok + 16 * t) + *reinterpret_cast<const f32x4 *>(np3_s + oj + 16 * t);
         const float *np3_q = a.np3 + (int64_t)(sg + min(cur.tu0, nunits - 1) * nsg) * g.N * (6 * FP);
         const unsigned oq = (unsigned)qb[min(cur.tt0 * 16 + l15, R - 1)] * (6 * FP) + mycol;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
+        for (int t = 0; t < 2; ++t) {
+          if (RN_PS_PROBE & 8) {
+            accP[t] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)(ok + oj);
+            accQ[t] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)oq;
+          } else {
+            accP[t] = *reinterpret_cast<const f32x4 *>(np3_s + ok + 16 * t) + *reinterpret_cast<const f32x4 *>(np3_s + oj + 16 * t);
+            accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
+          }
+        }
         ringrow0 = (cur.tile0 & (PS_NRT - 1)) * 16 + l15;
       }
       const bool have_next = ps_sched_next(sched, hi, nxt);  // (its one table read hides under the loads above)
-      split_landed(buf, ln);
+      if (!(RN_PS_PROBE & 16)) split_landed(buf, ln);
       PS_TICK(1);
       ps_arrive(sync_a + C_SPLIT, ln);
-      ps_wait_ge(sync_a + C_SPLIT, 4u * (k + 1u), a.fail, 1);
+      if (!(RN_PS_PROBE & 64)) ps_wait_ge(sync_a + C_SPLIT, 4u * (k + 1u), a.fail, 1);
       PS_TICK(2);
       // the seeds are complete before the next requests go out: nothing below waits on vmcnt, so the LDS-DMA
       // stays in flight across the whole step
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       // ---- B: request the next step's rows (its buffer and the node[a] tile are free: every producer is past step k - 1)
       PS_TICK(3);
       ln = launder(ln);
-      if (have_next) request(nxt, buf ^ 1, ln);
+      if (have_next && !(RN_PS_PROBE & 32)) request(nxt, buf ^ 1, ln);
       PS_TICK(4);
       // ---- the buffers of round g were last read by round g - 2
       if (cur.has_dest) ps_wait_ge(sync_a + ((cur.g & 1) ? C_DONE1 : C_DONE0), (unsigned)PS_CONS * (unsigned)(cur.g >> 1), a.fail, 2);
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
           *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t] * invc2;
       }
       PS_TICK(6);
-      for (int n = 0; n < cur.ntiles; ++n) {
+      for (int n = 0; n < ((RN_PS_PROBE & 128) ? 0 : cur.ntiles); ++n) {
         int ringrow = ringrow0;
         if (n > 0) {  // a second tile in one step is rare (once per unit): its node terms are fetched here
           const float *np3_q = a.np3 + (int64_t)(sg + min(cur.tu1, nunits - 1) * nsg) * g.N * (6 * FP);
