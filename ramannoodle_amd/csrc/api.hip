@@ -327,6 +327,7 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3n1_gs = L.take(2 * FeP);
     p.c3n1_bs = L.take(2 * FeP);
     p.mfma_scale = L.take(8);
+    p.mfma_scale_c = L.take(8);  // (right behind mfma_scale: one copy fetches both after a device-resident step)
     p.t_c3We = L.take((size_t)4 * FeP * FeP);
     p.t_c3Wn = L.take((size_t)6 * FeP * FnP);
     p.t_c2W = L.take((size_t)2 * FeP * FnP);
@@ -337,7 +338,6 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3_nshift_c = L.take(6 * FeP);
     p.c2_WT_c = L.take((size_t)FnP * 2 * FeP);
     p.c2_bias_c = L.take(2 * FeP);
-    p.mfma_scale_c = L.take(8);
   }
   const int HP = std::max(FeP, 32);  // readout hidden width: projections emit 32-column tiles
   L.W0T = L.take((size_t)FeP * HP);
@@ -2663,8 +2663,7 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
       HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 4 * (size_t)h->d.FeP * sizeof(float),
                              hipMemcpyDeviceToHost, st));
       // ... and the prescale pairs, which double as the finiteness flags of the weight blocks (mfma_f16_range_ok)
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.mfma_scale, w + q.mfma_scale, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.mfma_scale_c, w + q.mfma_scale_c, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.mfma_scale, w + q.mfma_scale, 16 * sizeof(float), hipMemcpyDeviceToHost, st));  // + mfma_scale_c
     }
     {  // ... and the split-f16 range guard reads the readout block (W0T .. b5, contiguous in the layout)
       const size_t lo = L.W0T, hi = L.b5 + 32;

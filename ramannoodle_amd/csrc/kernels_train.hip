@@ -77,17 +77,18 @@ __global__ void refresh_derived_kernel(float *__restrict__ w, const DerivedOp *_
       __syncthreads();
       continue;
     }
-    if (op.kind == 3) {  // one thread per row and [filter | core] block
-      const int bw = 2 * op.FeP, nblk = op.N / bw;
-      for (int i = threadIdx.x; i < op.K * nblk; i += blockDim.x) {
+    if (op.kind == 3) {  // one WAVE per (row, [filter | core] block): lanes own columns c, c + 64, ... of both halves
+      const int bw = 2 * op.FeP, nblk = op.N / bw, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+      for (int i = wave; i < op.K * nblk; i += nwaves) {
         const size_t base = (size_t)(i / nblk) * op.N + (size_t)(i % nblk) * bw;
         float sum = 0.0f;
-        for (int h = 0; h < 2; ++h)
-          for (int c = 0; c < op.Fe; ++c) sum += w[op.src + base + h * op.FeP + c];
+        for (int c = lane; c < op.Fe; c += 64) sum += w[op.src + base + c] + w[op.src + base + op.FeP + c];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
         const float mean = sum / (float)(2 * op.Fe);
-        for (int h = 0; h < 2; ++h)
-          for (int c = 0; c < op.FeP; ++c)
-            w[op.dst + base + h * op.FeP + c] = c < op.Fe ? w[op.src + base + h * op.FeP + c] - mean : 0.0f;
+        for (int c = lane; c < op.FeP; c += 64) {
+          w[op.dst + base + c] = c < op.Fe ? w[op.src + base + c] - mean : 0.0f;
+          w[op.dst + base + op.FeP + c] = c < op.Fe ? w[op.src + base + op.FeP + c] - mean : 0.0f;
+        }
       }
       continue;
     }
