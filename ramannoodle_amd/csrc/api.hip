@@ -155,6 +155,7 @@ struct rn_potgnn {
   rn_potgnn_config cfg{};
   Dims d{};
   int chunk = 1;
+  size_t f64_budget = 0;  // workspace bytes the float64 lanes may take (0: what the float32 lanes were given)
   int num_lanes = 2;
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
@@ -512,12 +513,12 @@ void pack_weights(rn_potgnn *h, const float *w) {
 bool lean_workspace(const rn_potgnn *h);
 size_t per_structure_elems(const rn_potgnn *h, bool lean);
 // The float32 chunk may have been sized from the LEAN workspace of the fused / narrow pipelines; float64 always runs the
-// unfused chain on the full-width buffers, so its chunk is counted from that layout (8 bytes per element) against the
-// same bytes the float32 lanes were given.
+// unfused chain on the full-width buffers, so its chunk is counted from that layout (8 bytes per element) against its own
+// allowance (rn_potgnn::f64_budget; with an explicit chunk: the bytes the float32 lanes were given).
 template <typename T>
 int chunk_frames(const rn_potgnn *h) {
   if (sizeof(T) == 4) return h->chunk;
-  const size_t budget = (size_t)h->chunk * per_structure_elems(h, lean_workspace(h)) * sizeof(float);
+  const size_t budget = std::max(h->f64_budget, (size_t)h->chunk * per_structure_elems(h, lean_workspace(h)) * sizeof(float));
   const size_t per64 = per_structure_elems(h, false) * sizeof(double);
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)h->chunk, budget / std::max<size_t>(per64, 1)));
 }
@@ -2161,6 +2162,11 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
         budget = std::min(budget, std::max<size_t>(free_b / 8 / (size_t)hp->num_lanes, (size_t)64 << 20));
       chunk = (int)std::max<size_t>(1, budget / std::max<size_t>(per, 1));
       chunk = std::min(chunk, 4096);
+      // the float64 lanes (created on first use) get their own allowance against the same "an eighth of what is free"
+      // rule: up to 24 GiB of the full-width float64 layout (1270 frames at 256 atoms, Fn = Fe = 64), so that the phonon
+      // finite differences of config 4 -- 1536 cells -- still run in two launches (chunk_frames<double>)
+      hp->f64_budget = (size_t)24 << 30;
+      if (free_b > 0) hp->f64_budget = std::min(hp->f64_budget, std::max<size_t>(free_b / 8 / (size_t)hp->num_lanes, (size_t)64 << 20));
     }
     hp->chunk = chunk;
     ensure_precision<float>(hp);
