@@ -57,8 +57,54 @@ def _ptr(array) -> C.c_void_p:
     return C.c_void_p(array.ctypes.data)
 
 
-class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attributes
+class _Activation(torch.nn.Module):
+    """Placeholder for the reference's parameter-free ``ShiftedSoftplus`` entries of its ``Sequential`` containers
+    (``_gnn.py:508-514, 532-539``): keeps the children's indices -- and with them the ``state_dict`` keys -- the
+    reference's.  The arithmetic happens in the kernels."""
+
+    def forward(self, x):  # pylint: disable=missing-function-docstring
+        return torch.nn.functional.softplus(x) - 0.6931471805599453
+
+
+class _GaussianFilter(torch.nn.Module):
+    """Holder of the ``offset`` buffer (``_gnn.py:53-66``)."""
+
+    def __init__(self, start: float, end: float, steps: int):
+        super().__init__()
+        self.register_buffer("offset", torch.linspace(start, end, steps, dtype=torch.float32))
+
+
+class _NodeBlockParams(torch.nn.Module):
+    """Parameters of ``_NodeBlock`` under the reference's names, in its order (``_gnn.py:106-120``)."""
+
+    def __init__(self, fn: int, fe: int):
+        super().__init__()
+        self.c1_linear = torch.nn.Linear(fn + fe, 2 * fn)
+        self.c1_norm = torch.nn.LayerNorm(2 * fn)
+        self.final_norm = torch.nn.LayerNorm(fn)
+
+
+class _EdgeBlockParams(torch.nn.Module):
+    """Parameters of ``_EdgeBlock`` under the reference's names, in its order (``_gnn.py:180-205``)."""
+
+    def __init__(self, fn: int, fe: int):
+        super().__init__()
+        self.c2_linear = torch.nn.Linear(fn, 2 * fe)
+        self.c3_linear = torch.nn.Linear(3 * fn + 2 * fe, 2 * fe)
+        self.c2_norm_1 = torch.nn.LayerNorm(2 * fe)
+        self.c3_norm_1 = torch.nn.LayerNorm(2 * fe)
+        self.c2_norm_2 = torch.nn.LayerNorm(fe)
+        self.c3_norm_2 = torch.nn.LayerNorm(fe)
+
+
+class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-instance-attributes
     """POlarizability Tensor Graph Neural Network, device evaluation.
+
+    A ``torch.nn.Module`` like the reference's (``_gnn.py:418-421``): its children are the reference's containers
+    (``_node_embedding``, ``_edge_embedding``, ``_node_blocks``, ``_edge_blocks``, ``_to_polarizability_embedding``)
+    holding real ``Linear`` / ``Embedding`` / ``LayerNorm`` / ``BatchNorm1d`` modules, so ``parameters()``,
+    ``state_dict()``, ``apply()``, ``modules()``, hooks, ``model(...)``, ``torch.save(model)`` and ``.to()`` are torch's
+    own.  The children only HOLD the parameters: ``forward`` hands them to the device kernels.
 
     Parameters are positional-compatible with the reference
     (``_gnn.py:453-464``); ``device`` (HIP ordinal) and ``max_chunk_structures`` are
@@ -89,6 +135,7 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         verify_ndarray_shape("mean_polarizability", mean_polarizability, (3, 3))
         verify_ndarray_shape("stddev_polarizability", stddev_polarizability, (3, 3))
         _lib.load()  # fail loudly before any work if the HIP library is absent
+        torch.nn.Module.__init__(self)
 
         self._ref_structure = ref_structure
         self._cutoff = cutoff
@@ -116,26 +163,38 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         self._gaussian_filter = (float(gaussian_filter_start), float(gaussian_filter_end))
         if self._fe < 2:
             raise ValueError("invalid size_edge_embedding: the Gaussian filter needs >= 2 steps")
-        state = self._fresh_state()
-        offset = state["_edge_embedding.offset"]
+        # the reference's module tree, created in its order so that the same torch.manual_seed gives the same initial
+        # weights (_gnn.py:508-539): trainable entries are Parameters (torch.optim works on them), the Gaussian offsets
+        # and the BatchNorm running statistics are buffers
+        fn, fe, k = self._fn, self._fe, self._num_atom_types
+        self._node_embedding = torch.nn.Sequential(torch.nn.Embedding(k, fn), _Activation(), torch.nn.Linear(fn, fn),
+                                                   _Activation(), torch.nn.Linear(fn, fn))
+        self._edge_embedding = _GaussianFilter(*self._gaussian_filter, fe)
+        self._node_blocks = torch.nn.ModuleList(_NodeBlockParams(fn, fe) for _ in range(self._passes))
+        self._edge_blocks = torch.nn.ModuleList(_EdgeBlockParams(fn, fe) for _ in range(self._passes))
+        self._to_polarizability_embedding = torch.nn.Sequential(
+            torch.nn.Linear(fe, fe), torch.nn.BatchNorm1d(fe), _Activation(), torch.nn.Linear(fe, fe), _Activation(),
+            torch.nn.Linear(fe, 12))
+        offset = self._edge_embedding.offset
         self._gauss_coefficient = -0.5 / (float(offset[1]) - float(offset[0])) ** 2  # _gnn.py:64
-        # trainable entries become torch Parameters (so torch.optim works on them); buffers
-        # (Gaussian offsets, BatchNorm running statistics) stay plain tensors
-        self._device_ahead = False     # DeviceAdam stepped: the device weights are newer than _state
+        self._device_ahead = False     # DeviceAdam stepped: the device weights are newer than the host tensors
         self._device_training = False  # gradients / optimiser state / BatchNorm buffers live in HBM
         self._device_anchor = torch.zeros(1, requires_grad=True)
         self._device_batches_tracked = 0
-        self._state_store = OrderedDict(
-            (k, torch.nn.Parameter(v) if self._is_trainable(k) else v) for k, v in state.items())
         self._handle = None
         self._profiling = 0
         self._uploaded_version = None
-        self.training = True  # like a fresh torch Module; calc_polarizabilities switches to eval
+        # (a fresh torch Module is in training mode; calc_polarizabilities switches to eval)
+
+    @property
+    def _state_store(self) -> "OrderedDict[str, torch.Tensor]":
+        """The module's own parameters and buffers, by ``state_dict`` key and in its order (the tensors themselves)."""
+        return torch.nn.Module.state_dict(self, keep_vars=True)
 
     @property
     def _state(self) -> "OrderedDict[str, torch.Tensor]":
-        """The host copy of the parameters and buffers, refreshed from the device first when a
-        device-resident optimiser has moved the weights (``DeviceAdam``)."""
+        """The module's parameters and buffers by ``state_dict`` key (the tensors themselves), refreshed from the device
+        first when a device-resident optimiser has moved the weights (``DeviceAdam``)."""
         if self._device_ahead:
             self._sync_from_device()
         return self._state_store
@@ -150,48 +209,21 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
             for value in store.values():
                 if value.is_floating_point():
                     n = value.numel()
-                    value.copy_(torch.from_numpy(blob[offset:offset + n].reshape(tuple(value.shape))))
+                    value.copy_(torch.from_numpy(blob[offset:offset + n].reshape(tuple(value.shape))).to(value.device))
                     offset += n
             store["_to_polarizability_embedding.1.num_batches_tracked"].fill_(self._device_batches_tracked)
         self._device_ahead = False
         self._uploaded_version = sum(int(v._version) for v in store.values())  # device == host again
 
-    def _fresh_state(self) -> "OrderedDict[str, torch.Tensor]":
-        """Freshly initialised tensors, created in the reference's module order so that the
-        same ``torch.manual_seed`` gives the same initial weights (_gnn.py:508-539)."""
-        fn, fe, k = self._fn, self._fe, self._num_atom_types
-        gaussian_filter_start, gaussian_filter_end = self._gaussian_filter
-        state: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-
-        def add(prefix, module):
-            for name, tensor in module.state_dict().items():
-                state[f"{prefix}.{name}"] = tensor.detach().clone()
-
-        add("_node_embedding.0", torch.nn.Embedding(k, fn))
-        add("_node_embedding.2", torch.nn.Linear(fn, fn))
-        add("_node_embedding.4", torch.nn.Linear(fn, fn))
-        offset = torch.linspace(gaussian_filter_start, gaussian_filter_end, fe, dtype=torch.float32)
-        state["_edge_embedding.offset"] = offset
-        for p in range(self._passes):
-            add(f"_node_blocks.{p}.c1_linear", torch.nn.Linear(fn + fe, 2 * fn))
-            add(f"_node_blocks.{p}.c1_norm", torch.nn.LayerNorm(2 * fn))
-            add(f"_node_blocks.{p}.final_norm", torch.nn.LayerNorm(fn))
-        for p in range(self._passes):
-            add(f"_edge_blocks.{p}.c2_linear", torch.nn.Linear(fn, 2 * fe))
-            add(f"_edge_blocks.{p}.c3_linear", torch.nn.Linear(3 * fn + 2 * fe, 2 * fe))
-            add(f"_edge_blocks.{p}.c2_norm_1", torch.nn.LayerNorm(2 * fe))
-            add(f"_edge_blocks.{p}.c3_norm_1", torch.nn.LayerNorm(2 * fe))
-            add(f"_edge_blocks.{p}.c2_norm_2", torch.nn.LayerNorm(fe))
-            add(f"_edge_blocks.{p}.c3_norm_2", torch.nn.LayerNorm(fe))
-        add("_to_polarizability_embedding.0", torch.nn.Linear(fe, fe))
-        add("_to_polarizability_embedding.1", torch.nn.BatchNorm1d(fe))
-        add("_to_polarizability_embedding.3", torch.nn.Linear(fe, fe))
-        add("_to_polarizability_embedding.5", torch.nn.Linear(fe, 12))
-        return state
-
     def reset_parameters(self) -> None:
-        """Re-initialise every parameter and buffer (``_gnn.py:559-566``)."""
-        self.load_state_dict(self._fresh_state())
+        """Re-initialise every parameter and buffer (``_gnn.py:559-566``: ``reset`` on every child, in order)."""
+        if self._device_ahead:
+            self._sync_from_device()
+        for module in self.modules():
+            if module is not self and hasattr(module, "reset_parameters"):
+                module.reset_parameters()
+        with torch.no_grad():
+            self._edge_embedding.offset.copy_(torch.linspace(*self._gaussian_filter, self._fe, dtype=torch.float32))
 
     # ------------------------------------------------------------------ properties
     @property
@@ -222,73 +254,35 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
     def _is_trainable(cls, key: str) -> bool:
         return not key.endswith(cls._BUFFER_SUFFIXES)
 
-    def parameters(self):
-        """Trainable parameters (``torch.nn.Parameter``), in ``state_dict`` order."""
-        return [v for k, v in self._state.items() if self._is_trainable(k)]
+    # torch.nn.Module's own parameters / named_parameters / state_dict / load_state_dict / apply / train / eval, with one
+    # addition: after a device-resident optimiser step the host tensors are refreshed from the device first
+    def _fresh(self) -> None:
+        if self._device_ahead:
+            self._sync_from_device()
 
-    def named_parameters(self):
-        return [(k, v) for k, v in self._state.items() if self._is_trainable(k)]
+    def parameters(self, recurse: bool = True):  # pylint: disable=missing-function-docstring
+        self._fresh()
+        return super().parameters(recurse)
 
-    def zero_grad(self) -> None:
-        for p in self.parameters():
-            p.grad = None
+    def named_parameters(self, *args, **kwargs):  # pylint: disable=missing-function-docstring
+        self._fresh()
+        return super().named_parameters(*args, **kwargs)
 
-    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+    def state_dict(self, *args, **kwargs):
         """Same keys, shapes and order as the reference's ``state_dict()``."""
-        return OrderedDict((k, v.detach().clone()) for k, v in self._state.items())
+        self._fresh()
+        return super().state_dict(*args, **kwargs)
 
-    def load_state_dict(self, state) -> None:
-        """Load parameters (torch tensors or numpy arrays); keys and shapes must match."""
-        missing = [k for k in self._state if k not in state]
-        unexpected = [k for k in state if k not in self._state]
-        if missing or unexpected:
-            raise RuntimeError(f"state_dict mismatch: missing {missing}, unexpected {unexpected}")
-        new = OrderedDict()
-        for key, old in self._state.items():
-            value = torch.as_tensor(np.asarray(state[key]) if not torch.is_tensor(state[key])
-                                    else state[key].detach().cpu())
-            if tuple(value.shape) != tuple(old.shape):
-                raise RuntimeError(f"size mismatch for {key}: {tuple(value.shape)} != "
-                                   f"{tuple(old.shape)}")
-            new[key] = value.to(old.dtype).clone()
-        with torch.no_grad():  # in place: Parameter objects (and optimisers holding them) stay valid
-            for key, value in new.items():
-                self._state[key].copy_(value)
-
-    def eval(self) -> "PotGNN":
-        """Evaluation mode: BatchNorm uses its running statistics."""
-        self.training = False
-        return self
-
-    def train(self, mode: bool = True) -> "PotGNN":
-        """Training mode: ``forward`` records a tape, BatchNorm uses batch statistics and
-        the returned tensor back-propagates into ``parameters()``."""
-        self.training = bool(mode)
-        return self
-
-    def apply(self, fn):
-        """``torch.nn.Module.apply`` stand-in for the notebook's weight initialisers: ``fn``
-        is called with light-weight views that look like the Linear / Embedding modules."""
-        for prefix, kind in self._module_kinds():
-            fn(_ModuleView(self._state, prefix, kind))
-        return self
-
-    def _module_kinds(self):
-        out = [("_node_embedding.0", torch.nn.Embedding), ("_node_embedding.2", torch.nn.Linear),
-               ("_node_embedding.4", torch.nn.Linear)]
-        for p in range(self._passes):
-            out.append((f"_node_blocks.{p}.c1_linear", torch.nn.Linear))
-        for p in range(self._passes):
-            out += [(f"_edge_blocks.{p}.c2_linear", torch.nn.Linear),
-                    (f"_edge_blocks.{p}.c3_linear", torch.nn.Linear)]
-        out += [("_to_polarizability_embedding.0", torch.nn.Linear),
-                ("_to_polarizability_embedding.3", torch.nn.Linear),
-                ("_to_polarizability_embedding.5", torch.nn.Linear)]
-        return out
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """``torch.nn.Module.load_state_dict`` (numpy arrays are accepted as values too); the Parameter objects stay the
+        same, so optimisers holding them stay valid."""
+        self._fresh()
+        state = OrderedDict((k, v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))) for k, v in state_dict.items())
+        return super().load_state_dict(state, strict=strict, assign=assign)
 
     # ------------------------------------------------------------------ device handle
     def _weights_blob(self) -> np.ndarray:
-        parts = [v.detach().numpy().astype(np.float32).ravel() for v in self._state.values()
+        parts = [v.detach().cpu().numpy().astype(np.float32).ravel() for v in self._state.values()
                  if v.is_floating_point()]
         return np.ascontiguousarray(np.concatenate(parts))
 
@@ -336,16 +330,16 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
     # -- copies and pickles carry the host state only (copy.deepcopy(model), torch.save(model)): the
     #    device handle, its optimiser state and the data-parallel hooks belong to this object
     def __getstate__(self):
+        self._fresh()  # (the host tensors are fetched from the device first when that copy is ahead)
         state = dict(self.__dict__)
-        state["_state_store"] = self._state  # (fetched from the device first when that copy is ahead)
         for key in ("_handle", "_dp_group", "_dp_callback", "_dp_installed_on"):
             state.pop(key, None)
         state.update(_device_ahead=False, _device_training=False, _uploaded_version=None)
         return state
 
     def __setstate__(self, state):
-        self.__dict__.update(state)
-        self._handle = None
+        torch.nn.Module.__setstate__(self, state)
+        self.__dict__["_handle"] = None
 
     def _release(self) -> None:
         if getattr(self, "_handle", None) is not None:
@@ -602,9 +596,10 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         rows = int(round(_lib.load().rn_potgnn_train_row_count(handle)))  # all ranks' rows
         pre = "_to_polarizability_embedding.1."
         with torch.no_grad():
-            self._state[pre + "running_mean"].mul_(0.9).add_(torch.from_numpy(mean) * 0.1)
-            unbiased = torch.from_numpy(var) * (rows / max(rows - 1, 1))
-            self._state[pre + "running_var"].mul_(0.9).add_(unbiased * 0.1)
+            running_mean, running_var = self._state[pre + "running_mean"], self._state[pre + "running_var"]
+            running_mean.mul_(0.9).add_(torch.from_numpy(mean).to(running_mean.device) * 0.1)
+            unbiased = torch.from_numpy(var).to(running_var.device) * (rows / max(rows - 1, 1))
+            running_var.mul_(0.9).add_(unbiased * 0.1)
             self._state[pre + "num_batches_tracked"].add_(1)
         self._uploaded_version = None  # buffers changed: re-upload before the next evaluation
         return out
@@ -700,8 +695,6 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
                 grads[key] = blob[offset:offset + n].reshape(tuple(value.shape)).copy()
             offset += n
         return out, loss, grads
-
-    __call__ = forward
 
     def calc_raman_tensors(self, ref_positions, displacements,
                            delta: float = RAMAN_TENSOR_CENTRAL_DIFFERENCE,
@@ -825,21 +818,6 @@ class PotGNN(PolarizabilityModel):  # pylint: disable=too-many-instance-attribut
         return {names[i].decode(): (ms[i], launches[i]) for i in range(max(n, 0))}
 
 
-class _ModuleView:
-    """What ``model.apply(fn)`` hands to ``fn``: ``isinstance(view, torch.nn.Linear)`` style
-    checks are answered through ``__class__`` and ``weight`` / ``bias`` are the model's own
-    Parameters, so ``torch.nn.init.*_(view.weight)`` initialises the model in place."""
-
-    def __init__(self, state, prefix, kind):
-        self._kind = kind
-        self.weight = state[prefix + ".weight"]
-        self.bias = state.get(prefix + ".bias")
-
-    @property
-    def __class__(self):  # noqa: D401 - makes isinstance(view, torch.nn.Linear) true
-        return self._kind
-
-
 class _TrainStep(torch.autograd.Function):
     """``PotGNN.forward`` in training mode: forward and backward both run on the device
     (``rn_potgnn_train_forward`` / ``rn_potgnn_train_backward``); autograd only routes the
@@ -857,7 +835,8 @@ class _TrainStep(torch.autograd.Function):
             ctx.model._train_backward_device(dvec6)
             return (None, None, None, None)
         grads = ctx.model._train_backward(dvec6)
-        return (None, None, None, *grads)
+        params = [p for _, p in torch.nn.Module.named_parameters(ctx.model)]
+        return (None, None, None, *[g.to(device=p.device, dtype=p.dtype) for g, p in zip(grads, params)])
 
 
 class _DeviceSpan:  # pylint: disable=too-few-public-methods

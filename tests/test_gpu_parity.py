@@ -1475,3 +1475,45 @@ def test_training_gradients_with_per_sample_lattices_and_species():
             continue
         worst = max(worst, np.abs(p.grad.numpy() - grads64[name]).max() / scale)
     assert worst < 1.5e-4, worst
+
+
+def test_potgnn_is_a_torch_module():
+    """``PotGNN`` is a ``torch.nn.Module`` as the reference's is (``_gnn.py:418-421``): ``model(...)``, forward hooks,
+    ``modules()``, ``torch.save(model)`` and ``.to()`` are torch's own -- and wherever the parameters live, the device
+    kernels see their current values."""
+    import io
+    g = load_golden("triclinic20")
+    model = product_model_from_golden(g)
+    assert isinstance(model, torch.nn.Module)
+    kinds = [type(m).__name__ for m in model.modules()]
+    assert kinds.count("Linear") == 3 * int(g["hp"][3]) + 5 and "Embedding" in kinds and "BatchNorm1d" in kinds
+    s = 4
+    lat = torch.tensor(g["lattice"]).expand(s, 3, 3)
+    zs = torch.tensor(g["atomic_numbers"]).expand(s, -1)
+    pos = torch.tensor(g["pos_batch"][:s])
+    model.eval()
+    seen = []
+    handle = model.register_forward_hook(lambda m, args, out: seen.append(tuple(out.shape)))
+    out = model(lat, zs, pos)           # nn.Module.__call__ -> forward
+    handle.remove()
+    assert seen == [(s, 6)]
+    np.testing.assert_allclose(out.numpy(), g["f32/forward"][:s], rtol=0, atol=REL * np.abs(g["f32/forward"]).max())
+    # torch.save / torch.load of the whole module
+    buffer = io.BytesIO()
+    torch.save(model, buffer)
+    buffer.seek(0)
+    loaded = torch.load(buffer, weights_only=False)
+    np.testing.assert_array_equal(loaded.eval()(lat, zs, pos).numpy(), out.numpy())
+    # parameters moved to the GPU: evaluation, a training step through torch.optim, evaluation again
+    model.to("cuda")
+    assert all(p.is_cuda for p in model.parameters())
+    np.testing.assert_array_equal(model(lat, zs, pos).numpy(), out.numpy())
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    loss = torch.nn.MSELoss()(model(lat.cuda(), zs.cuda(), pos.cuda()), torch.zeros((s, 6), device="cuda"))
+    loss.backward()
+    assert all(p.grad is not None and p.grad.is_cuda for p in model.parameters())
+    opt.step()
+    after = model.eval()(lat, zs, pos).numpy()
+    assert np.abs(after - out.numpy()).max() > 0   # the step reached the kernels
+    assert model.state_dict()["_node_embedding.0.weight"].is_cuda

@@ -222,8 +222,9 @@ def test_model_copies_and_pickles_carry_host_state_only():
         assert other._handle is None and other.num_edges == model.num_edges
         for (ka, va), (kb, vb) in zip(model.state_dict().items(), other.state_dict().items()):
             assert ka == kb and torch.equal(va, vb)
-        assert other.parameters()[0] is not model.parameters()[0]
-        assert isinstance(other.parameters()[0], torch.nn.Parameter)
+        assert next(other.parameters()) is not next(model.parameters())
+        assert isinstance(next(other.parameters()), torch.nn.Parameter)
+        assert isinstance(other, torch.nn.Module)
 
 
 def test_documented_size_limits_raise_not_implemented():
@@ -417,7 +418,8 @@ def test_parameters_apply_and_modes():
     """torch-facing surface of the model shell: Parameters for torch.optim, the notebook's
     `model.apply(init_fn)` idiom (machine-learning.ipynb:198-206), train/eval flags."""
     model = product_model_from_golden(load_golden("triclinic20"))
-    params = model.parameters()
+    assert isinstance(model, torch.nn.Module)  # like the reference's (_gnn.py:418-421)
+    params = list(model.parameters())
     assert all(isinstance(p, torch.nn.Parameter) for p in params)
     assert sum(p.numel() for p in params) == 4500  # the reference's parameter count for this model
     names = [k for k, _ in model.named_parameters()]
@@ -431,10 +433,10 @@ def test_parameters_apply_and_modes():
         if isinstance(m, torch.nn.Linear) or isinstance(m, torch.nn.Embedding):
             torch.nn.init.normal_(m.weight, mean=0, std=1)
 
-    before = model.state_dict()
+    before = {k: v.clone() for k, v in model.state_dict().items()}  # (torch's state_dict() aliases the parameters)
     torch.manual_seed(1)
     model.apply(init_biases).apply(init_weights)
-    after = model.state_dict()
+    after = {k: v.clone() for k, v in model.state_dict().items()}
     assert not torch.equal(before["_node_embedding.0.weight"], after["_node_embedding.0.weight"])
     assert not torch.equal(before["_edge_blocks.1.c3_linear.bias"], after["_edge_blocks.1.c3_linear.bias"])
     assert torch.equal(before["_node_blocks.0.c1_norm.weight"], after["_node_blocks.0.c1_norm.weight"])
@@ -444,7 +446,7 @@ def test_parameters_apply_and_modes():
     assert all(a is b for a, b in zip(params, model.parameters()))
     assert model.training and not model.eval().training and model.train().training
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
-    model.parameters()[0].grad = torch.ones_like(model.parameters()[0])
+    next(model.parameters()).grad = torch.ones_like(next(model.parameters()))
     opt.step()
     assert not torch.equal(model.state_dict()["_node_embedding.0.weight"], before["_node_embedding.0.weight"])
 
@@ -452,8 +454,8 @@ def test_parameters_apply_and_modes():
 def test_reset_parameters():
     """(reference: test/tests/torch/test_gnn.py:116-120)"""
     model = product_model_from_golden(load_golden("triclinic20"))
-    before = model.state_dict()
-    params = model.parameters()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    params = list(model.parameters())
     torch.manual_seed(11)
     model.reset_parameters()
     after = model.state_dict()
