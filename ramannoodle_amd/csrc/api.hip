@@ -102,6 +102,7 @@ struct PackedLayout {
     // copies of c3_linear / c2_linear centred over their real output columns (kernels_edge_ps.hip) and the
     // split-f16 prescales (s, 1/s) of W4 | W5 | c2 in that form
     size_t c3_WeT_c, c3_WnT_c, c3_nshift_c, c2_WT_c, c2_bias_c, mfma_scale_c;
+    size_t c1_WnT_c, c1_WeT_c, c1_bias_c;  // c1_linear centred over its 2 Fn output columns (fused NodeBlock)
   };
   std::vector<Pass> pass;
   size_t W0T, W3T, b3, W5T, b5, ones, b0p, t_W0, t_W3, t_W5;
@@ -268,16 +269,21 @@ std::vector<MfmaScaleOp> mfma_scale_ops(const rn_potgnn *h) {
 struct CentreOp {
   size_t src, dst;
   int K, N;
+  int F, FP;  // the [filter | core] blocks are 2 FP columns wide, the first F of each half real
 };
 std::vector<CentreOp> centre_ops(const rn_potgnn *h) {
   const int FnP = h->d.FnP, FeP = h->d.FeP;
   std::vector<CentreOp> ops;
   for (const auto &q : h->lay.pass) {
-    ops.push_back({q.c3_WeT, q.c3_WeT_c, FeP, 4 * FeP});
-    ops.push_back({q.c3_WnT, q.c3_WnT_c, FnP, 6 * FeP});
-    ops.push_back({q.c3_nshift, q.c3_nshift_c, 1, 6 * FeP});
-    ops.push_back({q.c2_WT, q.c2_WT_c, FnP, 2 * FeP});
-    ops.push_back({q.c2_bias, q.c2_bias_c, 1, 2 * FeP});
+    const int Fn = h->d.Fn, Fe = h->d.Fe;
+    ops.push_back({q.c3_WeT, q.c3_WeT_c, FeP, 4 * FeP, Fe, FeP});
+    ops.push_back({q.c3_WnT, q.c3_WnT_c, FnP, 6 * FeP, Fe, FeP});
+    ops.push_back({q.c3_nshift, q.c3_nshift_c, 1, 6 * FeP, Fe, FeP});
+    ops.push_back({q.c2_WT, q.c2_WT_c, FnP, 2 * FeP, Fe, FeP});
+    ops.push_back({q.c2_bias, q.c2_bias_c, 1, 2 * FeP, Fe, FeP});
+    ops.push_back({q.c1_WnT, q.c1_WnT_c, FnP, 2 * FnP, Fn, FnP});
+    ops.push_back({q.c1_WeT, q.c1_WeT_c, FeP, 2 * FnP, Fn, FnP});
+    ops.push_back({q.c1_bias, q.c1_bias_c, 1, 2 * FnP, Fn, FnP});
   }
   return ops;
 }
@@ -288,6 +294,7 @@ std::vector<MfmaScaleOp> centred_scale_ops(const rn_potgnn *h) {
     ops.push_back({q.c3_WeT_c, FeP, 2 * FeP, 4 * FeP, q.mfma_scale_c});
     ops.push_back({q.c3_WeT_c + 2 * FeP, FeP, 2 * FeP, 4 * FeP, q.mfma_scale_c + 2});
     ops.push_back({q.c2_WT_c, FnP, 2 * FeP, 2 * FeP, q.mfma_scale_c + 4});
+    ops.push_back({q.c1_WeT_c, FeP, 2 * FnP, 2 * FnP, q.mfma_scale_c + 6});
   }
   return ops;
 }
@@ -339,6 +346,9 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3_nshift_c = L.take(6 * FeP);
     p.c2_WT_c = L.take((size_t)FnP * 2 * FeP);
     p.c2_bias_c = L.take(2 * FeP);
+    p.c1_WnT_c = L.take((size_t)FnP * 2 * FnP);
+    p.c1_WeT_c = L.take((size_t)FeP * 2 * FnP);
+    p.c1_bias_c = L.take(2 * FnP);
   }
   const int HP = std::max(FeP, 32);  // readout hidden width: projections emit 32-column tiles
   L.W0T = L.take((size_t)FeP * HP);
@@ -470,17 +480,17 @@ void pack_weights(rn_potgnn *h, const float *w) {
     o[m.dst + 1] = 1.0f / sc;
   }
   for (const CentreOp &c : centre_ops(h)) {  // row-centred copies (float64 means; padded columns stay zero)
-    const int bw = 2 * FeP;
+    const int bw = 2 * c.FP;
     for (int k = 0; k < c.K; ++k)
       for (int b = 0; b < c.N / bw; ++b) {
         const size_t base = (size_t)k * c.N + (size_t)b * bw;
         double sum = 0;
         for (int hh = 0; hh < 2; ++hh)
-          for (int col = 0; col < Fe; ++col) sum += (double)o[c.src + base + hh * FeP + col];
-        const double mean = sum / (2.0 * Fe);
+          for (int col = 0; col < c.F; ++col) sum += (double)o[c.src + base + hh * c.FP + col];
+        const double mean = sum / (2.0 * c.F);
         for (int hh = 0; hh < 2; ++hh)
-          for (int col = 0; col < FeP; ++col)
-            o[c.dst + base + hh * FeP + col] = col < Fe ? (float)((double)o[c.src + base + hh * FeP + col] - mean) : 0.0f;
+          for (int col = 0; col < c.FP; ++col)
+            o[c.dst + base + hh * c.FP + col] = col < c.F ? (float)((double)o[c.src + base + hh * c.FP + col] - mean) : 0.0f;
       }
   }
   for (const MfmaScaleOp &m : centred_scale_ops(h)) {
@@ -687,6 +697,9 @@ void ensure_precision(rn_potgnn *h) {
     o.c2_WT_c = w + q.c2_WT_c;
     o.c2_bias_c = w + q.c2_bias_c;
     o.mfma_scale_c = w + q.mfma_scale_c;
+    o.c1_WnT_c = w + q.c1_WnT_c;
+    o.c1_WeT_c = w + q.c1_WeT_c;
+    o.c1_bias_c = w + q.c1_bias_c;
   }
   refresh_pass_flags<T>(h);
   P.ro = {w + L.W0T, w + L.scale0, w + L.shift0, w + L.W3T, w + L.b3, w + L.W5T, w + L.b5, w + L.ro_mfma_scale};
@@ -868,13 +881,14 @@ struct ChunkRun {
     }
     {
       Timer t(h, st(), K_PROJ_NODE);
-      project(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, w.c1_bias, 0, nullptr);
+      if (node_centred()) project(node[cur], MN, d.FnP, w.c1_WnT_c, 2 * d.FnP, npc1, w.c1_bias_c, 0, nullptr);  // zero row mean
+      else project(node[cur], MN, d.FnP, w.c1_WnT, 2 * d.FnP, npc1, w.c1_bias, 0, nullptr);
     }
     bool node_fused = false;
     if constexpr (sizeof(T) == 4) {
       if (fused() && h->use_node_fused) {  // c1 edge projection + aggregation in one launch
         Timer t(h, st(), K_NODE_AGG);
-        launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, h->mfma_f16, st());
+        launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, h->mfma_f16, node_centred(), st());
         node_fused = true;
       }
     }
@@ -982,6 +996,11 @@ struct ChunkRun {
   //  array the reverse pass needs; RN_POTGNN_TAPE_FUSED=0 keeps those runs on the unfused kernels)
   bool fused() const { return sizeof(T) == 4 && h->use_fused && (!prec<T>(h).tape_on || h->tape_fused); }
   bool narrow() const { return sizeof(T) == 4 && h->use_narrow && !prec<T>(h).tape_on; }
+  // the fused NodeBlock on the centred copy of c1_linear (evaluation runs, split-f16 products)
+  bool node_centred() const {
+    static const bool on = !(getenv("RN_POTGNN_NODE_CENTRED") && atoi(getenv("RN_POTGNN_NODE_CENTRED")) == 0);
+    return sizeof(T) == 4 && on && fused() && h->use_node_fused && h->mfma_f16 && !prec<T>(h).tape_on;
+  }
   // the role-specialised EdgeBlock (kernels_edge_ps.hip): split-f16 products and the folded gate scale only, evaluation runs
   bool role_split(const PassW<T> &w) const {
     return sizeof(T) == 4 && fused() && h->use_ps && h->mfma_f16 && (w.c3_fast & 1) != 0 && !prec<T>(h).tape_on;
@@ -1369,7 +1388,7 @@ std::vector<DerivedOp> derived_ops(const rn_potgnn *h, int *first_stage = nullpt
   transpose(L.W5T, HP, 32, L.t_W5);
   scaled(L.b0p, Fe, 1.0f, L.b0);  // the bias of readout Linear 0 lives twice (eval fold / training forward)
   for (const MfmaScaleOp &m : mfma_scale_ops(h)) ops.push_back({2, m.K, m.N, (float)m.ld, m.src, m.dst});
-  for (const CentreOp &c : centre_ops(h)) ops.push_back({3, c.K, c.N, 1.0f, c.src, c.dst, Fe, FeP});
+  for (const CentreOp &c : centre_ops(h)) ops.push_back({3, c.K, c.N, 1.0f, c.src, c.dst, c.F, c.FP});
   if (first_stage) *first_stage = (int)ops.size();
   // second launch: the prescales of the centred copies read what the first launch wrote
   for (const MfmaScaleOp &m : centred_scale_ops(h)) ops.push_back({2, m.K, m.N, (float)m.ld, m.src, m.dst});

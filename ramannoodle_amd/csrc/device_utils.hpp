@@ -164,6 +164,22 @@ __device__ __forceinline__ Vec4<T> ln_gate(const Vec4<T> &xf, const Vec4<T> &xc,
   return out;
 }
 
+// The same for a row that has zero mean by construction (a Linear whose weights and bias were centred over the row's
+// real columns) and exact zeros in its padded columns: the variance is the plain sum of squares -- no mean, no masking.
+template <int LG, typename T>
+__device__ __forceinline__ Vec4<T> ln_gate_zero_mean(const Vec4<T> &xf, const Vec4<T> &xc, const LnParams<T> &pf,
+                                                      const LnParams<T> &pc, T inv_n) {
+  T q = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q += xf.v[i] * xf.v[i] + xc.v[i] * xc.v[i];
+  q = lg_sum<LG>(q);
+  const T rstd = fast_rsq(q * inv_n + (T)1e-5);
+  Vec4<T> out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out.v[i] = gate(xf.v[i] * rstd * pf.g.v[i] + pf.b.v[i], xc.v[i] * rstd * pc.g.v[i] + pc.b.v[i]);
+  return out;
+}
+
 // LayerNorm over a row of logical width F (lane holds 4 columns).
 template <int LG, bool PAD, typename T>
 __device__ __forceinline__ Vec4<T> ln_row(const Vec4<T> &x, const LnParams<T> &p, T inv_n,

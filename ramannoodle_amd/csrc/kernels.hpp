@@ -77,7 +77,11 @@ struct PassW {
   const T *c3_nshift_c; // [6FeP]
   const T *c2_WT_c;     // [FnP][2FeP]
   const T *c2_bias_c;   // [2FeP]
-  const T *mfma_scale_c;  // [6] split-f16 prescales (s, 1/s) of c3_WeT_c[:, W4] | c3_WeT_c[:, W5] | c2_WT_c
+  // c1_linear centred the same way (the fused NodeBlock then needs no LayerNorm(2Fn) mean either)
+  const T *c1_WnT_c;    // [FnP][2FnP]
+  const T *c1_WeT_c;    // [FeP][2FnP]
+  const T *c1_bias_c;   // [2FnP]
+  const T *mfma_scale_c;  // [8] split-f16 prescales (s, 1/s) of c3_WeT_c[:, W4] | c3_WeT_c[:, W5] | c2_WT_c | c1_WeT_c
   int c3_fast;       // host-side decision: c3_norm_1 admits the folded-scale triplet loop
                      // (bit 0: in the fused EdgeBlock kernel, bit 1: in edge_agg_kernel)
 };
@@ -256,8 +260,10 @@ size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes);
 // `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
                           hipStream_t st);
+// `centred`: npc1 was projected with c1_WnT_c / c1_bias_c and the kernel multiplies with c1_WeT_c: zero row mean, the
+// LayerNorm(2Fn) in front of the gate needs the sum of squares only (split-f16 instantiations)
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
-                       const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st);
+                       const Graph &g, Dims d, const PassW<float> &w, bool f16, bool centred, hipStream_t st);
 // `agg_out` (taped runs, else null): the pre-LayerNorm triplet sums per destination edge
 void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
                        float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void edge_block_fused_kernel(EdgeFusedArgs 
 #ifndef RN_NODE_PROBE
 #define RN_NODE_PROBE 0  // timing experiments only (results wrong): 1 no MFMA, 2 no gate, 4 no per-atom phase, 8 no npc1 staging
 #endif
-template <bool PAD, bool F16>
+template <bool PAD, bool F16, bool ZM = false /* centred c1_linear: zero row mean (kernels.hpp) */>
 __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
@@ -598,8 +598,8 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
     d_bl[i] = g.edge_b[e] - j0;
   }
   WaveB<F16> bW;  // B fragments of the edge part of c1_linear, resident (prescaled: see the EdgeBlock kernel)
-  const float s1 = F16 ? a.w.mfma_scale[0] : 1.0f, inv1 = F16 ? a.w.mfma_scale[1] : 1.0f;
-  bW.load(a.w.c1_WeT, 2 * FP, colbase, l15, quad, s1);
+  const float s1 = F16 ? (ZM ? a.w.mfma_scale_c[6] : a.w.mfma_scale[0]) : 1.0f, inv1 = F16 ? (ZM ? a.w.mfma_scale_c[7] : a.w.mfma_scale[1]) : 1.0f;
+  bW.load(ZM ? a.w.c1_WeT_c : a.w.c1_WeT, 2 * FP, colbase, l15, quad, s1);
 
   const int grp = tid / LG, q4 = tid % LG, c0 = 4 * q4;
   const int nvalid = min(max(a.d.Fn - c0, 0), 4);
@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
           xf.v[k] = fmaf(xf.v[k], inv1, af.v[k]);
           xc.v[k] = fmaf(xc.v[k], inv1, ac.v[k]);
         }
-        store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
+        if constexpr (ZM) store4(gated + (size_t)i * LDG + c0, ln_gate_zero_mean<LG>(xf, xc, pf, pc, inv2n));
+        else store4(gated + (size_t)i * LDG + c0, ln_gate<LG, PAD>(xf, xc, pf, pc, inv2n, nvalid));
       }
 #if RN_NODE_PRIO
       __builtin_amdgcn_s_setprio(RN_NODE_PRIO);
@@ -744,7 +745,7 @@ size_t node_fused_lds_bytes(const Graph &g) { return node_fused_lds(g.nt_max_in_
 size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes) { return node_fused_lds(tile_in_rows, tile_nodes).total; }
 
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
-                       const Graph &g, Dims d, const PassW<float> &w, bool f16, hipStream_t st) {
+                       const Graph &g, Dims d, const PassW<float> &w, bool f16, bool centred, hipStream_t st) {
   if (S == 0 || g.N == 0) return;
   NodeFusedArgs a{edge, node_in, npc1, node_out, S, g, d, w};
   const bool pad = d.Fn != d.FnP;
@@ -755,8 +756,9 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
   }
 #endif
   const size_t lds = node_fused_lds_bytes(g);
-  auto kern = f16 ? (pad ? &node_block_fused_kernel<true, true> : &node_block_fused_kernel<false, true>)
-                         : (pad ? &node_block_fused_kernel<true, false> : &node_block_fused_kernel<false, false>);
+  auto kern = f16 ? (centred ? (pad ? &node_block_fused_kernel<true, true, true> : &node_block_fused_kernel<false, true, true>)
+                             : (pad ? &node_block_fused_kernel<true, true> : &node_block_fused_kernel<false, true>))
+                  : (pad ? &node_block_fused_kernel<true, false> : &node_block_fused_kernel<false, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
