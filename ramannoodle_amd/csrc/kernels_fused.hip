@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(bufP + l15 * LDQ + colbase + 16 * t + 4 * quad) = acc[t];
       }
+      if (!(RN_NODE_PROBE & 32))
       __syncthreads();  // S1: bufP complete, operand tile free
 #if RN_NODE_REGRING
       if (r + 1 < nrounds || s + nsg < a.S) publish_next();
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(256, 4) void node_block_fused_kernel(NodeFusedArgs 
       dma_wait();
       if (r + 1 < nrounds || s + nsg < a.S) split_landed_tiles();
 #endif
+      if (!(RN_NODE_PROBE & 16) || r + 1 == nrounds)
       __syncthreads();  // S2: bufP may be rewritten, next round's operand rows landed; after the last round: gated complete
     }
     // ---- per atom: sum over its in-edges (ascending, as the reference's scatter), LayerNorm, residual
