@@ -346,7 +346,10 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * edge_c2_kernel) be set.  The product build ignores those knobs.
  * bit 8 = every pass of a float32 evaluation takes the role-specialised fused EdgeBlock (edge_block_ps_kernel,
  * csrc/kernels_edge_ps.hip: producer waves + consumer waves in one 768-thread workgroup per CU; needs bits 0-2;
- * RN_POTGNN_EDGE_PS=0 at create time keeps the per-frame kernel of bit 0). */
+ * RN_POTGNN_EDGE_PS=0 at create time keeps the per-frame kernel of bit 0).
+ * bit 9 = float32 evaluations take the atom-owning fused NodeBlock (node_block_atom_kernel, csrc/kernels_node_atom.hip:
+ * tiles of 16 atoms, round r = their r-th in-edges, the gate on the MFMA accumulators; needs bits 0 and 2 and in-degrees
+ * even enough that it pays; RN_POTGNN_NODE_ATOM=0 at create time keeps node_block_fused_kernel). */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

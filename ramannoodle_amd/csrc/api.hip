@@ -888,7 +888,8 @@ struct ChunkRun {
     if constexpr (sizeof(T) == 4) {
       if (fused() && h->use_node_fused) {  // c1 edge projection + aggregation in one launch
         Timer t(h, st(), K_NODE_AGG);
-        launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, h->mfma_f16, node_centred(), st());
+        if (node_centred() && g.na_num > 0) launch_node_atom(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, st());
+        else launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, h->mfma_f16, node_centred(), st());
         node_fused = true;
       }
     }
@@ -2121,6 +2122,27 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.nt_max_in_rows = nt_max_in;
     g.nt_max_nodes = nt_max_nodes;
     g.nt_narrow = nt_narrow ? 1 : 0;
+    {
+      // the atom-owning NodeBlock pays max-in-degree rounds per 16-atom tile; the row-ordered one ceil(rows / 16) per tile of
+      // its own partition.  A round of the former is ~25 % cheaper (one barrier, no LDS pass per row): take it unless the
+      // in-degrees are so uneven that it runs > 1.2x the rounds.  RN_POTGNN_NODE_ATOM=0 / 1 forces.
+      int max_deg = 0;
+      long rounds_atom = 0, rounds_row = 0;
+      for (int n0 = 0; n0 < N; n0 += 16) {
+        int m = 0;
+        for (int n = n0; n < std::min(N, n0 + 16); ++n) m = std::max(m, hp->in_ptr[n + 1] - hp->in_ptr[n]);
+        rounds_atom += m;
+        max_deg = std::max(max_deg, m);
+      }
+      for (size_t t = 0; t + 1 < hp->nt_begin.size(); ++t)
+        rounds_row += (hp->in_ptr[hp->nt_begin[t + 1]] - hp->in_ptr[hp->nt_begin[t]] + 15) / 16;
+      bool ok = !nt_narrow && hp->d.FnP == 64 && hp->d.FeP == 64 && node_atom_lds_bytes(max_deg) <= (size_t)40 * 1024 &&
+                (double)rounds_atom <= 1.2 * (double)rounds_row;
+      if (const char *e = getenv("RN_POTGNN_NODE_ATOM"))
+        ok = atoi(e) != 0 && hp->d.FnP == 64 && hp->d.FeP == 64 && node_atom_lds_bytes(max_deg) <= (size_t)64 * 1024;
+      g.na_num = ok ? (N + 15) / 16 : 0;
+      g.na_max_deg = max_deg;
+    }
     g.et_num = hp->et_begin.empty() ? 0 : (int)hp->et_begin.size() - 1;
     g.et_begin = base + o_et;
     g.et_max_out_rows = et_max_rows;
@@ -2771,6 +2793,10 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
     bool ps = h->use_fused && h->use_ps && h->mfma_f16 && !h->f32.pass.empty();
     for (const auto &p : h->f32.pass) ps = ps && (p.c3_fast & 1);
     flags |= ps ? 256 : 0;
+  }
+  {  // bit 9: float32 evaluations take the atom-owning fused NodeBlock (kernels_node_atom.hip)
+    static const bool centred = !(getenv("RN_POTGNN_NODE_CENTRED") && atoi(getenv("RN_POTGNN_NODE_CENTRED")) == 0);
+    flags |= (h->use_fused && h->use_node_fused && h->mfma_f16 && centred && h->g.na_num > 0) ? 512 : 0;
   }
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));

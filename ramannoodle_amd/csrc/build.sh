@@ -12,7 +12,7 @@ bdir="build${tag:+_$tag}"
 mkdir -p "$here/$bdir"
 pids=()
 # RN_EXTRA_FLAGS=-DRN_EXPERIMENTS=1 adds the opt-in round-3 experiment kernels (experiments/); the product build has none.
-hip_srcs="api kernels_agg kernels_gemm kernels_fused kernels_edge_ps kernels_narrow kernels_bwd kernels_train spectrum"
+hip_srcs="api kernels_agg kernels_gemm kernels_fused kernels_edge_ps kernels_node_atom kernels_narrow kernels_bwd kernels_train spectrum"
 case " ${RN_EXTRA_FLAGS:-} " in *" -DRN_EXPERIMENTS=1 "*) hip_srcs="$hip_srcs experiments/kernels_fused_experiments";; esac
 objs=()
 for f in $hip_srcs; do

@@ -112,6 +112,18 @@ struct WaveB<true> {  // split f16 (device_utils.hpp: mfma_split3), K = 32 slice
         split_f16x8(tmp, h[t][s], l[t][s]);
       }
   }
+  // the same with the two 16-column tiles at col0 and col1 (not necessarily adjacent)
+  __device__ __forceinline__ void load2(const float *W, int ld, int col0, int col1, int l15, int quad, float prescale) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = prescale * W[(size_t)(quad * KS + 8 * s + j) * ld + (t ? col1 : col0) + l15];
+        split_f16x8(tmp, h[t][s], l[t][s]);
+      }
+  }
   template <bool K32 = (RN_MFMA_K32 != 0)>
   __device__ __forceinline__ void product(const float (&af)[KS], f32x4 (&acc)[2]) const {
     f16x8 ah[2], al[2];
@@ -159,6 +171,134 @@ __device__ __forceinline__ void load_split_a(const float *tile, int l15, int qua
     ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
     al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
   }
+}
+
+// ---- LDS access in inline assembly (kernels that keep LDS-DMA requests in flight across their rounds) ----------
+// With an LDS-DMA outstanding hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every LDS access it can see and
+// cannot prove disjoint from the DMA's destination, which would turn requests issued rounds ahead into synchronous
+// loads.  LDS operations of a wave are performed in order; the waits below are on lgkmcnt only.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+// hides a lane constant from loop-invariant code motion: what is derived from the result is recomputed where it is
+// used instead of occupying a register for the whole kernel (the producers hold 96 VGPRs of weights)
+__device__ __forceinline__ int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// LDS reads of a PRODUCER, in inline assembly for the same reason: with an LDS-DMA outstanding hipcc puts
+// s_waitcnt vmcnt(0) in front of every LDS read it can see (inside a loop it cannot prove that the read misses the
+// DMA's destination), which would turn the one-step-ahead requests into synchronous loads.  Reads and their
+// lgkmcnt wait form ONE statement, so no use of a result can be scheduled in between.
+__device__ __forceinline__ void lds_read4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, f32x4 &r0, f32x4 &r1,
+                                          f32x4 &r2, f32x4 &r3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+}
+__device__ __forceinline__ void lds_read2(unsigned a0, unsigned a1, f32x4 &r0, f32x4 &r1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1)
+               : "v"(a0), "v"(a1)
+               : "memory");
+}
+__device__ __forceinline__ void lds_write4(unsigned a0, float4 x) {  // (a write into an operand tile: same reason)
+  const f32x4 v = {x.x, x.y, x.z, x.w};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(a0), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read1x3(unsigned a0, unsigned a1, unsigned a2, int &r0, int &r1, int &r2) {
+  asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+               : "v"(a0), "v"(a1), "v"(a2)
+               : "memory");
+}
+__device__ __forceinline__ void lds_read3(unsigned a0, unsigned a1, unsigned a2, f32x4 &r0, f32x4 &r1, f32x4 &r2) {
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+               : "v"(a0), "v"(a1), "v"(a2)
+               : "memory");
+}
+__device__ __forceinline__ int lds_read1(unsigned a0) {
+  int r;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a0) : "memory");
+  return r;
+}
+// A fragments of one operand tile whose slots were converted by split_slot (fused_common.hpp: load_split_a)
+__device__ __forceinline__ void ps_load_split_a(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2]) {
+  union { f32x4 v; struct { f16x4 hi, lo; } h; } u[4];
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  lds_read4(row + (((4 * quad + 0) ^ l15) & 15) * 16, row + (((4 * quad + 1) ^ l15) & 15) * 16,
+            row + (((4 * quad + 2) ^ l15) & 15) * 16, row + (((4 * quad + 3) ^ l15) & 15) * 16, u[0].v, u[1].v, u[2].v, u[3].v);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+// the same plus two more 16-byte reads (a bias / scale pair) under the one wait
+__device__ __forceinline__ void ps_load_split_a2(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2],
+                                                 unsigned x0, unsigned x1, f32x4 &e0, f32x4 &e1) {
+  union { f32x4 v; struct { f16x4 hi, lo; } h; } u[4];
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  asm volatile(
+      "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+      "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(u[0].v), "=&v"(u[1].v), "=&v"(u[2].v), "=&v"(u[3].v), "=&v"(e0), "=&v"(e1)
+      : "v"(row + (((4 * quad + 0) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 1) ^ l15) & 15) * 16),
+        "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16), "v"(x0), "v"(x1)
+      : "memory");
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    ah[s2] = __builtin_shufflevector(u[2 * s2].h.hi, u[2 * s2 + 1].h.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    al[s2] = __builtin_shufflevector(u[2 * s2].h.lo, u[2 * s2 + 1].h.lo, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+// v[lane] + v[lane ^ 16] / v[lane] + v[lane ^ 32] on the VALU (v_permlane16_swap / v_permlane32_swap, new on gfx950): the
+// swap of a register with itself leaves (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3) -- resp. the two
+// halves -- in the result pair.  ds_swizzle / ds_bpermute do the same through the LDS crossbar at ~100 cycles of latency
+// per step, which is what the consumers' epilogue (five dependent reductions) and the producers' row norms were waiting on.
+__device__ __forceinline__ float sum_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over an aligned run of 32 lanes
+__device__ __forceinline__ float lg_sum32(float v) { return sum_xor16(lg_sum<16>(v)); }
+
+// ---- "pair" operand layout: the 16-byte slots 2m, 2m+1 of a 64-float row (k = 8m .. 8m+7) become [hi x8] and [lo x8], so an
+// MFMA fragment of a K = 32 slice is ONE 16-byte read per half with no register shuffling afterwards (the [hi x4 | lo x4]
+// slots of split_slot cost six v_mov per slice to reassemble).  Slot J of row r sits at physical position J ^ r, as before.
+// The lane that fetched physical slot `phys` of row `row` converts it: both lanes of a pair belong to the row's 16 lanes of
+// one wave, which read (and wait) before either writes.
+__device__ __forceinline__ void split_own_pair(unsigned tile_addr, int row, int phys) {
+  const int j = (phys ^ row) & 15;
+  const unsigned base = tile_addr + (unsigned)row * (FP * 4);
+  f32x4 u;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(u) : "v"(base + (unsigned)phys * 16u) : "memory");
+  f16x4 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (_Float16)u[i];
+    lo[i] = (_Float16)(u[i] - (float)hi[i]);
+  }
+  const unsigned half = (unsigned)(j & 1) * 8u;
+  asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(base + (unsigned)(((j & ~1) ^ row) & 15) * 16u + half),
+               "v"(base + (unsigned)(((j | 1) ^ row) & 15) * 16u + half), "v"(hi), "v"(lo)
+               : "memory");
+}
+__device__ __forceinline__ void load_pair_a(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2]) {
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(ah[0]), "=&v"(al[0]), "=&v"(ah[1]), "=&v"(al[1])
+      : "v"(row + (((4 * quad + 0) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 1) ^ l15) & 15) * 16),
+        "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16)
+      : "memory");
 }
 }  // namespace
 

@@ -29,6 +29,9 @@ struct Graph {
   const int *nt_begin;    // [nt_num+1] node ranges
   int nt_max_in_rows, nt_max_nodes;
   int nt_narrow;          // the partition was made for node_tiled_kernel (kernels_narrow.hip)
+  // atom-owning fused NodeBlock (kernels_node_atom.hip): tiles of 16 consecutive atoms, round r = their r-th in-edges
+  int na_num;             // ceil(N / 16), or 0 when that kernel does not serve the graph
+  int na_max_deg;         // largest in-degree
   // node tiles of the twelve-wave EdgeBlock kernel (edge_block3_kernel: one workgroup per CU, 48 destinations a round)
   int et_num;
   const int *et_begin;    // [et_num+1] node ranges
@@ -262,6 +265,10 @@ void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w
                           hipStream_t st);
 // `centred`: npc1 was projected with c1_WnT_c / c1_bias_c and the kernel multiplies with c1_WeT_c: zero row mean, the
 // LayerNorm(2Fn) in front of the gate needs the sum of squares only (split-f16 instantiations)
+size_t node_atom_lds_bytes(int max_deg);
+// (split-f16 products on the centred c1_linear only: PassW::c1_WeT_c, npc1 from c1_WnT_c / c1_bias_c)
+void launch_node_atom(const float *edge, const float *node_in, const float *npc1, float *node_out, int S, const Graph &g,
+                      Dims d, const PassW<float> &w, hipStream_t st);
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, bool centred, hipStream_t st);
 // `agg_out` (taped runs, else null): the pre-LayerNorm triplet sums per destination edge

@@ -1331,6 +1331,37 @@ def test_role_split_edge_block_against_oracle_and_per_frame_kernel(monkeypatch, 
     assert _rel_err((got - oracle.mean) / oracle.std, (old - oracle.mean) / oracle.std) < REL
 
 
+@pytest.mark.parametrize("case,cutoff,fn,fe,passes,frames", [
+    ("rocksalt64_parity", 3.2, 64, 64, 2, 23),   # regular graph: every round full, several frames per workgroup
+    ("rocksalt64_parity", 3.2, 64, 64, 1, 300),  # more frames than workgroups: the next frame's rows through the LDS slots
+    ("triclinic20", 3.4, 64, 64, 2, 5),          # ragged in-degrees, a last tile of 4 atoms
+    ("triclinic20", 3.0, 40, 50, 2, 3),          # padded columns in both embeddings (PAD instantiation)
+    ("triclinic20", 2.2, 64, 33, 1, 2),          # atoms with one or two in-edges: fewer rounds than the ring is deep
+])
+def test_atom_owning_node_block_against_oracle_and_row_kernel(monkeypatch, case, cutoff, fn, fe, passes, frames):
+    """The atom-owning fused NodeBlock (``csrc/kernels_node_atom.hip``: tiles of 16 atoms, round r = their r-th in-edges,
+    the gate on the MFMA accumulators) agrees with the pinned oracle and with the row-ordered kernel it replaces
+    (``RN_POTGNN_NODE_ATOM=0``), and repeats bit for bit."""
+    from oracle import potgnn_oracle as O
+    g = load_golden(case)
+    rng = np.random.default_rng(11)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=frames)] + rng.normal(scale=2e-3, size=(frames,) + base.shape[1:])
+    monkeypatch.setenv("RN_POTGNN_NODE_ATOM", "1")
+    model, oracle = _random_model(g, cutoff, fn, fe, passes, seed=fn * 7 + fe)
+    got = model.calc_polarizabilities(pos)
+    assert model.config_flags()["atom_owning_node_block"]
+    check = pos[:: max(1, frames // 8)]
+    want = O.calc_polarizabilities(oracle, check, faithful=False)
+    assert _rel_err((got[:: max(1, frames // 8)] - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos), got)
+    monkeypatch.setenv("RN_POTGNN_NODE_ATOM", "0")
+    rows, _ = _random_model(g, cutoff, fn, fe, passes, seed=fn * 7 + fe)
+    old = rows.calc_polarizabilities(pos)
+    assert not rows.config_flags()["atom_owning_node_block"]
+    assert _rel_err((got - oracle.mean) / oracle.std, (old - oracle.mean) / oracle.std) < REL
+
+
 def test_centred_weight_copies_follow_a_device_resident_step():
     """The role-specialised EdgeBlock multiplies with copies of c3_linear / c2_linear centred over their output columns.
     After a device-resident Adam step those copies are recomputed on the device (``refresh_derived_kernel`` kind 3):
