@@ -349,7 +349,10 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * RN_POTGNN_EDGE_PS=0 at create time keeps the per-frame kernel of bit 0).
  * bit 9 = float32 evaluations take the atom-owning fused NodeBlock (node_block_atom_kernel, csrc/kernels_node_atom.hip:
  * tiles of 16 atoms, round r = their r-th in-edges, the gate on the MFMA accumulators; needs bits 0 and 2 and in-degrees
- * even enough that it pays; RN_POTGNN_NODE_ATOM=0 at create time keeps node_block_fused_kernel). */
+ * even enough that it pays; RN_POTGNN_NODE_ATOM=0 at create time keeps node_block_fused_kernel).
+ * bit 10 = float32 evaluations keep the edge embedding in HBM as split-f16 operand pairs ([f16 hi x8][f16 lo x8] per eight
+ * columns, hi = f16(x), lo = f16(x - hi): the MFMA operand itself, same 256 B per row) between the geometry kernel, the
+ * EdgeBlocks, the NodeBlocks and the readout; needs bits 8 and 9; RN_POTGNN_PAIR_ROWS=0 at create time keeps float32 rows. */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
 /* Number of edge triplets T of the frozen graph. */

@@ -168,6 +168,7 @@ struct rn_potgnn {
   bool use_edge3 = false;  // fused EdgeBlock on twelve waves, one workgroup per CU (edge_block3_kernel + edge_c2_kernel)
   bool use_ps = false;     // role-specialised fused EdgeBlock (kernels_edge_ps.hip) on its own atom tiles (Graph::pt_*)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
+  bool want_pair_rows = true;   // RN_POTGNN_PAIR_ROWS at create time (ForwardRun::pair_rows decides per run)
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
   bool mfma_f16 = true;  // fused kernels: split-f16 MFMA products are in use (requested and inside the safe range)
@@ -843,8 +844,17 @@ struct ChunkRun {
     target_tape(0, 0);
     {
       Timer t(h, st(), K_GEOM);
-      launch_geom_rbf<T>(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
-                         P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (pair_rows()) {
+          launch_geom_rbf_pairs(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0, P.offsets,
+                                (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
+          done = true;
+        }
+      }
+      if (!done)
+        launch_geom_rbf<T>(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
+                           P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
     }
     {
       Timer t(h, st(), K_NODE_INIT);
@@ -888,7 +898,7 @@ struct ChunkRun {
     if constexpr (sizeof(T) == 4) {
       if (fused() && h->use_node_fused) {  // c1 edge projection + aggregation in one launch
         Timer t(h, st(), K_NODE_AGG);
-        if (node_centred() && g.na_num > 0) launch_node_atom(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, st());
+        if (node_centred() && g.na_num > 0) launch_node_atom(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, st(), pair_rows());
         else launch_node_fused(edge[cur], node[cur], npc1, node[nxt], S, g, d, w, h->mfma_f16, node_centred(), st());
         node_fused = true;
       }
@@ -942,7 +952,7 @@ struct ChunkRun {
         else if (fused() && h->use_edge2)
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
 #endif
-        else if (role_split(w)) launch_edge_ps(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->ps_fail.as<int>(), st());
+        else if (role_split(w)) launch_edge_ps(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->ps_fail.as<int>(), st(), pair_rows());
         else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
@@ -974,7 +984,7 @@ struct ChunkRun {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
         if (fused() && h->use_readout_fused) {  // the three layers in one launch
-          launch_readout_fused(edge[cur], ME, P.ro, bufA, h->mfma_f16, st());
+          launch_readout_fused(edge[cur], ME, P.ro, bufA, h->mfma_f16, st(), pair_rows());
           done = true;
         }
       }
@@ -1005,6 +1015,15 @@ struct ChunkRun {
   // the role-specialised EdgeBlock (kernels_edge_ps.hip): split-f16 products and the folded gate scale only, evaluation runs
   bool role_split(const PassW<T> &w) const {
     return sizeof(T) == 4 && fused() && h->use_ps && h->mfma_f16 && (w.c3_fast & 1) != 0 && !prec<T>(h).tape_on;
+  }
+  // Edge rows as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs): when EVERY kernel that touches them in this run is one
+  // that speaks the format -- the role-specialised EdgeBlock in every pass, the atom-owning NodeBlock, the fused readout --
+  // and nothing else looks at them (no tape, no stage snapshots).  RN_POTGNN_PAIR_ROWS=0 keeps plain float32 rows.
+  bool pair_rows() const {
+    if (sizeof(T) != 4 || !h->want_pair_rows || h->keep_stages || !node_centred() || h->g.na_num <= 0 || !h->use_readout_fused) return false;
+    for (const auto &w : prec<T>(h).pass)
+      if (!role_split(w)) return false;
+    return true;
   }
   T *tape_agg(int p) {  // where the EdgeBlock's pre-LayerNorm sums are recorded (taped runs only)
     Precision<T> &P = prec<T>(h);
@@ -2190,6 +2209,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // pipeline keeps two alternating lanes of 1.5 GiB.
     const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
     hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
+    hp->want_pair_rows = !(getenv("RN_POTGNN_PAIR_ROWS") && atoi(getenv("RN_POTGNN_PAIR_ROWS")) == 0);
     const bool want_ro = getenv("RN_POTGNN_READOUT_FUSED") ? atoi(getenv("RN_POTGNN_READOUT_FUSED")) != 0 : true;
     hp->use_readout_fused = hp->use_fused && want_ro;
     if (!getenv("RN_POTGNN_LANES")) hp->num_lanes = (hp->use_fused || hp->use_narrow) ? 1 : 2;
@@ -2796,7 +2816,10 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
   }
   {  // bit 9: float32 evaluations take the atom-owning fused NodeBlock (kernels_node_atom.hip)
     static const bool centred = !(getenv("RN_POTGNN_NODE_CENTRED") && atoi(getenv("RN_POTGNN_NODE_CENTRED")) == 0);
-    flags |= (h->use_fused && h->use_node_fused && h->mfma_f16 && centred && h->g.na_num > 0) ? 512 : 0;
+    const bool atom = h->use_fused && h->use_node_fused && h->mfma_f16 && centred && h->g.na_num > 0;
+    flags |= atom ? 512 : 0;
+    // bit 10: float32 evaluations keep their edge rows as split-f16 pairs (bits 8 and 9 and the fused readout)
+    flags |= (atom && (flags & 256) && h->use_readout_fused && h->want_pair_rows && !h->keep_stages) ? 1024 : 0;
   }
   bool fast = !h->f32.pass.empty();
   for (const auto &p : h->f32.pass) fast = fast && !h->use_narrow && (p.c3_fast & (h->use_fused ? 1 : 2));

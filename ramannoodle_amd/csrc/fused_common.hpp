@@ -275,11 +275,10 @@ __device__ __forceinline__ float lg_sum32(float v) { return sum_xor16(lg_sum<16>
 // slots of split_slot cost six v_mov per slice to reassemble).  Slot J of row r sits at physical position J ^ r, as before.
 // The lane that fetched physical slot `phys` of row `row` converts it: both lanes of a pair belong to the row's 16 lanes of
 // one wave, which read (and wait) before either writes.
-__device__ __forceinline__ void split_own_pair(unsigned tile_addr, int row, int phys) {
+// hi / lo halves of four floats -> the lane's 8-byte shares of the pair's two slots
+__device__ __forceinline__ void write_pair(unsigned tile_addr, int row, int phys, const f32x4 &u) {
   const int j = (phys ^ row) & 15;
   const unsigned base = tile_addr + (unsigned)row * (FP * 4);
-  f32x4 u;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(u) : "v"(base + (unsigned)phys * 16u) : "memory");
   f16x4 hi, lo;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -291,6 +290,14 @@ __device__ __forceinline__ void split_own_pair(unsigned tile_addr, int row, int 
                "v"(base + (unsigned)(((j | 1) ^ row) & 15) * 16u + half), "v"(hi), "v"(lo)
                : "memory");
 }
+__device__ __forceinline__ void split_own_pair(unsigned tile_addr, int row, int phys) {
+  f32x4 u;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(u)
+               : "v"(tile_addr + (unsigned)row * (FP * 4) + (unsigned)phys * 16u)
+               : "memory");
+  write_pair(tile_addr, row, phys, u);
+}
 __device__ __forceinline__ void load_pair_a(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2]) {
   const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
   asm volatile(
@@ -298,6 +305,18 @@ __device__ __forceinline__ void load_pair_a(unsigned tile_addr, int l15, int qua
       : "=&v"(ah[0]), "=&v"(al[0]), "=&v"(ah[1]), "=&v"(al[1])
       : "v"(row + (((4 * quad + 0) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 1) ^ l15) & 15) * 16),
         "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16)
+      : "memory");
+}
+// the same plus two more 16-byte reads (a bias / scale pair) under the one wait
+__device__ __forceinline__ void load_pair_a2(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2], unsigned x0,
+                                             unsigned x1, f32x4 &e0, f32x4 &e1) {
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  asm volatile(
+      "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+      "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(ah[0]), "=&v"(al[0]), "=&v"(ah[1]), "=&v"(al[1]), "=&v"(e0), "=&v"(e1)
+      : "v"(row + (((4 * quad + 0) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 1) ^ l15) & 15) * 16),
+        "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16), "v"(x0), "v"(x1)
       : "memory");
 }
 }  // namespace

@@ -133,6 +133,12 @@ template <typename T>
 void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
                      int lat_stride /* 0: one lattice for every frame; 9: lattice[S][9] */,
                      const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st);
+// "Pair" edge rows (float32 evaluations on the role-specialised EdgeBlock + atom-owning NodeBlock + fused readout, FeP = 64):
+// a row's 256 bytes hold, for each group m of eight columns, [f16 hi x8][f16 lo x8] with hi = f16(x), lo = f16(x - hi) --
+// the split-f16 MFMA operand itself (device_utils.hpp), written once by the kernel that produces the row instead of being
+// re-derived by each of its three consumers; x = hi + lo to 2^-25 absolute for |x| < 1 (tanh / Gaussian outputs).
+void launch_geom_rbf_pairs(const double *pos, int S, const Graph &g, const float *lattice, int lat_stride, const float *offsets,
+                           float coef, Dims d, float *unit4, float *edge0, hipStream_t st);
 
 template <typename T>
 void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node,
@@ -262,13 +268,13 @@ size_t node_fused_lds_bytes(const Graph &g);
 size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes);
 // `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
-                          hipStream_t st);
+                          hipStream_t st, bool pair_rows = false);
 // `centred`: npc1 was projected with c1_WnT_c / c1_bias_c and the kernel multiplies with c1_WeT_c: zero row mean, the
 // LayerNorm(2Fn) in front of the gate needs the sum of squares only (split-f16 instantiations)
 size_t node_atom_lds_bytes(int max_deg);
 // (split-f16 products on the centred c1_linear only: PassW::c1_WeT_c, npc1 from c1_WnT_c / c1_bias_c)
 void launch_node_atom(const float *edge, const float *node_in, const float *npc1, float *node_out, int S, const Graph &g,
-                      Dims d, const PassW<float> &w, hipStream_t st);
+                      Dims d, const PassW<float> &w, hipStream_t st, bool pair_rows = false);
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, bool centred, hipStream_t st);
 // `agg_out` (taped runs, else null): the pre-LayerNorm triplet sums per destination edge
@@ -283,7 +289,7 @@ size_t edge_ps_lds_bytes(int tile_out_rows, int tile_in_rows);
 bool edge_ps_tile_ok(const int *rb, const int *re, int D);
 // `fail`: device int, set to a nonzero code if a bounded spin wait inside the kernel ran out (never in a correct run)
 void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
-                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st);
+                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows = false);
 
 // Opt-in experiment kernels (experiments/kernels_fused_experiments.hip): compiled and reachable only with
 // -DRN_EXPERIMENTS=1; the product build has neither the kernels nor the RN_POTGNN_EDGE2 / EDGE3 / NODE_WAVE knobs.

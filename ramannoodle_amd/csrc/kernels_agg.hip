@@ -155,6 +155,63 @@ void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
   geom_rbf_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride,
                                                                       offsets, coef, d, unit4, edge0);
 }
+// The same with the rows written as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs), FeP = 64
+__global__ __launch_bounds__(256) void geom_rbf_pairs_kernel(const double *__restrict__ pos, int S, Graph g,
+                                                             const float *__restrict__ lat_base, int lat_stride,
+                                                             const float *__restrict__ offs, float coef, Dims d,
+                                                             float *__restrict__ unit4, float *__restrict__ edge0) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  __shared__ float sdist[256];
+  const int64_t total = (int64_t)S * g.E;
+  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  const int64_t row = r0 + threadIdx.x;
+  float dist = 0;
+  if (row < total) {
+    const int s = (int)(row / g.E), e = (int)(row % g.E);
+    const int a = g.edge_a[e], b = g.edge_b[e];
+    const float *lat = lat_base + (int64_t)s * lat_stride;
+    const double *pa = pos + ((int64_t)s * g.N + a) * 3;
+    const double *pb = pos + ((int64_t)s * g.N + b) * 3;
+    float f[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = wrap_min_image((float)pb[k] - (float)pa[k]);
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = f[0] * lat[k] + f[1] * lat[3 + k] + f[2] * lat[6 + k];
+    dist = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    float *u = unit4 + row * 4;
+    u[0] = c[0] / dist;
+    u[1] = c[1] / dist;
+    u[2] = c[2] / dist;
+    u[3] = dist;
+  }
+  sdist[threadIdx.x] = dist;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256 * 8; i += 256) {  // (row, group m of eight columns)
+    const int r = i >> 3, m = i & 7;
+    if (r0 + r >= total) break;
+    const float dd = sdist[r];
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = 8 * m + j;
+      const float x = dd - offs[col];
+      const float v = (col < d.Fe) ? exp(coef * (x * x)) : 0.0f;
+      hi[j] = (_Float16)v;
+      lo[j] = (_Float16)(v - (float)hi[j]);
+    }
+    h8 *o = reinterpret_cast<h8 *>(edge0 + (r0 + r) * 64 + 8 * m);
+    o[0] = hi;
+    o[1] = lo;
+  }
+}
+void launch_geom_rbf_pairs(const double *pos, int S, const Graph &g, const float *lattice, int lat_stride, const float *offsets,
+                           float coef, Dims d, float *unit4, float *edge0, hipStream_t st) {
+  const int64_t total = (int64_t)S * g.E;
+  if (total == 0) return;
+  geom_rbf_pairs_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride, offsets, coef, d, unit4,
+                                                                         edge0);
+}
 template void launch_geom_rbf<float>(const double *, int, const Graph &, const float *, int,
                                      const float *, float, Dims, float *, float *, hipStream_t);
 template void launch_geom_rbf<double>(const double *, int, const Graph &, const double *, int,

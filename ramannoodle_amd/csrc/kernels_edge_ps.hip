@@ -248,7 +248,9 @@ __device__ __forceinline__ f32x2 ln_row2(f32x2 x, f32x2 g, f32x2 b, float inv_n,
 }
 }  // namespace
 
-template <bool PAD>
+// PRE: edge rows in and out are split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs): the producers' edge tiles are MFMA-ready
+// as they land, the consumers read / write the (hi, lo) halves of their two columns
+template <bool PAD, bool PRE>
 __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
@@ -371,18 +373,22 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       dma16(eb0 + (r0 * FP + 4 * piece), dst + 2 * PS_TILE);
       dma16(eb1 + (r1 * FP + 4 * piece), dst + 3 * PS_TILE);
     };
-    // every lane turns the 16-byte slots IT fetched into [hi x4 | lo x4] halves in place: the edge rows, and
+    // every lane turns the 16-byte slots IT fetched into its shares of the [hi x8] / [lo x8] slot pairs (fused_common.hpp:
+    // write_pair) in place: the edge rows, and
     // node[b] * node[a] (the c2 operand) in the node[b] tile
     auto split_landed = [&](int buf, int ln) {
-      const unsigned sa = atile_a + (unsigned)(buf * PS_BUF + wave * 256 + ln * 4) * 4u;
-      auto f4 = [](const f32x4 &v) { return float4{v[0], v[1], v[2], v[3]}; };
+      const int row = 4 * wave + (ln >> 4), phys = ln & 15;
+      const unsigned tb = atile_a + (unsigned)(buf * PS_BUF) * 4u;
+      const unsigned sa = tb + (unsigned)(wave * 256 + ln * 4) * 4u;
       f32x4 u, v, w;
-      lds_read3(sa, sa + 2 * PS_TILE * 4, sa + 3 * PS_TILE * 4, u, v, w);
-      lds_write4(sa, split_slot(f4(u)));
-      lds_write4(sa + 2 * PS_TILE * 4, split_slot(f4(v)));
-      lds_write4(sa + 3 * PS_TILE * 4, split_slot(f4(w)));
+      if constexpr (!PRE) {
+        lds_read3(sa, sa + 2 * PS_TILE * 4, sa + 3 * PS_TILE * 4, u, v, w);
+        write_pair(tb, row, phys, u);
+        write_pair(tb + 2 * PS_TILE * 4, row, phys, v);
+        write_pair(tb + 3 * PS_TILE * 4, row, phys, w);
+      }
       lds_read2(sa + PS_TILE * 4, atile_a + (unsigned)(2 * PS_BUF + wave * 256 + ln * 4) * 4u, u, v);
-      lds_write4(sa + PS_TILE * 4, split_slot(f4(u * v)));
+      write_pair(tb + PS_TILE * 4, row, phys, u * v);
     };
     static_assert(PS_MAXNEW == 2, "split_landed / request are written for two source tiles per step");
 
@@ -454,13 +460,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       if (cur.has_dest) {
         const int slot0 = (cur.g & 1) * PS_ND;
         f16x8 ah[2], al[2];
-        ps_load_split_a(tb_a, l15, quad, ah, al);
+        load_pair_a(tb_a, l15, quad, ah, al);
         if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
 #pragma unroll
         for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3
           *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t] * inv4;
         f32x4 accC[2];
-        ps_load_split_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
+        load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
                          accC[0], accC[1]);  // + the centred c2 bias
 #pragma unroll
         for (int t = 0; t < 2; ++t) accC[t] *= sc2;
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         }
         f16x8 ah[2], al[2];
         f32x4 g3v[2];
-        ps_load_split_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (8 * FP + mycol) * 4,
+        load_pair_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (8 * FP + mycol) * 4,
                          lnp_a + (8 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3
         if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
         float ss = 0.f;
@@ -551,7 +557,14 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       f32x2 old2;
       if (active) {
-        old2 = *reinterpret_cast<const f32x2 *>(a.edge_in + drow * FP + cc);
+        if constexpr (PRE) {  // columns cc, cc + 1 of group m = cc / 8: two f16 of the hi slot, two of the lo slot
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          const h2 *pp = reinterpret_cast<const h2 *>(a.edge_in + drow * FP + (cc >> 3) * 8) + ((cc & 7) >> 1);
+          const h2 hh = pp[0], ll = pp[4];
+          old2 = f32x2{(float)hh[0] + (float)ll[0], (float)hh[1] + (float)ll[1]};
+        } else {
+          old2 = *reinterpret_cast<const f32x2 *>(a.edge_in + drow * FP + cc);
+        }
         const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
         const Vec4<float> xf = load4<float>(prow + c0), xc = load4<float>(prow + FP + c0);
         float sp = 0.f;
@@ -649,7 +662,16 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         const f32x2 gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
         const f32x2 g2 = {gate(xf.x * rstd2 * gf.x + bf.x, xc.x * rstd2 * gc.x + bc.x), gate(xf.y * rstd2 * gf.y + bf.y, xc.y * rstd2 * gc.y + bc.y)};
         const f32x2 c2 = ln_row2<PAD>(g2, *reinterpret_cast<const f32x2 *>(s_c2n2g + cc), *reinterpret_cast<const f32x2 *>(s_c2n2b + cc), invn, nvalid2);
-        *reinterpret_cast<f32x2 *>(a.edge_out + drow * FP + cc) = f32x2{fast_tanh(old2.x + c2.x + c3.x), fast_tanh(old2.y + c2.y + c3.y)};
+        const f32x2 y = {fast_tanh(old2.x + c2.x + c3.x), fast_tanh(old2.y + c2.y + c3.y)};
+        if constexpr (PRE) {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          h2 *pp = reinterpret_cast<h2 *>(a.edge_out + drow * FP + (cc >> 3) * 8) + ((cc & 7) >> 1);
+          const h2 hh = {(_Float16)y.x, (_Float16)y.y};
+          pp[0] = hh;
+          pp[4] = h2{(_Float16)(y.x - (float)hh[0]), (_Float16)(y.y - (float)hh[1])};
+        } else {
+          *reinterpret_cast<f32x2 *>(a.edge_out + drow * FP + cc) = y;
+        }
       }
       ps_arrive(sync_a + ((gr & 1u) ? C_DONE1 : C_DONE0), lane);  // this wave no longer reads round gr's buffers
       PS_TICK(13);
@@ -702,12 +724,13 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
 }
 
 void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
-                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st) {
+                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows) {
   if (S == 0 || g.E == 0) return;
   EdgePsArgs a{edge_in, edge_out, node, np3, agg_out, fail, S, g, d, w};
   const size_t lds = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows).total;
   const bool pad = d.Fe != d.FeP;
-  auto kern = pad ? &edge_block_ps_kernel<true> : &edge_block_ps_kernel<false>;
+  auto kern = pair_rows ? (pad ? &edge_block_ps_kernel<true, true> : &edge_block_ps_kernel<false, true>)
+                        : (pad ? &edge_block_ps_kernel<true, false> : &edge_block_ps_kernel<false, false>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int cus = 0;
   if (cus == 0) {

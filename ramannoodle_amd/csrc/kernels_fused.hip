@@ -794,7 +794,8 @@ struct ReadoutFusedArgs {
   ReadoutW<float> w;
 };
 
-template <bool F16>
+// PRE (with F16): the edge rows are split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs) -- the first layer's operand as fetched
+template <bool F16, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs a, int tiles_per_wave) {
   constexpr int LDW = FP + 4;  // floats: row stride of the transposed f32 weights and of the slabs
   constexpr int LDH = FP + 8;  // halves: row stride of the transposed split-f16 weights
@@ -847,6 +848,15 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
       split_f16x8(af + 8, ah[1], al[1]);
     }
   };
+  // PRE: this lane's 64 bytes of a pair row (k = 16 quad .. + 15) are [hi x8][lo x8] of the two K = 32 slices
+  auto operand_pairs = [&](const float (&af)[KS]) {
+    union { float f[4]; f16x8 h; } u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[j].f[i] = af[4 * j + i];
+    ah[0] = u[0].h; al[0] = u[1].h; ah[1] = u[2].h; al[1] = u[3].h;
+  };
   auto product = [&](const float (&af)[KS], const unsigned char *raw, int rows, int nt, f32x4 &acc) {
     acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (F16) {
@@ -897,7 +907,8 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
     if (it + 1 < tiles_per_wave && tile + 1 < num_tiles) fetch(tile + 1);
     f32x4 acc;
     // h1 = ssp(BN(edge W0^T))
-    operand(af);
+    if constexpr (PRE) operand_pairs(af);
+    else operand(af);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       product(af, w0_raw, FP, nt, acc);
@@ -929,13 +940,14 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
 }
 
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
-                          hipStream_t st) {
+                          hipStream_t st, bool pair_rows) {
   if (M == 0) return;
   ReadoutFusedArgs a{edge, pol, M, w};
   const int64_t tiles = (M + 15) / 16;
   const int tpw = 8;
   const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
-  if (f16) readout_fused_kernel<true><<<blocks, 256, 0, st>>>(a, tpw);
+  if (f16 && pair_rows) readout_fused_kernel<true, true><<<blocks, 256, 0, st>>>(a, tpw);
+  else if (f16) readout_fused_kernel<true><<<blocks, 256, 0, st>>>(a, tpw);
   else readout_fused_kernel<false><<<blocks, 256, 0, st>>>(a, tpw);
 }
 

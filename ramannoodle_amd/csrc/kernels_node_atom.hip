@@ -67,7 +67,8 @@ __device__ __forceinline__ float part_get(unsigned buf, int l15) {
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <bool PAD>
+// PRE: the edge rows arrive as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs) -- the operand tile is MFMA-ready as it lands
+template <bool PAD, bool PRE>
 __global__ __launch_bounds__(256, RN_NA_WGS) void node_block_atom_kernel(NodeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, RN_NA_WGS) void node_block_atom_kernel(NodeFus
 #pragma unroll
   for (int j = 0; j < NA_D - 1; ++j) request(j);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_D - 2) : "memory");
-  if (!(RN_NA_PROBE & 4)) split_own_pair(atile_a, frow, l15);  // this lane's 16 bytes of step 0
+  if (!PRE && !(RN_NA_PROBE & 4)) split_own_pair(atile_a, frow, l15);  // this lane's 16 bytes of step 0
   wg_barrier();
 
   int k = 0;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256, RN_NA_WGS) void node_block_atom_kernel(NodeFus
       }
       // ---- the next round's rows: requested NA_D - 1 rounds ago, one younger request may still be in flight
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_D - 3) : "memory");
-      if (!(RN_NA_PROBE & 4)) split_own_pair(atile_a + (unsigned)(((k + 1) & (NA_D - 1)) * NG * FP) * 4u, frow, l15);
+      if (!PRE && !(RN_NA_PROBE & 4)) split_own_pair(atile_a + (unsigned)(((k + 1) & (NA_D - 1)) * NG * FP) * 4u, frow, l15);
       wg_barrier();
       request((k + NA_D - 1) & (NA_D - 1));                 // into the slot round k - 1 multiplied from
       if (r == 0 && f + 1 < nframes) request_frame(f + 1);  // landed by round 2 (the waits above), read after the last
@@ -265,12 +266,13 @@ __global__ __launch_bounds__(256, RN_NA_WGS) void node_block_atom_kernel(NodeFus
 size_t node_atom_lds_bytes(int max_deg) { return node_atom_lds(max_deg).total; }
 
 void launch_node_atom(const float *edge, const float *node_in, const float *npc1, float *node_out, int S, const Graph &g,
-                      Dims d, const PassW<float> &w, hipStream_t st) {
+                      Dims d, const PassW<float> &w, hipStream_t st, bool pair_rows) {
   if (S == 0 || g.N == 0) return;
   NodeFusedArgs a{edge, node_in, npc1, node_out, S, g, d, w};
   const bool pad = d.Fn != d.FnP;
   const size_t lds = node_atom_lds_bytes(g.na_max_deg);
-  auto kern = pad ? &node_block_atom_kernel<true> : &node_block_atom_kernel<false>;
+  auto kern = pair_rows ? (pad ? &node_block_atom_kernel<true, true> : &node_block_atom_kernel<false, true>)
+                        : (pad ? &node_block_atom_kernel<true, false> : &node_block_atom_kernel<false, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int cus = 0;

@@ -799,7 +799,8 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
                 "split_f16_mfma": bool(flags & 4), "narrow_kernels": bool(flags & 8),
                 "mfma_range_fallback": bool(flags & 16), "pipelined_edge_block": bool(flags & 32),
                 "twelve_wave_edge_block": bool(flags & 64), "experiment_kernels": bool(flags & 128),
-                "role_split_edge_block": bool(flags & 256), "atom_owning_node_block": bool(flags & 512)}
+                "role_split_edge_block": bool(flags & 256), "atom_owning_node_block": bool(flags & 512),
+                "split_f16_pair_rows": bool(flags & 1024)}
 
     def set_profiling(self, mode: int) -> None:
         """0 = off, 1 = HIP-event timing of every kernel launch, 100+k = kernel k only."""

@@ -1362,6 +1362,35 @@ def test_atom_owning_node_block_against_oracle_and_row_kernel(monkeypatch, case,
     assert _rel_err((got - oracle.mean) / oracle.std, (old - oracle.mean) / oracle.std) < REL
 
 
+@pytest.mark.parametrize("case,cutoff,fn,fe,passes,frames", [
+    ("rocksalt64_parity", 3.2, 64, 64, 3, 40),
+    ("triclinic20", 3.4, 64, 64, 2, 5),
+    ("triclinic20", 3.0, 40, 50, 2, 3),          # padded columns (zeros in the pair rows too)
+])
+def test_split_f16_pair_rows_against_oracle_and_float32_rows(monkeypatch, case, cutoff, fn, fe, passes, frames):
+    """Edge rows stored as the split-f16 operand pairs (written once by the geometry kernel / the EdgeBlock epilogue, read as they
+    are by the NodeBlock, the next EdgeBlock and the readout) give what plain float32 rows give (``RN_POTGNN_PAIR_ROWS=0``): the
+    MFMA operands are the same bits, only the residual ``tanh(edge + c2 + c3)`` sees ``hi + lo`` (2^-25 absolute) for ``edge``."""
+    from oracle import potgnn_oracle as O
+    g = load_golden(case)
+    rng = np.random.default_rng(17)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=frames)] + rng.normal(scale=2e-3, size=(frames,) + base.shape[1:])
+    monkeypatch.setenv("RN_POTGNN_NODE_ATOM", "1")
+    model, oracle = _random_model(g, cutoff, fn, fe, passes, seed=fn + 3 * fe)
+    got = model.calc_polarizabilities(pos)
+    flags = model.config_flags()
+    assert flags["role_split_edge_block"] and flags["atom_owning_node_block"] and flags["split_f16_pair_rows"]
+    want = O.calc_polarizabilities(oracle, pos[:6], faithful=False)
+    assert _rel_err((got[:6] - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos), got)
+    monkeypatch.setenv("RN_POTGNN_PAIR_ROWS", "0")
+    plain, _ = _random_model(g, cutoff, fn, fe, passes, seed=fn + 3 * fe)
+    old = plain.calc_polarizabilities(pos)
+    assert not plain.config_flags()["split_f16_pair_rows"]
+    assert _rel_err((got - oracle.mean) / oracle.std, (old - oracle.mean) / oracle.std) < 2e-6
+
+
 def test_centred_weight_copies_follow_a_device_resident_step():
     """The role-specialised EdgeBlock multiplies with copies of c3_linear / c2_linear centred over their output columns.
     After a device-resident Adam step those copies are recomputed on the device (``refresh_derived_kernel`` kind 3):
