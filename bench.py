@@ -181,7 +181,7 @@ def committed_profile(name, n, e, fn, fe):
     return None
 
 
-def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow=False):
+def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow=False, atom=False):
     """The other scatter-aggregate of a pass: B_NB = 4 (E Fe + 2 N Fn) algorithmic bytes per
     structure and pass over the HIP-event time of the NodeBlock kernel."""
     ms, launches = times.get("node_agg", (0.0, 0))
@@ -190,12 +190,14 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow
     per = 4 * (e * fe + 2 * n * fn)
     achieved = per * frames * passes * steps / (ms * 1e-3) / 1e9
     traffic = None
-    rec = committed_profile("node_narrow_traffic.json" if narrow else "node_fused_traffic.json", n, e, fn, fe) \
-        if (fused or narrow) else None
+    rec = committed_profile("node_narrow_traffic.json" if narrow else "node_atom_traffic.json" if atom
+                            else "node_fused_traffic.json", n, e, fn, fe) if (fused or narrow) else None
     if rec:
         traffic = rec["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
     return {"kernel": "node_tiled_kernel (NodeBlock scatter-aggregate, projections included: in-edge rows staged "
                       "through LDS 256 at a time, one lane per row, per-atom sums from LDS)" if narrow
+            else "node_block_atom_kernel (NodeBlock: 16-atom tiles, MFMA c1 projection with the gate on the accumulators, "
+                 "per-atom sums in registers, operand rows through a 4-deep LDS-DMA ring)" if fused and atom
             else "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
             else "node_agg_kernel (NodeBlock scatter-aggregate; its c1 projection is a separate launch)",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -258,7 +260,8 @@ def measure_case(wl, device, steps, warmup, label):
                      "traffic_source": rec["_path"] if rec else None,
                      "launches": agg_launches, "avg_launch_ms": agg_ms / agg_launches if agg_launches else None,
                      "algorithmic_bytes_per_structure_pass": per_pass},
-        "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow),
+        "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow,
+                                                 bool(flags.get("atom_owning_node_block"))),
     }
 
 
@@ -627,9 +630,13 @@ def main():
                                     "f16 MFMA products with fp32 accumulation; measured error vs float64 6e-7, as "
                                     "exact-fp32 MFMA (RN_POTGNN_MFMA=f32)" if flags["split_f16_mfma"] and fused
                                     else "fp32 scalar FMA" if narrow else "exact fp32 MFMA"),
+                # layout of the edge embedding in HBM between the kernels of a pass (include/rn_potgnn.h, flag bit 10)
+                "edge_rows": ("split-f16 operand pairs (f16 hi x8 | f16 lo x8 per eight columns, 256 B per row)"
+                              if flags.get("split_f16_pair_rows") else "float32"),
             },
             "roofline": roofline,
-            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused, narrow),
+            "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, mine, passes, args.steps, fused, narrow,
+                                                     bool(flags.get("atom_owning_node_block"))),
             "roofline_projection": projection_roofline(times, e, fn, fe, mine, passes, args.steps),
             # the same step through the C ABI's host-buffer entry, pipelined (PCIe both ways inside the clock);
             # `value` is the HBM-resident figure the contract asks for

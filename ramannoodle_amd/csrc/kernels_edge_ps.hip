@@ -115,7 +115,7 @@ __host__ __device__ inline PsLds ps_lds(int maxR, int maxD) {
   L.bufP = off; off += (size_t)2 * PS_ND * LDQ * 4;
   L.bufC = off; off += (size_t)2 * PS_ND * LDQ * 4;
   L.atile = off; off += ((size_t)2 * PS_BUF + PS_TILE) * 4;  // two buffers + the node[a] tile they share
-  L.lnp = off; off += (size_t)14 * FP * 4;
+  L.lnp = off; off += (size_t)16 * FP * 4;
   L.ints = off; off += up((maxR16 + 7 * (size_t)maxD + 2 * rounds + 8) * 4);
   L.sync = off; off += 128;
   L.total = off;
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   float *na_tile = atile + 2 * PS_BUF;
   float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
   float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
-        *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP, *s_g3 = lnp + 8 * FP, *s_ig3 = lnp + 10 * FP, *s_c2b = lnp + 12 * FP;
+        *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP, *s_g3 = lnp + 8 * FP, *s_ig3 = lnp + 10 * FP, *s_c2b = lnp + 12 * FP,
+        *s_g3q = lnp + 14 * FP;
   int *ints = reinterpret_cast<int *>(smem_raw + L.ints);
   unsigned *sync = reinterpret_cast<unsigned *>(smem_raw + L.sync);
   const unsigned sync_a = lds_addr(sync);  // LDS byte address of the signalling words
@@ -296,8 +297,11 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     s_c2n1b[c] = a.w.c2_norm_1.b[c];
     s_c2b[c] = a.w.c2_bias_c[c];
     const float gam = a.w.c3_norm_1s.g[c];  // c3_norm_1's scale times the gate's exp2 factor (-log2e | 2 log2e)
-    s_g3[c] = gam;
-    s_ig3[c] = ((c % FP) < a.d.Fe) ? 1.0f / gam : 0.0f;
+    // The producers leave their accumulators in the weights' power-of-two prescale: P' rows carry 1/inv4, Q' rows are
+    // multiplied by gamma / s5 as they go to the ring, c2 rows carry 1/invc2 (LayerNorm does not see it: eps scaled)
+    s_g3[c] = gam * a.w.mfma_scale_c[1];
+    s_ig3[c] = ((c % FP) < a.d.Fe) ? a.w.mfma_scale_c[1] / gam : 0.0f;
+    s_g3q[c] = gam * a.w.mfma_scale_c[3];
     if (c < FP) {
       s_c3n2g[c] = a.w.c3_norm_2.g[c];
       s_c3n2b[c] = a.w.c3_norm_2.b[c];
@@ -340,14 +344,14 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     const int colbase = wave * 32;  // this wave's 32 of the 128 pre-activation columns
     // (uniform values: kept in SGPRs -- as VGPR operands of packed multiplies each would cost a register pair)
     auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-    const float s4 = uni(a.w.mfma_scale_c[0]), inv4 = uni(a.w.mfma_scale_c[1]);
+    const float s4 = uni(a.w.mfma_scale_c[0]);
     const float s5 = uni(a.w.mfma_scale_c[2]), inv5 = uni(a.w.mfma_scale_c[3]);
-    const float sc2 = uni(a.w.mfma_scale_c[4]), invc2 = uni(a.w.mfma_scale_c[5]);
+    const float sc2 = uni(a.w.mfma_scale_c[4]);
     WaveB<true> bW4, bW5, bWc;
     bW4.load(a.w.c3_WeT_c, 4 * FP, colbase, l15, quad, s4);
     bW5.load(a.w.c3_WeT_c + 2 * FP, 4 * FP, colbase, l15, quad, s5);
     bWc.load(a.w.c2_WT_c, 2 * FP, colbase, l15, quad, sc2);
-    const float inv2n = uni(1.0f / (float)(2 * a.d.Fe));
+    const float qscale = uni(inv5 * inv5 / (float)(2 * a.d.Fe));  // |q|^2 / 2Fe from the prescaled accumulators
 
     // LDS-DMA of a step's operand rows: wave w brings rows 4w..4w+3 of every tile; slot (row, piece p) receives
     // global piece p ^ row (the XOR swizzle load_split_a undoes).  Always the same five requests -- a step without
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
 #pragma unroll
         for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3
-          *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t] * inv4;
+          *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t];
         f32x4 accC[2];
         load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
                          accC[0], accC[1]);  // + the centred c2 bias
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t] * invc2;
+          *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t];
       }
       PS_TICK(6);
       for (int n = 0; n < ((RN_PS_PROBE & 128) ? 0 : cur.ntiles); ++n) {
@@ -487,20 +491,18 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         }
         f16x8 ah[2], al[2];
         f32x4 g3v[2];
-        load_pair_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (8 * FP + mycol) * 4,
-                         lnp_a + (8 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3
+        load_pair_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (14 * FP + mycol) * 4,
+                         lnp_a + (14 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3q
         if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
         float ss = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          accQ[t] *= inv5;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int e = 0; e < 4; ++e) ss = fmaf(accQ[t][e], accQ[t][e], ss);
-        }
         ss = sum_xor32(sum_xor16(ss));  // the row's four lanes l15 + 16 quad
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(ring + ringrow * LDQ + mycol + 16 * t) = accQ[t] * g3v[t];
-        if (quad == 0) qnp[ringrow * 4 + wave] = ss * inv2n;
+        if (quad == 0) qnp[ringrow * 4 + wave] = ss * qscale;
       }
       PS_TICK(7);
       // ---- the LAST producer to get here completes |q|^2 of the step's new rows (every producer's part is in LDS by then)
@@ -529,6 +531,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   const int cc = c0 + 2 * part;             // the two columns this lane finishes in the epilogue
   const int nvalid2 = min(max(a.d.Fe - cc, 0), 2);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
+  const float spscale = a.w.mfma_scale_c[1] * a.w.mfma_scale_c[1] * inv2n;  // P' rows arrive prescaled (see s_g3)
+  const float eps_c2 = 1e-5f * a.w.mfma_scale_c[4] * a.w.mfma_scale_c[4];     // so do the c2 rows
   f32x2 bf2[2], bc2[2];  // c3_norm_1's shift with the exp2 scale of the gate folded in
   {
     const Vec4<float> bf = load4<float>(a.w.c3_norm_1s.b + c0), bc = load4<float>(a.w.c3_norm_1s.b + FP + c0);
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
             pc2[hh] = f32x2{xc.v[2 * hh] * g3c.v[2 * hh], xc.v[2 * hh + 1] * g3c.v[2 * hh + 1]};
           }
         }
-        const float spe = sp * inv2n + 1e-5f;
+        const float spe = sp * spscale + 1e-5f;
         const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
         const int half = (cnt + 1) >> 1;
         const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's half of the triplets
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         // zero mean (centred weights) and exact zeros in its padded columns, so its variance is the plain sum of squares
         const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
         const f32x2 xf = *reinterpret_cast<const f32x2 *>(crow + cc), xc = *reinterpret_cast<const f32x2 *>(crow + FP + cc);
-        const float rstd2 = fast_rsq(lg_sum32(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + 1e-5f);
+        const float rstd2 = fast_rsq(lg_sum32(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + eps_c2);
         const f32x2 gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
         const f32x2 gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
         const f32x2 g2 = {gate(xf.x * rstd2 * gf.x + bf.x, xc.x * rstd2 * gc.x + bc.x), gate(xf.y * rstd2 * gf.y + bf.y, xc.y * rstd2 * gc.y + bc.y)};

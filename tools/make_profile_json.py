@@ -18,7 +18,7 @@ src, dst, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 n, e, fn, fe, frames, passes = (int(v) for v in sys.argv[4:10])
 structures = frames
 kernels = {"edge": ("edge_block_ps_kernel", "edge_block_fused_kernel", "edge_block2_kernel", "edge_narrow_kernel", "edge_agg_kernel"),
-           "node": ("node_block_fused_kernel", "node_tiled_kernel", "node_narrow_kernel", "node_agg_kernel")}
+           "node": ("node_block_atom_kernel", "node_block_fused_kernel", "node_tiled_kernel", "node_narrow_kernel", "node_agg_kernel")}
 traffic = open(os.path.join(src, "pmc_traffic.txt")).read().splitlines()
 sq = open(os.path.join(src, "sq_counters.txt")).read().splitlines()
 os.makedirs(dst, exist_ok=True)
@@ -36,7 +36,7 @@ for kind, names in kernels.items():
                "write_bytes_per_structure_pass": wr * 1e6 * launches / (structures * passes),
                "source": f"{os.path.basename(src)}/pmc_traffic.txt: {launches} launches over {structures} structures x {passes} passes"}
         family = ("narrow" if ("narrow" in kernel or "tiled" in kernel) else "ps" if "block_ps" in kernel
-                  else "fused" if ("fused" in kernel or "block2" in kernel) else "agg")
+                  else "atom" if "block_atom" in kernel else "fused" if ("fused" in kernel or "block2" in kernel) else "agg")
         json.dump(rec, open(os.path.join(dst, f"{prefix}{kind}_{family}_traffic.json"), "w"), indent=1)
         print(kind, "traffic", round(per), "B per structure and pass")
         break
@@ -48,7 +48,7 @@ for kind, names in kernels.items():
                    "valu_plus_mfma_busy": valu + mfma, "waves_per_simd": waves, "wait_any": float(f[-4]),
                    "source": f"{os.path.basename(src)}/sq_counters.txt"}
             family = ("narrow" if ("narrow" in line or "tiled" in line) else "ps" if "block_ps" in line
-                      else "fused" if ("fused" in line or "block2" in line) else "agg")
+                      else "atom" if "block_atom" in line else "fused" if ("fused" in line or "block2" in line) else "agg")
             json.dump(rec, open(os.path.join(dst, f"{prefix}{kind}_{family}_issue.json"), "w"), indent=1)
             print(kind, "issue", valu + mfma)
             break
