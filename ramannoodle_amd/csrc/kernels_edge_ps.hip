@@ -541,6 +541,14 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     bc2[0] = f32x2{bc.v[0], bc.v[1]};
     bc2[1] = f32x2{bc.v[2], bc.v[3]};
   }
+  // LayerNorm parameters of this lane's two epilogue columns: registers (the consumers have ~50 to spare), not eight LDS
+  // reads per round
+  const f32x2 k_c3g = *reinterpret_cast<const f32x2 *>(s_c3n2g + cc), k_c3b = *reinterpret_cast<const f32x2 *>(s_c3n2b + cc);
+  const f32x2 k_c21gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), k_c21bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
+  const f32x2 k_c21gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), k_c21bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
+  const f32x2 k_c22g = *reinterpret_cast<const f32x2 *>(s_c2n2g + cc), k_c22b = *reinterpret_cast<const f32x2 *>(s_c2n2b + cc);
+  const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);  // (likewise: the folds of a P' row)
+  const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
   const float *ringc = ring + c0;
   const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
   int ub = 0;                      // ring row of the unit's first source row
@@ -578,8 +586,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         // pd = p / gamma * (2 / 2Fe), pg = p * gamma;  var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
         f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2];
         {
-          const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);
-          const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
           const float two_inv = 2.0f * inv2n;
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
@@ -656,16 +662,15 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         // from here on the two halves split the COLUMNS: this lane finishes columns cc, cc + 1
         const f32x2 a2 = part ? f32x2{acc[2], acc[3]} : f32x2{acc[0], acc[1]};
         if (a.agg_out) *reinterpret_cast<f32x2 *>(a.agg_out + drow * FP + cc) = a2;
-        const f32x2 c3 = ln_row2<PAD>(a2, *reinterpret_cast<const f32x2 *>(s_c3n2g + cc), *reinterpret_cast<const f32x2 *>(s_c3n2b + cc), invn, nvalid2);
+        const f32x2 c3 = ln_row2<PAD>(a2, k_c3g, k_c3b, invn, nvalid2);
         // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228); the pre-activation row has
         // zero mean (centred weights) and exact zeros in its padded columns, so its variance is the plain sum of squares
         const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
         const f32x2 xf = *reinterpret_cast<const f32x2 *>(crow + cc), xc = *reinterpret_cast<const f32x2 *>(crow + FP + cc);
         const float rstd2 = fast_rsq(lg_sum32(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + eps_c2);
-        const f32x2 gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
-        const f32x2 gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
+        const f32x2 gf = k_c21gf, bf = k_c21bf, gc = k_c21gc, bc = k_c21bc;
         const f32x2 g2 = {gate(xf.x * rstd2 * gf.x + bf.x, xc.x * rstd2 * gc.x + bc.x), gate(xf.y * rstd2 * gf.y + bf.y, xc.y * rstd2 * gc.y + bc.y)};
-        const f32x2 c2 = ln_row2<PAD>(g2, *reinterpret_cast<const f32x2 *>(s_c2n2g + cc), *reinterpret_cast<const f32x2 *>(s_c2n2b + cc), invn, nvalid2);
+        const f32x2 c2 = ln_row2<PAD>(g2, k_c22g, k_c22b, invn, nvalid2);
         const f32x2 y = {fast_tanh(old2.x + c2.x + c3.x), fast_tanh(old2.y + c2.y + c3.y)};
         if constexpr (PRE) {
           typedef _Float16 h2 __attribute__((ext_vector_type(2)));
