@@ -295,7 +295,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   for (int c = tid; c < 2 * FP; c += PS_THREADS) {
     s_c2n1g[c] = a.w.c2_norm_1.g[c];
     s_c2n1b[c] = a.w.c2_norm_1.b[c];
-    s_c2b[c] = a.w.c2_bias_c[c];
+    s_c2b[c] = a.w.c2_bias_c[c] * a.w.mfma_scale_c[4];  // (in the c2 weight's prescale: the accumulator's seed as it is)
     const float gam = a.w.c3_norm_1s.g[c];  // c3_norm_1's scale times the gate's exp2 factor (-log2e | 2 log2e)
     // The producers leave their accumulators in the weights' power-of-two prescale: P' rows carry 1/inv4, Q' rows are
     // multiplied by gamma / s5 as they go to the ring, c2 rows carry 1/invc2 (LayerNorm does not see it: eps scaled)
@@ -472,8 +472,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         f32x4 accC[2];
         load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
                          accC[0], accC[1]);  // + the centred c2 bias
-#pragma unroll
-        for (int t = 0; t < 2; ++t) accC[t] *= sc2;
         if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
