@@ -2206,7 +2206,11 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // Infinity Cache does not reward small chunks.  The fused kernels take a whole CU each, so a
     // second lane has nothing to overlap with: ONE lane with an 8 GiB workspace (of 288 GB HBM)
     // beats two lanes of 1.5 GiB (63.7 k vs 62.1 k structures/s at 4000 frames).  The unfused
-    // pipeline keeps two alternating lanes of 1.5 GiB.
+    // pipeline keeps two alternating lanes of 1.5 GiB.  Round 4: the role-specialised EdgeBlock is bound by SIMD issue and
+    // leaves HBM idle and ~10 KiB of LDS per CU free, so the small HBM-bound kernels of a second lane (geometry, per-atom
+    // projections, readout reduction) do run under it: RN_POTGNN_LANES=2 gives 48.9 -> 49.2 k structures/s on config 3.
+    // Not the default: kernels of two lanes wait for each other's LDS, and HIP events around a launch then time the wait
+    // too (the NodeBlock's HBM figure of the bench line reads 6 % instead of 46 %).
     const bool want_node = getenv("RN_POTGNN_NODE_FUSED") ? atoi(getenv("RN_POTGNN_NODE_FUSED")) != 0 : true;
     hp->use_node_fused = hp->use_fused && want_node && node_fused_lds_bytes(hp->g) <= 64 * 1024;
     hp->want_pair_rows = !(getenv("RN_POTGNN_PAIR_ROWS") && atoi(getenv("RN_POTGNN_PAIR_ROWS")) == 0);
