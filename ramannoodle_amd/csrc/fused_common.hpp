@@ -307,6 +307,17 @@ __device__ __forceinline__ void load_pair_a(unsigned tile_addr, int l15, int qua
         "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16)
       : "memory");
 }
+// the same from four precomputed lane addresses of ring slot 0 plus a compile-time byte offset (the slot): no address
+// arithmetic at all in a loop unrolled over the ring
+template <int OFF>
+__device__ __forceinline__ void load_pair_a_at(const unsigned (&a4)[4], f16x8 (&ah)[2], f16x8 (&al)[2]) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\t"
+      "ds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(ah[0]), "=&v"(al[0]), "=&v"(ah[1]), "=&v"(al[1])
+      : "v"(a4[0]), "v"(a4[1]), "v"(a4[2]), "v"(a4[3]), "n"(OFF)
+      : "memory");
+}
 // the same plus two more 16-byte reads (a bias / scale pair) under the one wait
 __device__ __forceinline__ void load_pair_a2(unsigned tile_addr, int l15, int quad, f16x8 (&ah)[2], f16x8 (&al)[2], unsigned x0,
                                              unsigned x1, f32x4 &e0, f32x4 &e1) {

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void geom_rbf_pairs_kernel(const double *__res
     for (int j = 0; j < 8; ++j) {
       const int col = 8 * m + j;
       const float x = dd - offs[col];
-      const float v = (col < d.Fe) ? exp(coef * (x * x)) : 0.0f;
+      // (hardware exp2: 1 ulp, and the value is rounded to hi + lo = 2^-25 absolute right below anyway)
+      const float v = (col < d.Fe) ? __builtin_amdgcn_exp2f((coef * 1.4426950408889634f) * (x * x)) : 0.0f;
       hi[j] = (_Float16)v;
       lo[j] = (_Float16)(v - (float)hi[j]);
     }

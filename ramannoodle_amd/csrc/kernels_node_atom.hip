@@ -24,6 +24,7 @@
 // Every LDS access inside the round loop is inline assembly (fused_common.hpp) and the barrier is a bare s_barrier behind an
 // explicit s_waitcnt: a compiler-visible LDS access or __syncthreads() would drain vmcnt(0), i.e. the whole request ring.
 #include "fused_common.hpp"
+#include <type_traits>
 
 namespace rn {
 namespace {
@@ -69,7 +70,7 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // PRE: the edge rows arrive as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs) -- the operand tile is MFMA-ready as it lands
 template <bool PAD, bool PRE>
-__global__ __launch_bounds__(256, RN_NA_WGS) void node_block_atom_kernel(NodeFusedArgs a) {
+__global__ __launch_bounds__(256, PRE ? RN_NA_WGS : 3) void node_block_atom_kernel(NodeFusedArgs a) {  // (float32 rows: the in-place split needs ~12 more registers)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
   const NodeAtomLds L = node_atom_lds(g.na_max_deg);
@@ -209,56 +210,71 @@ __global__ __launch_bounds__(256, RN_NA_WGS) void node_block_atom_kernel(NodeFus
   if (!PRE && !(RN_NA_PROBE & 4)) split_own_pair(atile_a, frow, l15);  // this lane's 16 bytes of step 0
   wg_barrier();
 
-  int k = 0;
-  for (int f = 0; f < nframes; ++f) {
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < R; ++r, ++k) {
-      // ---- matrix phase: 16 filter + 16 core columns of the round's 16 rows, the node term as the C operand
-      f32x4 acc[2] = {seed[0], seed[1]};
-      if (!(RN_NA_PROBE & 1)) {
-        f16x8 ah[2], al[2];
-        load_pair_a(atile_a + (unsigned)((k & (NA_D - 1)) * NG * FP) * 4u, l15, quad, ah, al);
-        bW.product_split(ah, al, acc);
-      }
-      // this wave's part of |row|^2 (the row has zero mean: that is the variance's numerator)
-      const unsigned pbuf = part_a + (unsigned)(k & 1) * 256u;
-      {
-        float q = 0.f;
+  // One round with the ring slot J = k & (NA_D - 1) as a compile-time constant: the loop below is unrolled over the ring, so
+  // every LDS address of a round is a loop-invariant register plus an immediate offset.
+  unsigned afrag[4];  // this lane's four fragment addresses in ring slot 0
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q = fmaf(acc[0][i], acc[0][i], fmaf(acc[1][i], acc[1][i], q));
-        part_put(pbuf, l15, quad, wave, sum_quads(q));
-      }
-      // ---- the next round's rows: requested NA_D - 1 rounds ago, one younger request may still be in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_D - 3) : "memory");
-      if (!PRE && !(RN_NA_PROBE & 4)) split_own_pair(atile_a + (unsigned)(((k + 1) & (NA_D - 1)) * NG * FP) * 4u, frow, l15);
-      wg_barrier();
-      request((k + NA_D - 1) & (NA_D - 1));                 // into the slot round k - 1 multiplied from
-      if (r == 0 && f + 1 < nframes) request_frame(f + 1);  // landed by round 2 (the waits above), read after the last
-      // ---- gate phase on the accumulators: LayerNorm(2Fn) of a zero-mean row, sigmoid * tanh, sum in edge order
-      if (!(RN_NA_PROBE & 2)) {
-        const float rstd = fast_rsq(fmaf(part_get(pbuf, l15), inv2n, eps_s));
-        f32x4 out;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float e1 = fast_exp2(fmaf(acc[0][i] * rstd, gfm[i], bfm[i]));
-          const float yc = __builtin_amdgcn_fmed3f(fmaf(acc[1][i] * rstd, gcm[i], bcm[i]), -kClamp, kClamp);
-          const float e2 = fast_exp2(yc);
-          const float t = 1.0f + e2;
-          out[i] = (e2 - 1.0f) * fast_rcp(fmaf(e1, t, t));
-        }
-        if (r < deg_own) sum += out;
-      } else {
-        sum += acc[0] + acc[1];
-      }
+  for (int j = 0; j < 4; ++j) afrag[j] = atile_a + (unsigned)l15 * (FP * 4) + (unsigned)(((4 * quad + j) ^ l15) & 15) * 16u;
+  int r = 0, f = 0;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  auto round = [&](auto slot_tag) {
+    constexpr int J = decltype(slot_tag)::value;
+    // ---- matrix phase: 16 filter + 16 core columns of the round's 16 rows, the node term as the C operand
+    f32x4 acc[2] = {seed[0], seed[1]};
+    if (!(RN_NA_PROBE & 1)) {
+      f16x8 ah[2], al[2];
+      load_pair_a_at<J * NG * FP * 4>(afrag, ah, al);
+      bW.product_split(ah, al, acc);
     }
+    // this wave's part of |row|^2 (the row has zero mean: that is the variance's numerator)
+    const unsigned pbuf = part_a + (unsigned)(J & 1) * 256u;
+    {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q = fmaf(acc[0][i], acc[0][i], fmaf(acc[1][i], acc[1][i], q));
+      part_put(pbuf, l15, quad, wave, sum_quads(q));
+    }
+    // ---- the next round's rows: requested NA_D - 1 rounds ago, one younger request may still be in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_D - 3) : "memory");
+    if (!PRE && !(RN_NA_PROBE & 4)) split_own_pair(atile_a + (unsigned)(((J + 1) & (NA_D - 1)) * NG * FP) * 4u, frow, l15);
+    wg_barrier();
+    request((J + NA_D - 1) & (NA_D - 1));                 // into the slot the previous round multiplied from
+    if (r == 0 && f + 1 < nframes) request_frame(f + 1);  // landed by round 2 (the waits above), read after the last
+    // ---- gate phase on the accumulators: LayerNorm(2Fn) of a zero-mean row, sigmoid * tanh, sum in edge order
+    if (!(RN_NA_PROBE & 2)) {
+      const float rstd = fast_rsq(fmaf(part_get(pbuf, l15), inv2n, eps_s));
+      f32x4 out;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e1 = fast_exp2(fmaf(acc[0][i] * rstd, gfm[i], bfm[i]));
+        const float yc = __builtin_amdgcn_fmed3f(fmaf(acc[1][i] * rstd, gcm[i], bcm[i]), -kClamp, kClamp);
+        const float e2 = fast_exp2(yc);
+        const float t = 1.0f + e2;
+        out[i] = (e2 - 1.0f) * fast_rcp(fmaf(e1, t, t));
+      }
+      if (r < deg_own) sum += out;
+    } else {
+      sum += acc[0] + acc[1];
+    }
+    if (++r < R) return true;
+    // ---- the frame's last round: LayerNorm(Fn), residual, store; the next frame's node term out of its LDS slots
     epilogue(f, sum, nullptr);
-    if (f + 1 < nframes) {
-      if (R < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requested fewer than two waits ago)
-      f32x4 n0, n1;
-      lds_read2(land_a, land_a + 4096u, n0, n1);
-      seed[0] = n0 * s1;
-      seed[1] = n1 * s1;
-    }
+    sum = f32x4{0.f, 0.f, 0.f, 0.f};
+    r = 0;
+    if (++f == nframes) return false;
+    if (R < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requested fewer than two waits ago)
+    f32x4 n0, n1;
+    lds_read2(land_a, land_a + 4096u, n0, n1);
+    seed[0] = n0 * s1;
+    seed[1] = n1 * s1;
+    return true;
+  };
+  static_assert(NA_D == 4, "the round loop is unrolled over a four-slot ring");
+  for (;;) {
+    if (!round(std::integral_constant<int, 0>{})) break;
+    if (!round(std::integral_constant<int, 1>{})) break;
+    if (!round(std::integral_constant<int, 2>{})) break;
+    if (!round(std::integral_constant<int, 3>{})) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's re-fetches
 }
