@@ -545,8 +545,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   const f32x2 k_c21gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), k_c21bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
   const f32x2 k_c21gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), k_c21bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
   const f32x2 k_c22g = *reinterpret_cast<const f32x2 *>(s_c2n2g + cc), k_c22b = *reinterpret_cast<const f32x2 *>(s_c2n2b + cc);
-  const Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);  // (likewise: the folds of a P' row)
-  const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);
+  Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);  // (likewise: the folds of a P' row;
+  const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);  //  1/gamma with the 2 / 2Fe of p.q)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    igf.v[k] *= 2.0f * inv2n;
+    igc.v[k] *= 2.0f * inv2n;
+  }
   const float *ringc = ring + c0;
   const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
   int ub = 0;                      // ring row of the unit's first source row
@@ -561,12 +566,12 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       PS_T0();
       ps_wait_ge(sync_a + C_READY, gr + 1u, a.fail, 4);
       PS_TICK(10);
-      const int i = r * PS_ND + slot;
-      const bool active = i < D;
-      const int64_t drow = active ? erow0 + d_edge[i] : 0;
+      const bool active = r * PS_ND + slot < D;
+      const int i = min(r * PS_ND + slot, D - 1);  // (a lane group beyond the tile's last destination: zero triplets of a valid one)
+      const int64_t drow = erow0 + d_edge[i];
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       f32x2 old2;
-      if (active) {
+      {
         if constexpr (PRE) {  // columns cc, cc + 1 of group m = cc / 8: two f16 of the hi slot, two of the lo slot
           typedef _Float16 h2 __attribute__((ext_vector_type(2)));
           const h2 *pp = reinterpret_cast<const h2 *>(a.edge_in + drow * FP + (cc >> 3) * 8) + ((cc & 7) >> 1);
@@ -584,17 +589,16 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         // pd = p / gamma * (2 / 2Fe), pg = p * gamma;  var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
         f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2];
         {
-          const float two_inv = 2.0f * inv2n;
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh] * two_inv, xf.v[2 * hh + 1] * igf.v[2 * hh + 1] * two_inv};
-            pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh] * two_inv, xc.v[2 * hh + 1] * igc.v[2 * hh + 1] * two_inv};
+            pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh], xf.v[2 * hh + 1] * igf.v[2 * hh + 1]};
+            pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh], xc.v[2 * hh + 1] * igc.v[2 * hh + 1]};
             pf2[hh] = f32x2{xf.v[2 * hh] * g3f.v[2 * hh], xf.v[2 * hh + 1] * g3f.v[2 * hh + 1]};
             pc2[hh] = f32x2{xc.v[2 * hh] * g3c.v[2 * hh], xc.v[2 * hh + 1] * g3c.v[2 * hh + 1]};
           }
         }
         const float spe = sp * spscale + 1e-5f;
-        const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
+        const int rb = d_rb[i], cnt = active ? d_cnt[i] : 0, rskip = d_skip[i];
         const int half = (cnt + 1) >> 1;
         const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's half of the triplets
         auto triplet = [&](const float *qr, float (&sumk)[4]) {
