@@ -169,6 +169,7 @@ struct rn_potgnn {
   bool use_ps = false;     // role-specialised fused EdgeBlock (kernels_edge_ps.hip) on its own atom tiles (Graph::pt_*)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool want_pair_rows = true;   // RN_POTGNN_PAIR_ROWS at create time (ForwardRun::pair_rows decides per run)
+  bool tape_ps = true;          // RN_POTGNN_TAPE_PS: taped float32 runs on the role-specialised EdgeBlock / atom-owning NodeBlock
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
   bool mfma_f16 = true;  // fused kernels: split-f16 MFMA products are in use (requested and inside the safe range)
@@ -1010,17 +1011,20 @@ struct ChunkRun {
   // the fused NodeBlock on the centred copy of c1_linear (evaluation runs, split-f16 products)
   bool node_centred() const {
     static const bool on = !(getenv("RN_POTGNN_NODE_CENTRED") && atoi(getenv("RN_POTGNN_NODE_CENTRED")) == 0);
-    return sizeof(T) == 4 && on && fused() && h->use_node_fused && h->mfma_f16 && !prec<T>(h).tape_on;
+    return sizeof(T) == 4 && on && fused() && h->use_node_fused && h->mfma_f16 && (!prec<T>(h).tape_on || h->tape_ps);
   }
-  // the role-specialised EdgeBlock (kernels_edge_ps.hip): split-f16 products and the folded gate scale only, evaluation runs
+  // the role-specialised EdgeBlock (kernels_edge_ps.hip): split-f16 products and the folded gate scale only.  Taped runs
+  // take it too (round 4: it records the pre-LayerNorm sums like the per-frame kernel, and the reverse pass recomputes
+  // every projection from the taped node / edge rows, so it never sees the centred copies); RN_POTGNN_TAPE_PS=0 keeps
+  // them on the per-frame kernel and the row-ordered NodeBlock
   bool role_split(const PassW<T> &w) const {
-    return sizeof(T) == 4 && fused() && h->use_ps && h->mfma_f16 && (w.c3_fast & 1) != 0 && !prec<T>(h).tape_on;
+    return sizeof(T) == 4 && fused() && h->use_ps && h->mfma_f16 && (w.c3_fast & 1) != 0 && (!prec<T>(h).tape_on || h->tape_ps);
   }
   // Edge rows as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs): when EVERY kernel that touches them in this run is one
   // that speaks the format -- the role-specialised EdgeBlock in every pass, the atom-owning NodeBlock, the fused readout --
   // and nothing else looks at them (no tape, no stage snapshots).  RN_POTGNN_PAIR_ROWS=0 keeps plain float32 rows.
   bool pair_rows() const {
-    if (sizeof(T) != 4 || !h->want_pair_rows || h->keep_stages || !node_centred() || h->g.na_num <= 0 || !h->use_readout_fused) return false;
+    if (sizeof(T) != 4 || !h->want_pair_rows || h->keep_stages || prec<T>(h).tape_on || !node_centred() || h->g.na_num <= 0 || !h->use_readout_fused) return false;
     for (const auto &w : prec<T>(h).pass)
       if (!role_split(w)) return false;
     return true;
@@ -1779,6 +1783,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   if (const char *e = getenv("RN_POTGNN_MFMA")) h->mfma_f16_requested = !(e[0] == 'f' && e[1] == '3');
   h->mfma_f16 = h->mfma_f16_requested;
   if (const char *e = getenv("RN_POTGNN_TAPE_FUSED")) h->tape_fused = atoi(e) != 0;
+  if (const char *e = getenv("RN_POTGNN_TAPE_PS")) h->tape_ps = atoi(e) != 0;
 
   // ---- graph: CSR over a (edges are already grouped), CSR over b, tiles, triplet offsets
   h->edge_a.assign(edge_a, edge_a + E);
