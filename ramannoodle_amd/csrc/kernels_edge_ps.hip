@@ -413,8 +413,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       // ---- A: this step's operand rows have landed (requested one step ago)
       dma_wait();
       PS_TICK(0);
-      // node terms of this step's rows (they seed the accumulators): in flight while the tiles are split
-      f32x4 accP[2], accQ[2];
+      // node terms of this step's destinations: four 16-byte loads per lane, issued now and added to the product where that is
+      // finished (`seeds_landed` below) -- in flight under the split, the sync, the next requests and the first MFMAs; the
+      // source tile's two follow when the P' registers are free, in flight under the c2 and Q' products.
+      // Inline assembly: the compiler would wait for a load it can see with vmcnt(0) at its first use, i.e. for the five
+      // LDS-DMA requests issued after it as well; in order, "all but the five youngest" is exactly these loads.
+      f32x4 kP[2], jP[2], qS[2];
+      const float *q_src;  // this lane's node term of the step's first source tile: requested when the P' registers are free
       int ringrow0;
       {
         const int l15 = ln & 15, mycol = colbase + 4 * (ln >> 4);
@@ -426,13 +431,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           if (RN_PS_PROBE & 8) {
-            accP[t] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)(ok + oj);
-            accQ[t] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)oq;
+            kP[t] = jP[t] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)(ok + oj);
           } else {
-            accP[t] = *reinterpret_cast<const f32x4 *>(np3_s + ok + 16 * t) + *reinterpret_cast<const f32x4 *>(np3_s + oj + 16 * t);
-            accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kP[t]) : "v"(np3_s + ok + 16 * t) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(jP[t]) : "v"(np3_s + oj + 16 * t) : "memory");
           }
         }
+        q_src = np3_q + oq;
         ringrow0 = (cur.tile0 & (PS_NRT - 1)) * 16 + l15;
       }
       const bool have_next = ps_sched_next(sched, hi, nxt);  // (its one table read hides under the loads above)
@@ -441,19 +446,25 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       ps_arrive(sync_a + C_SPLIT, ln);
       if (!(RN_PS_PROBE & 64)) ps_wait_ge(sync_a + C_SPLIT, 4u * (k + 1u), a.fail, 1);
       PS_TICK(2);
-      // the seeds are complete before the next requests go out: nothing below waits on vmcnt, so the LDS-DMA
-      // stays in flight across the whole step
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        accP[t] *= s4;
-        accQ[t] *= s5;
-      }
-      // (the operands pin the seeds' arithmetic -- the last use of the loaded values -- above this point)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(accP[0]), "+v"(accP[1]), "+v"(accQ[0]), "+v"(accQ[1])::"memory");
       // ---- B: request the next step's rows (its buffer and the node[a] tile are free: every producer is past step k - 1)
       PS_TICK(3);
       ln = launder(ln);
-      if (have_next && !(RN_PS_PROBE & 32)) request(nxt, buf ^ 1, ln);
+      // Always five requests, also after the last step (its own rows again, into the buffer nobody will read): the wait below
+      // is then ONE statement on one path.  With two variants behind a branch the compiler copied the loaded registers into
+      // the merge point's registers in front of one of the waits -- i.e. before the data was there.
+      if (!(RN_PS_PROBE & 32)) request(have_next ? nxt : cur, buf ^ 1, ln);
+      // the node terms are there once at most the five requests above are outstanding
+      // (the product's accumulators are operands too: the wait stays BEHIND the MFMAs it is meant to be covered by)
+      auto seeds_landed = [&](f32x4 (&acc)[2]) {
+        if (RN_PS_PROBE & 32)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(kP[0]), "+v"(kP[1]), "+v"(jP[0]), "+v"(jP[1]), "+v"(acc[0]), "+v"(acc[1])::"memory");
+        else
+          asm volatile("s_waitcnt vmcnt(5)" : "+v"(kP[0]), "+v"(kP[1]), "+v"(jP[0]), "+v"(jP[1]), "+v"(acc[0]), "+v"(acc[1])::"memory");
+      };
+      // Every load issued in assembly is waited for on EVERY path, by a statement that names its registers: a register that
+      // is loaded and then never read (a step without destinations, a step without a source tile) would be free for the
+      // compiler to hand to something else while the load is still in flight.  So the waits are unconditional and only the
+      // arithmetic around them is not.
       PS_TICK(4);
       // ---- the buffers of round g were last read by round g - 2
       if (cur.has_dest) ps_wait_ge(sync_a + ((cur.g & 1) ? C_DONE1 : C_DONE0), (unsigned)PS_CONS * (unsigned)(cur.g >> 1), a.fail, 2);
@@ -461,37 +472,44 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       ln = launder(ln);
       const int l15 = ln & 15, quad = ln >> 4, mycol = colbase + 4 * quad;  // + 16 t: the four columns of tile t this lane ends up with
       const unsigned tb_a = atile_a + (unsigned)(buf * PS_BUF) * 4u;
-      if (cur.has_dest) {
-        const int slot0 = (cur.g & 1) * PS_ND;
-        f16x8 ah[2], al[2];
-        load_pair_a(tb_a, l15, quad, ah, al);
-        if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
+      const int slot0 = (cur.g & 1) * PS_ND;
+      {
+        f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (cur.has_dest) {
+          f16x8 ah[2], al[2];
+          load_pair_a(tb_a, l15, quad, ah, al);
+          if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
+        }
+        seeds_landed(accP);
+        if (cur.has_dest) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3
-          *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = accP[t];
+          for (int t = 0; t < 2; ++t)  // row l15, columns mycol + 16 t .. + 3; the node terms in the weights' prescale
+            *reinterpret_cast<f32x4 *>(bufP + (slot0 + l15) * LDQ + mycol + 16 * t) = (kP[t] + jP[t]) * s4 + accP[t];
+        }
+      }
+      // the first source tile's node term: requested now that the P' registers are free, in flight under the c2 and Q' products
+      if (RN_PS_PROBE & 8) {
+        qS[0] = qS[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qS[0]) : "v"(q_src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qS[1]) : "v"(q_src + 16) : "memory");
+      }
+      if (cur.has_dest) {
+        f16x8 ah[2], al[2];
         f32x4 accC[2];
         load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
-                         accC[0], accC[1]);  // + the centred c2 bias
+                     accC[0], accC[1]);  // + the centred c2 bias
         if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t];
       }
       PS_TICK(6);
-      for (int n = 0; n < ((RN_PS_PROBE & 128) ? 0 : cur.ntiles); ++n) {
-        int ringrow = ringrow0;
-        if (n > 0) {  // a second tile in one step is rare (once per unit): its node terms are fetched here
-          const float *np3_q = a.np3 + (int64_t)(sg + min(cur.tu1, nunits - 1) * nsg) * g.N * (6 * FP);
-          const unsigned oq = (unsigned)lds_read1(ints_a + (unsigned)min(cur.tt1 * 16 + l15, R - 1) * 4u) * (6 * FP) + mycol;  // qb[]
+      const int ntl = (RN_PS_PROBE & 128) ? 0 : cur.ntiles;
+      // source tile n of the step: product, node term, |q|^2 part, scaled row to the ring
+      auto q_tile_finish = [&](f32x4 (&accQ)[2], const f32x4 (&g3v)[2], int ringrow) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) accQ[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t) * s5;
-          ringrow = ((cur.tile0 + 1) & (PS_NRT - 1)) * 16 + l15;
-        }
-        f16x8 ah[2], al[2];
-        f32x4 g3v[2];
-        load_pair_a2(tb_a + (unsigned)((2 + n) * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (14 * FP + mycol) * 4,
-                         lnp_a + (14 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3q
-        if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+        for (int t = 0; t < 2; ++t) accQ[t] = qS[t] * s5 + accQ[t];
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -501,6 +519,30 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4 *>(ring + ringrow * LDQ + mycol + 16 * t) = accQ[t] * g3v[t];
         if (quad == 0) qnp[ringrow * 4 + wave] = ss * qscale;
+      };
+      {
+        f32x4 accQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, g3v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (ntl > 0) {
+          f16x8 ah[2], al[2];
+          load_pair_a2(tb_a + (unsigned)(2 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (14 * FP + mycol) * 4,
+                       lnp_a + (14 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3q
+          if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+        }
+        // (issued after this step's requests: everything of this wave has landed then -- the requests are ~2000 cycles old)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qS[0]), "+v"(qS[1]), "+v"(accQ[0]), "+v"(accQ[1])::"memory");
+        if (ntl > 0) q_tile_finish(accQ, g3v, ringrow0);
+      }
+      if (ntl > 1) {  // a second tile in one step is rare (once per unit): its node terms are fetched here, by ordinary loads
+        const float *np3_q = a.np3 + (int64_t)(sg + min(cur.tu1, nunits - 1) * nsg) * g.N * (6 * FP);
+        const unsigned oq = (unsigned)lds_read1(ints_a + (unsigned)min(cur.tt1 * 16 + l15, R - 1) * 4u) * (6 * FP) + mycol;  // qb[]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) qS[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
+        f16x8 ah[2], al[2];
+        f32x4 accQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, g3v[2];
+        load_pair_a2(tb_a + (unsigned)(3 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (14 * FP + mycol) * 4,
+                     lnp_a + (14 * FP + mycol + 16) * 4, g3v[0], g3v[1]);
+        if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+        q_tile_finish(accQ, g3v, ((cur.tile0 + 1) & (PS_NRT - 1)) * 16 + l15);
       }
       PS_TICK(7);
       // ---- the LAST producer to get here completes |q|^2 of the step's new rows (every producer's part is in LDS by then)
@@ -518,6 +560,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       cur = nxt;
       have = have_next;
     }
+    dma_wait();  // (the last step's re-fetch)
     return;
   }
 

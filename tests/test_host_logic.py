@@ -510,3 +510,20 @@ def test_config1_plumbing_linear_model_phonon_spectrum():
 
     with pytest.raises(ValueError, match="incompatible"):
         Phonons(g["positions"], g["wavenumbers"], g["displacements"]).get_raman_spectrum(Wrong())
+
+
+def test_role_split_producers_leave_in_flight_registers_alone():
+    """The producers of the role-specialised EdgeBlock (``csrc/kernels_edge_ps.hip``) load their node terms in inline assembly
+    and wait for them with a hand-counted ``s_waitcnt vmcnt(5)`` behind the first product.  ``tools/check_ps_isa.py`` compiles
+    the file and checks in the ISA of every instantiation that nothing reads, copies or spills those registers before the
+    wait (a tied-operand copy in front of a wait on a second code path did exactly that once)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_ps_isa.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " 0 violation(s)" in out.stdout and "0 in-flight loads" not in out.stdout
