@@ -581,6 +581,9 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     bf2[1] = f32x2{bf.v[2], bf.v[3]};
     bc2[0] = f32x2{bc.v[0], bc.v[1]};
     bc2[1] = f32x2{bc.v[2], bc.v[3]};
+    // (consumed here: left pending, these two loads get their vmcnt waits INSIDE the triplet loop -- their first use -- where
+    //  every round's own loads and stores are outstanding too)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf2[0]), "+v"(bf2[1]), "+v"(bc2[0]), "+v"(bc2[1]));
   }
   // LayerNorm parameters of this lane's two epilogue columns: registers (the consumers have ~50 to spare), not eight LDS
   // reads per round
