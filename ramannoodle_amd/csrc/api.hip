@@ -169,6 +169,8 @@ struct rn_potgnn {
   bool use_ps = false;     // role-specialised fused EdgeBlock (kernels_edge_ps.hip) on its own atom tiles (Graph::pt_*)
   bool use_node_fused = false;  // fused NodeBlock (only together with the fused EdgeBlock)
   bool want_pair_rows = true;   // RN_POTGNN_PAIR_ROWS at create time (ForwardRun::pair_rows decides per run)
+  DeviceBuf step_seg, step_stage;  // segments / staging of the one download after a device-resident Adam step
+  float *step_host = nullptr;      // its pinned host image
   bool tape_ps = true;          // RN_POTGNN_TAPE_PS: taped float32 runs on the role-specialised EdgeBlock / atom-owning NodeBlock
   bool use_readout_fused = false;  // readout MLP in one launch (same condition)
   bool use_narrow = false;  // narrow-width kernels (kernels_narrow.hip): Fn, Fe <= 16, one lane per row
@@ -2274,6 +2276,7 @@ void rn_potgnn_destroy(rn_potgnn *h) {
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   for (int i = 0; i < 2; ++i)
     if (h->ev_g[i]) (void)hipEventDestroy(h->ev_g[i]);
+  if (h->step_host) (void)hipHostFree(h->step_host);
   delete h;
 }
 
@@ -2742,16 +2745,37 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
                         w + L.node_table, w + L.b0, w + L.bn_w, w + L.bn_b, w + L.bn_rm, w + L.bn_rv,
                         w + L.scale0, w + L.shift0, st);
     HIP_TRY(hipGetLastError());
-    // the triplet loop's folded-scale variant is chosen on the host from c3_norm_1: fetch those 4 P FeP floats
-    for (const auto &q : L.pass) {  // (scale then shift, adjacent in the packed layout: one copy per pass)
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.c3n1_g, w + q.c3n1_g, 4 * (size_t)h->d.FeP * sizeof(float),
-                             hipMemcpyDeviceToHost, st));
-      // ... and the prescale pairs, which double as the finiteness flags of the weight blocks (mfma_f16_range_ok)
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + q.mfma_scale, w + q.mfma_scale, 16 * sizeof(float), hipMemcpyDeviceToHost, st));  // + mfma_scale_c
-    }
-    {  // ... and the split-f16 range guard reads the readout block (W0T .. b5, contiguous in the layout)
-      const size_t lo = L.W0T, hi = L.b5 + 32;
-      HIP_TRY(hipMemcpyAsync(h->packed.data() + lo, w + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, st));
+    // The host looks at three kinds of entries after a step: c3_norm_1's folded constants (the triplet loop's folded-scale
+    // variant is chosen from them), the prescale pairs (which double as the finiteness flags of the weight blocks,
+    // mfma_f16_range_ok) and the readout block of the split-f16 range guard.  One gather kernel + ONE download into pinned
+    // memory (2 P + 1 separate small downloads cost a round trip each: 0.2 ms of a 0.3 ms step).
+    {
+      std::vector<long long> seg;
+      long long total = 0;
+      auto add = [&](size_t src, size_t n) {
+        seg.push_back((long long)src);
+        seg.push_back(total);
+        seg.push_back((long long)n);
+        total += (long long)n;
+      };
+      for (const auto &q : L.pass) {
+        add(q.c3n1_g, 4 * (size_t)h->d.FeP);  // scale then shift, adjacent in the packed layout
+        add(q.mfma_scale, 16);                // + mfma_scale_c
+      }
+      add(L.W0T, L.b5 + 32 - L.W0T);          // W0T .. b5, contiguous in the layout
+      if (h->step_seg.bytes < seg.size() * sizeof(long long)) {
+        h->step_seg.ensure(seg.size() * sizeof(long long));
+        HIP_TRY(hipMemcpy(h->step_seg.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice));
+        h->step_stage.ensure((size_t)total * sizeof(float));
+        if (h->step_host) (void)hipHostFree(h->step_host);
+        h->step_host = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->step_host), (size_t)total * sizeof(float), hipHostMallocDefault));
+      }
+      launch_gather_segments(w, h->step_seg.as<long long>(), (int)(seg.size() / 3), h->step_stage.as<float>(), st);
+      HIP_TRY(hipMemcpyAsync(h->step_host, h->step_stage.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      for (size_t i = 0; i < seg.size(); i += 3)
+        std::memcpy(h->packed.data() + seg[i], h->step_host + seg[i + 1], (size_t)seg[i + 2] * sizeof(float));
     }
     HIP_TRY(hipStreamSynchronize(st));
     h->host_stale = true;

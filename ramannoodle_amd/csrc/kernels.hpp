@@ -338,6 +338,8 @@ void launch_adam(float *w, const float *g, float *m, float *v, const unsigned ch
                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                  hipStream_t st);
 void launch_refresh_derived(float *w, const DerivedOp *ops, int num_ops, hipStream_t st);
+// staging[dst .. dst + n) = w[src .. src + n) for every (src, dst, n) of `seg` (kernels_train.hip)
+void launch_gather_segments(const float *w, const long long *seg, int nseg, float *staging, hipStream_t st);
 void launch_bn_running(float *running_mean, float *running_var, const float *batch_mean, const float *batch_var,
                        int F, double momentum, double unbias, hipStream_t st);
 

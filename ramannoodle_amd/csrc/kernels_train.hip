@@ -40,6 +40,21 @@ void launch_adam(float *w, const float *g, float *m, float *v, const unsigned ch
                                                           (float)bc1, (float)sqrt(bc2));
 }
 
+// Pieces of the packed blob the host looks at after a device-resident step (c3_norm_1's folded constants, the prescale /
+// finiteness pairs, the readout block of the range guard) -> one contiguous staging buffer: one download instead of 2 P + 1
+// small ones, each a round trip of its own.  seg[3 i .. 3 i + 2] = (source offset, staging offset, count).
+__global__ void gather_segments_kernel(const float *__restrict__ w, const long long *__restrict__ seg, int nseg,
+                                       float *__restrict__ staging) {
+  for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+    const long long src = seg[3 * i], dst = seg[3 * i + 1], n = seg[3 * i + 2];
+    for (long long k = threadIdx.x; k < n; k += blockDim.x) staging[dst + k] = w[src + k];
+  }
+}
+void launch_gather_segments(const float *w, const long long *seg, int nseg, float *staging, hipStream_t st) {
+  if (nseg <= 0) return;
+  gather_segments_kernel<<<(unsigned)nseg, 256, 0, st>>>(w, seg, nseg, staging);
+}
+
 // one entry per derived range of the packed blob
 //   kind 0: dst[n*K + k] = src[k*N + n]   (transposed copy, src is [K][N])
 //   kind 1: dst[i] = src[i] * scale       (count = K: copies with scale 1, folded LayerNorm halves)
