@@ -278,6 +278,16 @@ int rn_potgnn_train_forward_samples_f64(rn_potgnn *h, const double *lattices, co
  */
 int rn_potgnn_set_device_training(rn_potgnn *h, int enabled);
 int rn_potgnn_train_backward_device(rn_potgnn *h, const float *dvec6);
+/*
+ * The same step with nothing crossing PCIe (round 4: train_single_epoch moves a batch to the device and takes the loss
+ * there, _train.py:51-75): positions device f64[S*N*3], d_lattices device f32[S*9] or NULL, d_atom_types device int32[S*N]
+ * or NULL (validated by the caller) -> d_vec6 device f32[S*6]; then the cotangents d_dvec6 device f32[S*6].  Both need
+ * device-resident training (rn_potgnn_set_device_training), order their work after `stream` and make `stream` wait for
+ * it; neither synchronises.  The gradients stay in HBM for rn_potgnn_adam_step.
+ */
+int rn_potgnn_train_forward_samples_device(rn_potgnn *h, const float *d_lattices, const int32_t *d_atom_types,
+                                           const double *d_positions, int64_t S, float *d_vec6, void *stream);
+int rn_potgnn_train_backward_samples_device(rn_potgnn *h, const float *d_dvec6, void *stream);
 int rn_potgnn_gradient_buffer(rn_potgnn *h, void **device_ptr, size_t *count);
 int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int64_t step);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "rn_potgnn_train_forward_samples": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "rn_potgnn_train_forward_samples_f64": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "rn_potgnn_forward_samples_device": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int]),
+    "rn_potgnn_train_forward_samples_device": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P]),
+    "rn_potgnn_train_backward_samples_device": (C.c_int, [_P, _P, _P]),
     "rn_potgnn_train_backward_f64": (C.c_int, [_P, _P, _P]),
     "rn_potgnn_num_triplets": (C.c_int64, [_P]),
     "rn_potgnn_debug_triplets": (C.c_int, [_P, _P, _P, _P, _P, _P]),

@@ -1461,34 +1461,18 @@ void sync_host(rn_potgnn *h) {
 
 // ---- training: forward with batch-statistics BatchNorm, then parameter gradients (float32 for
 // the product path; float64 for validating the reverse pass against float64 autograd)
+// The taped forward + the training-mode readout (batch-statistics BatchNorm) over the S structures whose positions (and, per
+// h->train_lat / h->train_types, lattices and atom types) sit in h->io_pos / io_lat / io_types; everything is enqueued on lane
+// 0's stream, the standardised 6-vectors end up in h->io_vec6 / io_alpha and the batch statistics in P.mv.
 template <typename T>
-void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batch_mean, T *batch_var,
-                   const double *host_lat = nullptr /* [S][9] or null */, const int32_t *host_types = nullptr /* [S][N] or null */) {
-  ensure_precision<T>(h);
+ChunkRun<T> train_forward_core(rn_potgnn *h, int S) {
   Precision<T> &P = prec<T>(h);
   const PackedLayout &L = h->lay;
   const Graph &g = h->g;
   const Dims d = h->d;
   const int HP = std::max(d.FeP, 32);
-  const size_t pb = (size_t)S * g.N * 3 * sizeof(double);
-  h->io_pos.ensure(pb);
-  HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, pb, hipMemcpyHostToDevice));
-  // per-sample lattices (in the arithmetic of the run, as the reference's forward casts them) and atom types: the graph
-  // topology stays the reference structure's (_gnn.py:603-611, 541-557)
-  if (host_lat) {
-    std::vector<T> lat((size_t)S * 9);
-    for (size_t i = 0; i < lat.size(); ++i) lat[i] = (T)host_lat[i];
-    h->io_lat.ensure(lat.size() * sizeof(T));
-    HIP_TRY(hipMemcpy(h->io_lat.p, lat.data(), lat.size() * sizeof(T), hipMemcpyHostToDevice));
-  }
-  if (host_types) {
-    h->io_types.ensure((size_t)S * g.N * sizeof(int32_t));
-    HIP_TRY(hipMemcpy(h->io_types.p, host_types, (size_t)S * g.N * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
-  h->train_lat = host_lat != nullptr;
-  h->train_types = host_types != nullptr;
-  ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), S, host_lat ? h->io_lat.as<T>() : nullptr,
-                                   host_types ? h->io_types.as<int>() : nullptr);
+  ChunkRun<T> c = taped_forward<T>(h, h->io_pos.as<double>(), S, h->train_lat ? h->io_lat.as<T>() : nullptr,
+                                   h->train_types ? h->io_types.as<int>() : nullptr);
   hipStream_t st = c.st();
   const int64_t R = (int64_t)S * g.E;
   T *Wd = P.weights.template as<T>();
@@ -1522,6 +1506,52 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
   launch_readout_reduce<T>(c.bufA, c.unit4, S, g, ms, ms + 9, h->io_vec6.as<float>(), nullptr,
                            h->io_alpha.as<double>() /* standardised 3x3 in double */, st);
   HIP_TRY(hipGetLastError());
+  return c;
+}
+// running statistics where the weights live (torch: momentum 0.1, unbiased variance) and everything derived from them
+inline void train_running_stats(rn_potgnn *h, hipStream_t st) {
+  Precision<float> &P = h->f32;
+  const PackedLayout &L = h->lay;
+  const Dims d = h->d;
+  const int HP = std::max(d.FeP, 32);
+  float *Wd = P.weights.as<float>();
+  const double rows = h->bn_count;
+  launch_bn_running(Wd + L.bn_rm, Wd + L.bn_rv, P.mv.as<float>(), P.mv.as<float>() + HP, d.Fe, 0.1,
+                    rows / std::max(rows - 1.0, 1.0), st);
+  launch_setup<float>(Wd + L.emb, Wd + L.W2, Wd + L.b2, Wd + L.W4, Wd + L.b4, h->cfg.num_atom_types, h->d,
+                      Wd + L.node_table, Wd + L.b0, Wd + L.bn_w, Wd + L.bn_b, Wd + L.bn_rm, Wd + L.bn_rv,
+                      Wd + L.scale0, Wd + L.shift0, st);
+  h->host_stale = true;
+}
+
+template <typename T>
+void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batch_mean, T *batch_var,
+                   const double *host_lat = nullptr /* [S][9] or null */, const int32_t *host_types = nullptr /* [S][N] or null */) {
+  ensure_precision<T>(h);
+  Precision<T> &P = prec<T>(h);
+  const Graph &g = h->g;
+  const Dims d = h->d;
+  const int HP = std::max(d.FeP, 32);
+  const size_t pb = (size_t)S * g.N * 3 * sizeof(double);
+  h->io_pos.ensure(pb);
+  HIP_TRY(hipMemcpy(h->io_pos.p, host_pos, pb, hipMemcpyHostToDevice));
+  // per-sample lattices (in the arithmetic of the run, as the reference's forward casts them) and atom types: the graph
+  // topology stays the reference structure's (_gnn.py:603-611, 541-557)
+  if (host_lat) {
+    std::vector<T> lat((size_t)S * 9);
+    for (size_t i = 0; i < lat.size(); ++i) lat[i] = (T)host_lat[i];
+    h->io_lat.ensure(lat.size() * sizeof(T));
+    HIP_TRY(hipMemcpy(h->io_lat.p, lat.data(), lat.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  if (host_types) {
+    h->io_types.ensure((size_t)S * g.N * sizeof(int32_t));
+    HIP_TRY(hipMemcpy(h->io_types.p, host_types, (size_t)S * g.N * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  h->train_lat = host_lat != nullptr;
+  h->train_types = host_types != nullptr;
+  ChunkRun<T> c = train_forward_core<T>(h, S);
+  hipStream_t st = c.st();
+  DeviceBuf &mv = P.mv;
   HIP_TRY(hipStreamSynchronize(st));
   if constexpr (sizeof(T) == 4) {
     HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1533,14 +1563,8 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
       for (int k = 0; k < 6; ++k) vec6[(size_t)s * 6 + k] = (T)raw[(size_t)s * 9 + pick[k]];
   }
   if constexpr (sizeof(T) == 4) {
-    if (h->device_training) {  // running statistics where the weights live (torch: momentum 0.1, unbiased variance)
-      const double rows = h->bn_count;
-      launch_bn_running(Wd + L.bn_rm, Wd + L.bn_rv, mv.template as<float>(), mv.template as<float>() + HP, d.Fe,
-                        0.1, rows / std::max(rows - 1.0, 1.0), st);
-      launch_setup<float>(Wd + L.emb, Wd + L.W2, Wd + L.b2, Wd + L.W4, Wd + L.b4, h->cfg.num_atom_types, h->d,
-                          Wd + L.node_table, Wd + L.b0, Wd + L.bn_w, Wd + L.bn_b, Wd + L.bn_rm, Wd + L.bn_rv,
-                          Wd + L.scale0, Wd + L.shift0, st);
-      h->host_stale = true;
+    if (h->device_training) {
+      train_running_stats(h, st);
       HIP_TRY(hipStreamSynchronize(st));
     }
   }
@@ -1552,6 +1576,39 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
   }
   h->train_S = S;
   h->train_prec = (int)sizeof(T);
+}
+
+// The same step with everything where it already is (device-resident training, float32): positions [S][N][3] float64,
+// optional lattices [S][9] float32 and atom types [S][N] int32, and the [S][6] result are DEVICE buffers; work is ordered
+// after `user` and `user` is made to wait for it; no host round trip, no synchronisation.
+inline void train_forward_device(rn_potgnn *h, const double *d_pos, int S, const float *d_lat, const int32_t *d_types,
+                                 float *d_vec6, hipStream_t user) {
+  ensure_precision<float>(h);
+  Precision<float> &P = h->f32;
+  const Graph &g = h->g;
+  hipStream_t st = P.lanes[0].stream;
+  HIP_TRY(hipEventRecord(h->ev_start, user));
+  HIP_TRY(hipStreamWaitEvent(st, h->ev_start, 0));
+  const size_t pb = (size_t)S * g.N * 3 * sizeof(double);
+  h->io_pos.ensure(pb);  // (the reverse pass reads the positions again)
+  HIP_TRY(hipMemcpyAsync(h->io_pos.p, d_pos, pb, hipMemcpyDeviceToDevice, st));
+  if (d_lat) {
+    h->io_lat.ensure((size_t)S * 9 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->io_lat.p, d_lat, (size_t)S * 9 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  if (d_types) {
+    h->io_types.ensure((size_t)S * g.N * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(h->io_types.p, d_types, (size_t)S * g.N * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  }
+  h->train_lat = d_lat != nullptr;
+  h->train_types = d_types != nullptr;
+  (void)train_forward_core<float>(h, S);
+  HIP_TRY(hipMemcpyAsync(d_vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  train_running_stats(h, st);
+  HIP_TRY(hipEventRecord(P.lanes[0].done, st));
+  HIP_TRY(hipStreamWaitEvent(user, P.lanes[0].done, 0));
+  h->train_S = S;
+  h->train_prec = 4;
 }
 
 template <typename T>
@@ -1581,6 +1638,31 @@ void train_backward(rn_potgnn *h, const T *dvec6, T *grads /* null: leave the gr
   std::vector<T> gp(h->lay.total);
   HIP_TRY(hipMemcpy(gp.data(), P.grad.p, gp.size() * sizeof(T), hipMemcpyDeviceToHost));
   unpack_grads<T>(h, gp.data(), grads, false);
+}
+
+// Reverse pass of a pending train_forward(_device) with the cotangents [S][6] in a DEVICE buffer; the gradients stay in HBM
+// (device-resident training), nothing is synchronised: `user` waits for the lane, the Adam step runs on the lane's stream.
+inline void train_backward_device(rn_potgnn *h, const float *d_dvec6, hipStream_t user) {
+  Precision<float> &P = h->f32;
+  const int S = h->train_S;
+  if (S <= 0 || h->train_prec != 4)
+    throw HipError{hipErrorInvalidValue, "train_backward without a train_forward of the same precision"};
+  ChunkRun<float> c(h, P.lanes[0], h->io_pos.as<double>(), S, nullptr, nullptr, nullptr);
+  c.d_lat = h->train_lat ? h->io_lat.as<float>() : nullptr;
+  c.d_types = h->train_types ? h->io_types.as<int>() : nullptr;
+  hipStream_t st = c.st();
+  HIP_TRY(hipEventRecord(h->ev_start, user));
+  HIP_TRY(hipStreamWaitEvent(st, h->ev_start, 0));
+  P.seeds.ensure((size_t)S * 6 * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(P.seeds.p, d_dvec6, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  P.grad.ensure(h->lay.total * sizeof(float));
+  HIP_TRY(hipMemsetAsync(P.grad.p, 0, h->lay.total * sizeof(float), st));
+  Reverse<float> rv{S, 1, P.seeds.as<float>(), nullptr, P.grad.as<float>(), true};
+  reverse_pass<float>(h, c, rv);
+  HIP_TRY(hipEventRecord(P.lanes[0].done, st));
+  HIP_TRY(hipStreamWaitEvent(user, P.lanes[0].done, 0));
+  h->train_S = 0;
+  h->grads_on_device = true;
 }
 
 // inverse of pack_weights for a gradient blob in the packed layout -> state_dict order
@@ -2634,6 +2716,35 @@ int rn_potgnn_train_forward_samples_f64(rn_potgnn *h, const double *lattices, co
     sync_host(h);
     train_forward<double>(h, positions, (int)S, vec6, batch_mean, batch_var, lattices, atom_types);
   });
+}
+
+int rn_potgnn_train_forward_samples_device(rn_potgnn *h, const float *d_lattices, const int32_t *d_atom_types,
+                                           const double *d_positions, int64_t S, float *d_vec6, void *stream) {
+  if (!h || S <= 0 || !d_positions || !d_vec6) {
+    set_error(h, "invalid arguments to train_forward_samples_device");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (!h->device_training) {
+    set_error(h, "train_forward_samples_device needs device-resident training (rn_potgnn_set_device_training)");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S > h->chunk) {
+    set_error(h, "training batch of %lld frames exceeds max_chunk_structures = %d", (long long)S, h->chunk);
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_forward_device(h, d_positions, (int)S, d_lattices, d_atom_types, d_vec6, (hipStream_t)stream); });
+}
+
+int rn_potgnn_train_backward_samples_device(rn_potgnn *h, const float *d_dvec6, void *stream) {
+  if (!h || !d_dvec6) {
+    set_error(h, "invalid arguments to train_backward_samples_device");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (!h->device_training || h->train_S <= 0 || h->train_prec != 4) {
+    set_error(h, "train_backward_samples_device needs device-resident training and a preceding float32 train_forward");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  return guarded(h, [&]() { train_backward_device(h, d_dvec6, (hipStream_t)stream); });
 }
 
 int rn_potgnn_forward_samples_device(rn_potgnn *h, const float *d_lattices, const int32_t *d_atom_types,

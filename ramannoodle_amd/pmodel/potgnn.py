@@ -456,6 +456,9 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         on_device = pos_t.is_cuda or lat_t.is_cuda or zs_t.is_cuda
         if on_device and not self.training:
             return self._forward_on_device(lat_t, zs_t, pos_t)
+        if on_device and self._device_training and getattr(self, "_dp_group", None) is None:
+            # device-resident training on a device-resident batch: nothing crosses PCIe in either direction
+            return _TrainStepOnDevice.apply(self, lat_t, zs_t, pos_t, self._device_anchor)
         out_device = next((t.device for t in (pos_t, lat_t, zs_t) if t.is_cuda), None)
         pos = np.ascontiguousarray(pos_t.detach().cpu().numpy(), dtype=np.float64)
         lat = np.ascontiguousarray(lat_t.detach().cpu().numpy(), dtype=np.float64)
@@ -491,9 +494,10 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
             _lib.check(rc, handle, "rn_potgnn_forward_samples")
         return torch.from_numpy(out)
 
-    def _forward_on_device(self, lat_t: torch.Tensor, zs_t: torch.Tensor, pos_t: torch.Tensor) -> torch.Tensor:
-        """Evaluation-mode ``forward`` on device-resident inputs: every check and conversion is a torch operation on
-        the device, the kernels read the tensors where they are, the ``[S,6]`` result is a device tensor."""
+    def _device_inputs(self, lat_t: torch.Tensor, zs_t: torch.Tensor, pos_t: torch.Tensor):
+        """What the device entries take, from tensors of which at least one is on a GPU: every check and conversion is a
+        torch operation on the device.  Returns ``(device, S, positions f64 [S,N,3], lattices f32 [S,9] or None, atom types
+        int32 [S,N] or None)``."""
         device = next(t.device for t in (pos_t, lat_t, zs_t) if t.is_cuda)
         if device.index is not None and self._device is not None and device.index != int(self._device):
             raise ValueError(f"inputs live on {device}, the model evaluates on cuda:{int(self._device)}")
@@ -501,9 +505,8 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         pos = pos_t.detach().to(device=device, dtype=torch.float64).contiguous()
         lat = lat_t.detach().to(device=device, dtype=torch.float64)
         zs = zs_t.detach().to(device=device)
-        out = torch.empty((s, 6), dtype=torch.float32, device=device)
         if s == 0:
-            return out
+            return device, s, pos, None, None
         ref_lat = torch.as_tensor(np.asarray(self._ref_structure.lattice, dtype=np.float64), device=device)
         ref_zs = torch.as_tensor(np.asarray(self._ref_structure.atomic_numbers), device=device).to(zs.dtype)
         same_lattice = bool(torch.allclose(lat, ref_lat.expand_as(lat), rtol=1e-6, atol=1e-9))
@@ -521,6 +524,15 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
             if int(types.min()) < 0:
                 raise IndexError("index out of range in self: atomic_numbers holds a species the "
                                  "model has no atom type for")
+        return device, s, pos, lat32, types
+
+    def _forward_on_device(self, lat_t: torch.Tensor, zs_t: torch.Tensor, pos_t: torch.Tensor) -> torch.Tensor:
+        """Evaluation-mode ``forward`` on device-resident inputs: the kernels read the tensors where they are, the ``[S,6]``
+        result is a device tensor."""
+        device, s, pos, lat32, types = self._device_inputs(lat_t, zs_t, pos_t)
+        out = torch.empty((s, 6), dtype=torch.float32, device=device)
+        if s == 0:
+            return out
         handle = self._ensure_handle()
         stream = torch.cuda.current_stream(device).cuda_stream
         rc = _lib.load().rn_potgnn_forward_samples_device(
@@ -529,6 +541,32 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
             C.c_void_p(out.data_ptr()), C.c_void_p(stream), 1)
         _lib.check(rc, handle, "rn_potgnn_forward_samples_device")
         return out
+
+    def _train_forward_on_device(self, lat_t: torch.Tensor, zs_t: torch.Tensor, pos_t: torch.Tensor) -> torch.Tensor:
+        """Training-mode ``forward`` of a device-resident batch with device-resident weights
+        (``rn_potgnn_train_forward_samples_device``): enqueued behind torch's current stream, no synchronisation."""
+        device, s, pos, lat32, types = self._device_inputs(lat_t, zs_t, pos_t)
+        if s == 0:
+            raise ValueError("a training batch needs at least one structure")
+        out = torch.empty((s, 6), dtype=torch.float32, device=device)
+        handle = self._ensure_handle()
+        self._install_reducer(handle)  # (no data-parallel group here: clears one that was installed before)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = _lib.load().rn_potgnn_train_forward_samples_device(
+            handle, None if lat32 is None else C.c_void_p(lat32.data_ptr()),
+            None if types is None else C.c_void_p(types.data_ptr()), C.c_void_p(pos.data_ptr()), s,
+            C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, handle, "rn_potgnn_train_forward_samples_device")
+        self._device_batches_tracked += 1  # (the library updated the running statistics where they live)
+        self._device_ahead = True
+        return out
+
+    def _train_backward_on_device(self, grad_out: torch.Tensor) -> None:
+        dvec6 = grad_out.detach().to(dtype=torch.float32).contiguous()
+        stream = torch.cuda.current_stream(dvec6.device).cuda_stream
+        rc = _lib.load().rn_potgnn_train_backward_samples_device(self._handle, C.c_void_p(dvec6.data_ptr()),
+                                                                 C.c_void_p(stream))
+        _lib.check(rc, self._handle, "rn_potgnn_train_backward_samples_device")
 
     # -- training step pieces used by _TrainStep ------------------------------------------
     def enable_data_parallel(self, group=None) -> None:
@@ -838,6 +876,22 @@ class _TrainStep(torch.autograd.Function):
         grads = ctx.model._train_backward(dvec6)
         params = [p for _, p in torch.nn.Module.named_parameters(ctx.model)]
         return (None, None, None, *[g.to(device=p.device, dtype=p.dtype) for g, p in zip(grads, params)])
+
+
+class _TrainStepOnDevice(torch.autograd.Function):
+    """``PotGNN.forward`` in training mode on CUDA tensors with ``DeviceAdam``: the batch, the result, the cotangents and
+    the parameter gradients all stay in HBM (``rn_potgnn_train_forward_samples_device`` /
+    ``rn_potgnn_train_backward_samples_device``); ``anchor`` only gives autograd a reason to call ``backward``."""
+
+    @staticmethod
+    def forward(ctx, model, lat_t, zs_t, pos_t, anchor):  # pylint: disable=arguments-differ,unused-argument
+        ctx.model = model
+        return model._train_forward_on_device(lat_t, zs_t, pos_t)
+
+    @staticmethod
+    def backward(ctx, grad_out):  # pylint: disable=arguments-differ
+        ctx.model._train_backward_on_device(grad_out)
+        return (None, None, None, None, None)
 
 
 class _DeviceSpan:  # pylint: disable=too-few-public-methods

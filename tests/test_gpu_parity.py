@@ -1019,6 +1019,39 @@ def _adam_run(model, optimizer, lat, zs, pos, targets, steps):
     return losses
 
 
+def test_device_resident_training_step_on_cuda_tensors():
+    """``train_single_epoch`` moves a batch to the device and takes the loss there (``_train.py:51-75``).  With ``DeviceAdam``
+    and CUDA tensors nothing crosses PCIe (``rn_potgnn_train_forward_samples_device`` /
+    ``rn_potgnn_train_backward_samples_device``): the output and the loss live on the GPU, and six steps -- two batch sizes,
+    strained lattices and substituted species in half of them -- give the weights that the same steps from host tensors give."""
+    from ramannoodle_amd.pmodel import DeviceAdam
+    g, _, lat, zs, pos = _load_train_case()
+    targets = torch.tensor(g["train/target"])
+    rng = np.random.default_rng(4)
+    lat2 = lat * torch.tensor(1.0 + 0.01 * rng.standard_normal((lat.shape[0], 1, 1)), dtype=lat.dtype)
+    kw = dict(lr=2e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-3)
+    runs = {}
+    for where in ("cpu", "cuda"):
+        model = product_model_from_golden(g)
+        opt = DeviceAdam(model, **kw)
+        model.train()
+        losses = []
+        for it in range(6):
+            sel = slice(0, pos.shape[0]) if it % 2 == 0 else slice(1, pos.shape[0])
+            la = (lat2 if it >= 3 else lat)[sel].to(where)
+            out = model.forward(la, zs[sel].to(where), pos[sel].to(where))
+            assert out.device.type == where and out.requires_grad
+            loss = torch.nn.MSELoss()(out, targets[sel].to(where))
+            loss.backward()
+            losses.append(float(loss.detach()))
+            opt.step()
+            opt.zero_grad()
+        runs[where] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    np.testing.assert_allclose(runs["cuda"][0], runs["cpu"][0], rtol=1e-5)
+    for k, v in runs["cpu"][1].items():
+        np.testing.assert_allclose(runs["cuda"][1][k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)  # (the loss is summed on another device)
+
+
 def test_device_adam_matches_torch_adam():
     """Device-resident training (gradients, Adam moments, weights and BatchNorm buffers stay in
     HBM; ``rn_potgnn_adam_step``) against ``torch.optim.Adam`` on the host copy of the same model,
