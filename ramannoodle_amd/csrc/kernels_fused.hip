@@ -795,15 +795,19 @@ struct ReadoutFusedArgs {
 };
 
 // PRE (with F16): the edge rows are split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs) -- the first layer's operand as fetched
-template <bool F16, bool PRE = false>
-__global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs a, int tiles_per_wave) {
+// NW waves per workgroup share one copy of the weights in LDS (41 KiB as split f16) and own a 4.3 KiB slab each: eight waves
+// = 77 KiB, two workgroups per CU = four waves per SIMD at 88 VGPRs (four waves per workgroup were two per SIMD: the
+// weights' copy per workgroup set the occupancy).
+template <bool F16, bool PRE = false, int NW = (F16 ? 8 : 4)>
+__global__ __launch_bounds__(64 * NW, 2) void readout_fused_kernel(ReadoutFusedArgs a, int tiles_per_wave) {
   constexpr int LDW = FP + 4;  // floats: row stride of the transposed f32 weights and of the slabs
   constexpr int LDH = FP + 8;  // halves: row stride of the transposed split-f16 weights
   // transposed weights [n][k]: f32 (LDW) or split f16, hi then lo (LDH)
   constexpr int kW64 = F16 ? 2 * FP * LDH * 2 : FP * LDW * 4, kW16 = F16 ? 2 * 16 * LDH * 2 : 16 * LDW * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char w0_raw[kW64], w3_raw[kW64], w5_raw[kW16];
-  __shared__ __attribute__((aligned(16))) float slab_all[4 * 16 * LDW];
-  __shared__ float s_scale0[FP], s_shift0[FP], s_b3[FP], s_b5[16];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ro_smem[];
+  unsigned char *w0_raw = ro_smem, *w3_raw = w0_raw + kW64, *w5_raw = w3_raw + kW64;
+  float *slab_all = reinterpret_cast<float *>(w5_raw + kW16);
+  float *s_scale0 = slab_all + NW * 16 * LDW, *s_shift0 = s_scale0 + FP, *s_b3 = s_shift0 + FP, *s_b5 = s_b3 + FP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   auto put = [&](unsigned char *raw, int rows, int n, int k, float v) {
@@ -820,12 +824,12 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
   const float ps0 = F16 ? a.w.mfma_scale[0] : 1.0f, inv0 = F16 ? a.w.mfma_scale[1] : 1.0f;
   const float ps3 = F16 ? a.w.mfma_scale[2] : 1.0f, inv3 = F16 ? a.w.mfma_scale[3] : 1.0f;
   const float ps5 = F16 ? a.w.mfma_scale[4] : 1.0f, inv5 = F16 ? a.w.mfma_scale[5] : 1.0f;
-  for (int i = tid; i < FP * FP; i += 256) {
+  for (int i = tid; i < FP * FP; i += 64 * NW) {
     const int k = i / FP, n = i % FP;  // W?T is [K][N] row-major
     put(w0_raw, FP, n, k, ps0 * a.w.W0T[i]);
     put(w3_raw, FP, n, k, ps3 * a.w.W3T[i]);
   }
-  for (int i = tid; i < FP * 16; i += 256) {
+  for (int i = tid; i < FP * 16; i += 64 * NW) {
     const int k = i / 16, n = i % 16;
     put(w5_raw, 16, n, k, ps5 * a.w.W5T[k * 32 + n]);
   }
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void readout_fused_kernel(ReadoutFusedArgs 
   __syncthreads();
   float *slab = slab_all + wave * 16 * LDW;
   const int64_t num_tiles = (a.M + 15) / 16;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+  const int64_t first = ((int64_t)blockIdx.x * NW + wave) * tiles_per_wave;
 
   // one 16 x 64 times 64 x (16 NT) product: A in registers (k = 16 quad + s), B rows from LDS
   f16x8 ah[2], al[2];  // split-f16 image of the A rows in `af` (F16 only; refreshed by `operand`)
@@ -945,10 +949,19 @@ void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w
   ReadoutFusedArgs a{edge, pol, M, w};
   const int64_t tiles = (M + 15) / 16;
   const int tpw = 8;
-  const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
-  if (f16 && pair_rows) readout_fused_kernel<true, true><<<blocks, 256, 0, st>>>(a, tpw);
-  else if (f16) readout_fused_kernel<true><<<blocks, 256, 0, st>>>(a, tpw);
-  else readout_fused_kernel<false><<<blocks, 256, 0, st>>>(a, tpw);
+  // dynamic LDS: the three weight copies + one slab per wave + the four small vectors (readout_fused_kernel)
+  auto launch = [&](auto kern, int nw, bool f16w) {
+    constexpr int LDW = FP + 4, LDH = FP + 8;
+    const size_t lds = (f16w ? (size_t)2 * (2 * FP * LDH * 2) + 2 * 16 * LDH * 2 : (size_t)2 * FP * LDW * 4 + 16 * LDW * 4) +
+                       (size_t)nw * 16 * LDW * 4 + (3 * FP + 16) * 4;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const unsigned blocks = (unsigned)((tiles + (int64_t)nw * tpw - 1) / ((int64_t)nw * tpw));
+    kern<<<blocks, 64 * nw, lds, st>>>(a, tpw);
+  };
+  if (f16 && pair_rows) launch(&readout_fused_kernel<true, true>, 8, true);
+  else if (f16) launch(&readout_fused_kernel<true>, 8, true);
+  else launch(&readout_fused_kernel<false>, 4, false);
 }
 
 size_t edge_fused_lds_bytes(const Graph &g) {
