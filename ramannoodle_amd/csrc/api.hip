@@ -981,13 +981,15 @@ struct ChunkRun {
         return;
       }
     }
+    int pol_stride = 32;
     {
       Timer t(h, st(), K_READOUT_MLP);
       const int HP = std::max(d.FeP, 32);
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (fused() && h->use_readout_fused) {  // the three layers in one launch
-          launch_readout_fused(edge[cur], ME, P.ro, bufA, h->mfma_f16, st(), pair_rows());
+        if (fused() && h->use_readout_fused) {  // the three layers in one launch; whole 64-byte rows of the 16 columns it writes
+          pol_stride = h->keep_stages ? 32 : 16;  // (the stage snapshots read the unfused chain's 32-column layout)
+          launch_readout_fused(edge[cur], ME, P.ro, bufA, h->mfma_f16, st(), pair_rows(), pol_stride);
           done = true;
         }
       }
@@ -1002,7 +1004,7 @@ struct ChunkRun {
     {
       Timer t(h, st(), K_READOUT_REDUCE);
       const double *ms = h->d_mean_std.as<double>();
-      launch_readout_reduce<T>(bufA, unit4, S, g, ms, ms + 9, d_vec6, d_alpha, d_alpha_raw, st());
+      launch_readout_reduce<T>(bufA, unit4, S, g, ms, ms + 9, d_vec6, d_alpha, d_alpha_raw, st(), pol_stride);
     }
     HIP_TRY(hipGetLastError());
   }

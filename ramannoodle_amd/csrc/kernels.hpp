@@ -175,7 +175,7 @@ void launch_edge_agg(const T *pq, const T *np3, const T *c2pre, const T *edge_in
 template <typename T>
 void launch_readout_reduce(const T *pol, const T *unit4, int S, const Graph &g,
                            const double *mean9, const double *std9, float *vec6,
-                           double *alpha, double *alpha_raw, hipStream_t st);
+                           double *alpha, double *alpha_raw, hipStream_t st, int pol_stride = 32 /* floats between rows of pol */);
 
 void launch_radius_graph(const double *lattice, const double *pos, int N, float cutoff,
                          unsigned char *adjacency, hipStream_t st);
@@ -268,7 +268,7 @@ size_t node_fused_lds_bytes(const Graph &g);
 size_t node_fused_lds_bytes(int tile_in_rows, int tile_nodes);
 // `f16`: matrix products as three split-f16 MFMAs (device_utils.hpp) instead of the exact-f32 MFMA
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
-                          hipStream_t st, bool pair_rows = false);
+                          hipStream_t st, bool pair_rows = false, int pol_stride = 32 /* 16: rows of exactly the 16 columns written */);
 // `centred`: npc1 was projected with c1_WnT_c / c1_bias_c and the kernel multiplies with c1_WeT_c: zero row mean, the
 // LayerNorm(2Fn) in front of the gate needs the sum of squares only (split-f16 instantiations)
 size_t node_atom_lds_bytes(int max_deg);

@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256) void readout_reduce_kernel(const T *__restrict
                                                              const double *__restrict__ std9,
                                                              float *__restrict__ vec6,
                                                              double *__restrict__ alpha,
-                                                             double *__restrict__ alpha_raw) {
+                                                             double *__restrict__ alpha_raw, int pol_stride) {
   __shared__ T red[4][6];
   __shared__ T fin[6];
   const int s = blockIdx.x;
@@ -818,9 +818,9 @@ __global__ __launch_bounds__(256) void readout_reduce_kernel(const T *__restrict
   for (int e = threadIdx.x; e < g.E; e += 256) {
     const int64_t row = (int64_t)s * g.E + e;
     const Vec4<T> u = load4<T>(unit4 + row * 4);
-    const Vec4<T> m0 = load4<T>(pol + row * 32);
-    const Vec4<T> m1 = load4<T>(pol + row * 32 + 4);
-    const Vec4<T> m2 = load4<T>(pol + row * 32 + 8);
+    const Vec4<T> m0 = load4<T>(pol + row * pol_stride);
+    const Vec4<T> m1 = load4<T>(pol + row * pol_stride + 4);
+    const Vec4<T> m2 = load4<T>(pol + row * pol_stride + 8);
     const T ux = u.v[0], uy = u.v[1], uz = u.v[2];
     a[3] += (m0.v[0] - m0.v[1]) * (ux * uy);                 // xy <- emb 0,1
     a[4] += (m0.v[2] - m0.v[3]) * (ux * uz);                 // xz <- emb 2,3
@@ -855,16 +855,16 @@ __global__ __launch_bounds__(256) void readout_reduce_kernel(const T *__restrict
 template <typename T>
 void launch_readout_reduce(const T *pol, const T *unit4, int S, const Graph &g,
                            const double *mean9, const double *std9, float *vec6, double *alpha,
-                           double *alpha_raw, hipStream_t st) {
+                           double *alpha_raw, hipStream_t st, int pol_stride) {
   if (S == 0) return;
-  readout_reduce_kernel<T><<<S, 256, 0, st>>>(pol, unit4, S, g, mean9, std9, vec6, alpha, alpha_raw);
+  readout_reduce_kernel<T><<<S, 256, 0, st>>>(pol, unit4, S, g, mean9, std9, vec6, alpha, alpha_raw, pol_stride);
 }
 template void launch_readout_reduce<float>(const float *, const float *, int, const Graph &,
                                            const double *, const double *, float *, double *,
-                                           double *, hipStream_t);
+                                           double *, hipStream_t, int);
 template void launch_readout_reduce<double>(const double *, const double *, int, const Graph &,
                                             const double *, const double *, float *, double *,
-                                            double *, hipStream_t);
+                                            double *, hipStream_t, int);
 
 // ============================================================================ radius graph
 // One-time neighbour search of the reference structure (_utils.py:118-137): all N^2

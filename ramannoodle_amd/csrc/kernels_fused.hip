@@ -789,9 +789,10 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
 // Replaces three projection launches that wrote and re-read two [S*E, 64] intermediates.
 struct ReadoutFusedArgs {
   const float *edge;  // [M, FP]
-  float *pol;         // [M, 32]: columns 0..15 written (12 real)
+  float *pol;         // [M, pol_stride]: columns 0..15 written (12 real)
   int64_t M;
   ReadoutW<float> w;
+  int pol_stride;     // 32 (the unfused chain's layout) or 16 (whole 64-byte rows)
 };
 
 // PRE (with F16): the edge rows are split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs) -- the first layer's operand as fetched
@@ -938,15 +939,15 @@ __global__ __launch_bounds__(64 * NW, 2) void readout_fused_kernel(ReadoutFusedA
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int64_t row = tile * 16 + 4 * quad + rr;
-      if (row < a.M) a.pol[row * 32 + l15] = fmaf(acc[rr], inv5, s_b5[l15]);
+      if (row < a.M) a.pol[row * a.pol_stride + l15] = fmaf(acc[rr], inv5, s_b5[l15]);
     }
   }
 }
 
 void launch_readout_fused(const float *edge, int64_t M, const ReadoutW<float> &w, float *pol, bool f16,
-                          hipStream_t st, bool pair_rows) {
+                          hipStream_t st, bool pair_rows, int pol_stride) {
   if (M == 0) return;
-  ReadoutFusedArgs a{edge, pol, M, w};
+  ReadoutFusedArgs a{edge, pol, M, w, pol_stride};
   const int64_t tiles = (M + 15) / 16;
   const int tpw = 8;
   // dynamic LDS: the three weight copies + one slab per wave + the four small vectors (readout_fused_kernel)
