@@ -169,7 +169,7 @@ def mean_over_ranks(value: float, group=None) -> float:
     """Mean of a per-rank scalar over the ranks (one small all-reduce)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(value)
-    buf = torch.tensor([float(value)], dtype=torch.float64)
+    buf = torch.tensor([float(value)], dtype=torch.float64, device="cpu")
     if dist.get_backend(group) == "nccl":
         buf = buf.cuda()
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)

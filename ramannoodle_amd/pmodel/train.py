@@ -17,8 +17,13 @@ def train_single_epoch(model, training_set, validation_set, batch_size: int, opt
     the validation predictions [6])``.  Forward and backward run on the device; the
     optimiser is whatever ``torch.optim`` object the caller built on ``model.parameters()``.
     """
+    # the shuffling generator lives on torch's default device, as the reference's does (_train.py:51-58): under
+    # torch.set_default_device("cuda") -- the reference's GPU recipe -- the sampler draws its permutation there and a
+    # CPU generator is refused.  Every rank of a data-parallel run builds it the same way (same device type, same
+    # default seed), so the ranks' mini-batches stay in step.
+    default_device = torch.get_default_device()
     train_loader = DataLoader(training_set, batch_size=batch_size, shuffle=True,
-                              generator=torch.Generator())
+                              generator=torch.Generator(device=default_device))
     validation_loader = DataLoader(validation_set, batch_size=min(100, len(validation_set)),
                                    shuffle=False)
     # data-parallel (``model.enable_data_parallel()``): every rank draws the same shuffled
@@ -32,12 +37,12 @@ def train_single_epoch(model, training_set, validation_set, batch_size: int, opt
     host_threads = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
-        return _run_epoch(model, train_loader, validation_loader, optimizer, loss_function, group)
+        return _run_epoch(model, train_loader, validation_loader, optimizer, loss_function, group, default_device)
     finally:
         torch.set_num_threads(host_threads)
 
 
-def _run_epoch(model, train_loader, validation_loader, optimizer, loss_function, group):
+def _run_epoch(model, train_loader, validation_loader, optimizer, loss_function, group, device):
     model.train()
     train_losses = []
     for batch in train_loader:
@@ -51,8 +56,9 @@ def _run_epoch(model, train_loader, validation_loader, optimizer, loss_function,
             # share so that the averaged step is the full-batch step
             weight = parallel.rank_loss_weight(batch[0].shape[0], global_items, group)
         lattice, atomic_numbers, position, polarizability = batch
-        out = model.forward(lattice, atomic_numbers, position)
-        loss = loss_function(out, polarizability) * weight
+        # the batch goes to the default device (_train.py:65-69); the result lives where the batch lives
+        out = model.forward(lattice.to(device), atomic_numbers.to(device), position.to(device))
+        loss = loss_function(out, polarizability.to(out.device)) * weight
         loss.backward()
         if group is not None:
             parallel.average_gradients(model, group)
@@ -65,8 +71,8 @@ def _run_epoch(model, train_loader, validation_loader, optimizer, loss_function,
     model.eval()
     validation_losses, validation_vars = [], []
     for lattice, atomic_numbers, position, polarizability in validation_loader:
-        out = model.forward(lattice, atomic_numbers, position)
-        validation_losses.append(float(loss_function(out, polarizability).detach()))
+        out = model.forward(lattice.to(device), atomic_numbers.to(device), position.to(device))
+        validation_losses.append(float(loss_function(out, polarizability.to(out.device)).detach()))
         validation_vars.append(torch.var(out, dim=0).detach().cpu().numpy().copy())
     return (float(np.mean(train_losses)), float(np.mean(validation_losses)),
             np.mean(validation_vars, axis=0))
