@@ -1143,13 +1143,13 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
 #endif
       if (fail != 0) {
         HIP_TRY(hipMemset(h->ps_fail.p, 0, sizeof(int)));
-        // (which wait: 1 = the producers' split sync, 2 = a producer waiting for the consumers of round g - 2, 4 = a consumer
-        //  waiting for its round)
+        // (which wait: 1 = the producers' split sync, 2 = a producer waiting for round g - 2's P' / c2 rows to be taken,
+        //  3 = a producer waiting for round g - 3 to be finished, 4 = a consumer waiting for its round)
         static const char *const which[5] = {
             "role-specialised EdgeBlock: a wait between producer and consumer waves timed out",
             "role-specialised EdgeBlock: the producers' split sync timed out",
-            "role-specialised EdgeBlock: a producer's wait for the consumers of an earlier round timed out",
-            "role-specialised EdgeBlock: a wait between producer and consumer waves timed out",
+            "role-specialised EdgeBlock: a producer's wait for the consumers to take the rows of an earlier round timed out",
+            "role-specialised EdgeBlock: a producer's wait for the consumers to finish an earlier round (ring rows) timed out",
             "role-specialised EdgeBlock: a consumer's wait for its round timed out"};
         throw HipError{hipErrorLaunchFailure, which[fail >= 0 && fail <= 4 ? fail : 0]};
       }

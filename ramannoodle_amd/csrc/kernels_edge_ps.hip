@@ -12,20 +12,29 @@
 //              then by MFMA  P'_d = W4 edge_d + Wj node[b_d] + Wk node[a_d] + bias  and the c2 pre-activation
 //              for the round's 16 destination edges, and  Q'_e = W5 edge_e + Wi node[b_e]  for the 16-row source
 //              tiles the coming rounds need.  The node terms seed the accumulators, so an MFMA result IS the row.
-//   waves 4-11 CONSUMERS (two per SIMD).  A wave owns two destinations of the round, each split over two 16-lane
-//              groups (one half of its triplets each): triplet loop on LDS operands, both halves added by one
-//              cross-row swizzle, LayerNorms, c2 gate, residual tanh, store.  No weights: ~110 VGPRs.
+//   waves 4-11 CONSUMERS (two per SIMD) in TWO SETS of four (round 5): waves 4-7 take the even rounds, waves 8-11 the odd
+//              ones.  A wave owns FOUR destinations of its round, one per 16-lane group with the destination's whole
+//              triplet list (lane q of a group: columns 4q..4q+3 of the filter and of the core half): P' row -> registers,
+//              the c2 branch (gate(LN(c2 pre-activation)) -> LN, independent of the triplets) right away, then the
+//              triplet loop on the ring's rows, LayerNorm, residual tanh, store.  No weights: ~130 VGPRs.
+//              (Round 4 gave every destination TWO lane groups of one wave, half of the triplets each, so that all eight
+//               waves worked on every round: the per-destination prologue ran twice, the epilogue crossed lane groups,
+//               and every round was one hand-over of all twelve waves.  A set now has two round periods for its round,
+//               a destination's prologue / epilogue runs once on 16 lanes, and 17 triplets cost 17 loop slots, not 18.)
 //
 // Three waves per SIMD, and no s_barrier after start-up: the roles meet through LDS words (an LDS atomic add to
 // signal, a relaxed poll with s_sleep to wait; a wave's LDS operations are performed in order):
 //   c_split / c_norm  the four producers among themselves (operand tiles split; projections written)
 //   c_ready           round g may be consumed (published by the LAST producer to finish the step, once it has
-//                     completed the new rows' |q|^2 from the four producers' parts)
-//   c_done[g & 1]     consumer waves that finished round g -- a producer overwrites the buffers of round g only
-//                     after all eight waves finished round g - 2.
+//                     completed the new rows' |q|^2 from the four producers' parts); its top bit = "a bounded wait ran
+//                     out somewhere in this workgroup": every row stored after that is NaN
+//   c_free[g & 1]     consumer waves that have TAKEN round g's P' and c2 rows into registers (right after the round
+//                     starts): a producer overwrites those buffers for round g + 2 after all four waves of the set did
+//   c_rd[g & 1]       consumer waves that FINISHED round g (no longer read the ring)
 // Q' lives in a RING of source-row tiles (PS_NRT x 16 rows): destinations are sorted by their atom and so are the
-// source rows, so round g needs a sliding window of rows; a tile is overwritten when the rounds that read it are
-// done (the host checks, by running the same schedule, that "round g - 2 finished" implies that: ps_schedule_ok).
+// source rows, so round g needs a sliding window of rows.  The step of round g writes its new tiles once round g - 3
+// is finished, i.e. while rounds g - 2 and g - 1 may still be reading: the host checks, by running the same
+// schedule, that no tile those rounds read is overwritten then (edge_ps_tile_ok).
 //
 // No LayerNorm mean anywhere: c3_linear / c2_linear are centred over their output columns on the host
 // (api.hip: centred_ops), LN(x) = LN(x - mean x) and mean x is linear in the inputs, so the projections come out
@@ -91,7 +100,6 @@ struct EdgePsArgs {
 namespace {
 constexpr int PS_THREADS = 768;
 constexpr int PS_PROD = 4;   // producer waves
-constexpr int PS_CONS = 8;   // consumer waves
 constexpr int PS_ND = 16;    // destinations per round (two per consumer wave)
 constexpr int PS_NRT = 8;    // ring capacity, in 16-row source tiles
 constexpr int PS_RING = PS_NRT * 16;
@@ -100,7 +108,11 @@ constexpr int PS_MAXNEW = 2;             // source tiles a step produces at most
 constexpr int PS_TILE = 16 * FP;         // floats of one operand tile
 constexpr int PS_BUF = (2 + PS_MAXNEW) * PS_TILE;  // one DMA buffer: edge_d | node[b] | PS_MAXNEW x edge_e
 
-enum { C_SPLIT = 0, C_NORM = 16, C_READY = 32, C_DONE0 = 48, C_DONE1 = 64 };  // byte offsets of the signalling words
+constexpr int PS_CSET = 4;   // consumer waves per set (even rounds: waves 4-7, odd rounds: waves 8-11)
+constexpr unsigned PS_FAILBIT = 0x80000000u;  // in the C_READY word: a bounded wait ran out, everything stored from now on is NaN
+
+// byte offsets of the signalling words
+enum { C_SPLIT = 0, C_NORM = 16, C_READY = 32, C_FREE0 = 48, C_FREE1 = 64, C_RD0 = 80, C_RD1 = 96 };
 
 struct PsLds {
   size_t ring, qnp, bufP, bufC, atile, lnp, ints, sync, total;
@@ -201,15 +213,27 @@ __host__ __device__ inline bool ps_sched_next(PsSched &s, HiFn hi, PsStep &st) {
 // (a full HBM round trip per step), for a consumer the previous round's output stores.  LDS operations of a wave are
 // performed in order, and the waits below are on lgkmcnt only.
 // Bounded: a wait that has not been satisfied after ~2^21 polls (tens of milliseconds; a real one takes microseconds)
-// reports `code` through *fail and lets the wave go on, so a protocol bug produces an error instead of a hung GPU.
-__device__ __forceinline__ void ps_wait_ge(unsigned word, unsigned target, int *fail, int code) {
+// reports `code` through *fail, sets the top bit of the workgroup's C_READY word -- every wave that stores a row after seeing
+// it stores NaN, so an entry point that does not synchronise (and so cannot look at *fail) never hands back plausible numbers
+// -- and lets the wave go on: a protocol bug produces an error, not a hung GPU.  Returns the value read (wave-uniform).
+__device__ __forceinline__ unsigned ps_wait_ge(unsigned word, unsigned target, unsigned ready_word, int *fail, int code) {
   for (unsigned spins = 0;; ++spins) {
     unsigned v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(word) : "memory");
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
-    if (spins > (1u << 21)) {
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    if (v >= target) return v;
+    // (once any wave of the workgroup has given up, the others follow within a thousand polls instead of 2^21 each)
+    bool give_up = spins > (1u << 21);
+    if ((spins & 1023u) == 1023u && !give_up) {
+      unsigned rv;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rv) : "v"(ready_word) : "memory");
+      give_up = ((unsigned)__builtin_amdgcn_readfirstlane((int)rv) & PS_FAILBIT) != 0;
+    }
+    if (give_up) {
       *fail = code;
-      break;
+      // (the store counts in vmcnt like a load: drain, so that no counted wait behind this point returns early)
+      asm volatile("ds_or_b32 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(ready_word), "v"(PS_FAILBIT) : "memory");
+      return v | PS_FAILBIT;
     }
 #if RN_PS_SLEEP
     __builtin_amdgcn_s_sleep(RN_PS_SLEEP);
@@ -228,23 +252,10 @@ __device__ __forceinline__ unsigned ps_arrive_ticket(unsigned word, int lane) {
   if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(word), "v"(1u) : "memory");
   return (unsigned)__builtin_amdgcn_readfirstlane((int)old);
 }
+// (an unsigned maximum, not a write: the failure bit of C_READY survives later publications)
 __device__ __forceinline__ void ps_publish(unsigned word, unsigned value, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(word), "v"(value) : "memory");
-}
-// LayerNorm of a row of logical width F spread over THIRTY-TWO lanes, two columns per lane (the two 16-lane halves
-// of a destination share the epilogue: each finishes half of the columns instead of both finishing all of them)
-template <bool PAD>
-__device__ __forceinline__ f32x2 ln_row2(f32x2 x, f32x2 g, f32x2 b, float inv_n, int nvalid) {
-  const float mean = lg_sum32(x.x + x.y) * inv_n;
-  f32x2 d = {x.x - mean, x.y - mean};
-  if (PAD) {
-    if (nvalid < 1) d.x = 0.f;
-    if (nvalid < 2) d.y = 0.f;
-  }
-  const float q = lg_sum32(d.x * d.x + d.y * d.y);
-  const float rstd = fast_rsq(q * inv_n + 1e-5f);
-  return f32x2{d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y};
+  if (lane == 0) asm volatile("ds_max_u32 %0, %1" ::"v"(word), "v"(value) : "memory");
 }
 }  // namespace
 
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       if (!(RN_PS_PROBE & 16)) split_landed(buf, ln);
       PS_TICK(1);
       ps_arrive(sync_a + C_SPLIT, ln);
-      if (!(RN_PS_PROBE & 64)) ps_wait_ge(sync_a + C_SPLIT, 4u * (k + 1u), a.fail, 1);
+      if (!(RN_PS_PROBE & 64)) ps_wait_ge(sync_a + C_SPLIT, 4u * (k + 1u), sync_a + C_READY, a.fail, 1);
       PS_TICK(2);
       // ---- B: request the next step's rows (its buffer and the node[a] tile are free: every producer is past step k - 1)
       PS_TICK(3);
@@ -466,8 +477,9 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       // compiler to hand to something else while the load is still in flight.  So the waits are unconditional and only the
       // arithmetic around them is not.
       PS_TICK(4);
-      // ---- the buffers of round g were last read by round g - 2
-      if (cur.has_dest) ps_wait_ge(sync_a + ((cur.g & 1) ? C_DONE1 : C_DONE0), (unsigned)PS_CONS * (unsigned)(cur.g >> 1), a.fail, 2);
+      // ---- the P' / c2 buffers of round g were last read by round g - 2: its set has taken the rows into registers
+      if (cur.has_dest)
+        ps_wait_ge(sync_a + ((cur.g & 1) ? C_FREE1 : C_FREE0), (unsigned)PS_CSET * (unsigned)(cur.g >> 1), sync_a + C_READY, a.fail, 2);
       PS_TICK(5);
       ln = launder(ln);
       const int l15 = ln & 15, quad = ln >> 4, mycol = colbase + 4 * quad;  // + 16 t: the four columns of tile t this lane ends up with
@@ -530,6 +542,11 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         }
         // (issued after this step's requests: everything of this wave has landed then -- the requests are ~2000 cycles old)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qS[0]), "+v"(qS[1]), "+v"(accQ[0]), "+v"(accQ[1])::"memory");
+        // ---- the ring: this step's tiles overwrite rows that rounds <= g - 3 read (edge_ps_tile_ok) -- round g - 3 must be done
+        // (rounds of the parity of g + 1; there are ((g - 3) >> 1) + 1 of them up to g - 3).  Behind the product: hidden under it.
+        if (cur.has_dest && cur.g >= 3)
+          ps_wait_ge(sync_a + (((cur.g + 1) & 1) ? C_RD1 : C_RD0), (unsigned)PS_CSET * (unsigned)(((cur.g - 3) >> 1) + 1), sync_a + C_READY,
+                     a.fail, 3);
         if (ntl > 0) q_tile_finish(accQ, g3v, ringrow0);
       }
       if (ntl > 1) {  // a second tile in one step is rare (once per unit): its node terms are fetched here, by ordinary loads
@@ -565,12 +582,11 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   }
 
   // ============================================================================================= CONSUMER
-  const int cw = wave - PS_PROD;            // 0..7: destinations 2 cw, 2 cw + 1 of every round
-  const int q4 = l15, c0 = 4 * q4;          // lane q4 of a group owns columns 4 q4 .. + 3 (+ FP)
-  const int dsel = quad >> 1, part = quad & 1;  // which of the wave's two destinations, which half of its triplets
-  const int slot = 2 * cw + dsel;
-  const int cc = c0 + 2 * part;             // the two columns this lane finishes in the epilogue
-  const int nvalid2 = min(max(a.d.Fe - cc, 0), 2);
+  const int cw = wave - PS_PROD;            // 0..7
+  const int cset = cw >> 2;                 // 0: the even global rounds, 1: the odd ones
+  const int slot = 4 * (cw & 3) + quad;     // the destination of a round this 16-lane group owns
+  const int c0 = 4 * l15;                   // lane l15 of a group owns columns c0 .. c0 + 3 of the filter and of the core half
+  const int nvalid = min(max(a.d.Fe - c0, 0), 4);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
   const float spscale = a.w.mfma_scale_c[1] * a.w.mfma_scale_c[1] * inv2n;  // P' rows arrive prescaled (see s_g3)
   const float eps_c2 = 1e-5f * a.w.mfma_scale_c[4] * a.w.mfma_scale_c[4];     // so do the c2 rows
@@ -585,13 +601,12 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     //  every round's own loads and stores are outstanding too)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf2[0]), "+v"(bf2[1]), "+v"(bc2[0]), "+v"(bc2[1]));
   }
-  // LayerNorm parameters of this lane's two epilogue columns: registers (the consumers have ~50 to spare), not eight LDS
-  // reads per round
-  const f32x2 k_c3g = *reinterpret_cast<const f32x2 *>(s_c3n2g + cc), k_c3b = *reinterpret_cast<const f32x2 *>(s_c3n2b + cc);
-  const f32x2 k_c21gf = *reinterpret_cast<const f32x2 *>(s_c2n1g + cc), k_c21bf = *reinterpret_cast<const f32x2 *>(s_c2n1b + cc);
-  const f32x2 k_c21gc = *reinterpret_cast<const f32x2 *>(s_c2n1g + FP + cc), k_c21bc = *reinterpret_cast<const f32x2 *>(s_c2n1b + FP + cc);
-  const f32x2 k_c22g = *reinterpret_cast<const f32x2 *>(s_c2n2g + cc), k_c22b = *reinterpret_cast<const f32x2 *>(s_c2n2b + cc);
-  Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);  // (likewise: the folds of a P' row;
+  // LayerNorm parameters of this lane's four columns: registers (a consumer has ~40 to spare), not LDS reads per round
+  const LnParams<float> k_c3 = {load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
+  const LnParams<float> k_c21f = {load4<float>(s_c2n1g + c0), load4<float>(s_c2n1b + c0)};
+  const LnParams<float> k_c21c = {load4<float>(s_c2n1g + FP + c0), load4<float>(s_c2n1b + FP + c0)};
+  const LnParams<float> k_c22 = {load4<float>(s_c2n2g + c0), load4<float>(s_c2n2b + c0)};
+  Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);  // (the folds of a P' row:
   const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);  //  1/gamma with the 2 / 2Fe of p.q)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -600,140 +615,168 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   }
   const float *ringc = ring + c0;
   const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
-  int ub = 0;                      // ring row of the unit's first source row
-  unsigned gr = 0;                 // global round
+  // this set's first round: global round `cset` = (unit u, local round r); ub = ring row of unit u's first source row
+  int u = 0, r = cset, ub = 0;
+  while (r >= nrounds) {
+    r -= nrounds;
+    ++u;
+    ub = (ub + nrt * 16) & (PS_RING - 1);
+  }
+  bool poisoned = false;  // a bounded wait ran out in this workgroup: store NaN from here on
 #if RN_PS_TIMING
   long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
   const bool timed = blockIdx.x == 0 && wave == PS_PROD && lane == 0;
 #endif
-  for (int s = sg; s < a.S; s += nsg) {
-    const int64_t erow0 = (int64_t)s * g.E;
-    for (int r = 0; r < nrounds; ++r, ++gr) {
-      PS_T0();
-      ps_wait_ge(sync_a + C_READY, gr + 1u, a.fail, 4);
-      PS_TICK(10);
-      const bool active = r * PS_ND + slot < D;
-      const int i = min(r * PS_ND + slot, D - 1);  // (a lane group beyond the tile's last destination: zero triplets of a valid one)
-      const int64_t drow = erow0 + d_edge[i];
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      f32x2 old2;
-      {
-        if constexpr (PRE) {  // columns cc, cc + 1 of group m = cc / 8: two f16 of the hi slot, two of the lo slot
-          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-          const h2 *pp = reinterpret_cast<const h2 *>(a.edge_in + drow * FP + (cc >> 3) * 8) + ((cc & 7) >> 1);
-          const h2 hh = pp[0], ll = pp[4];
-          old2 = f32x2{(float)hh[0] + (float)ll[0], (float)hh[1] + (float)ll[1]};
-        } else {
-          old2 = *reinterpret_cast<const f32x2 *>(a.edge_in + drow * FP + cc);
-        }
-        const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
-        const Vec4<float> xf = load4<float>(prow + c0), xc = load4<float>(prow + FP + c0);
-        float sp = 0.f;
+  for (unsigned gr = (unsigned)cset; u < nunits; gr += 2) {
+    PS_T0();
+    poisoned |= (ps_wait_ge(sync_a + C_READY, gr + 1u, sync_a + C_READY, a.fail, 4) & PS_FAILBIT) != 0;
+    PS_TICK(10);
+    const int64_t erow0 = (int64_t)(sg + u * nsg) * g.E;
+    const bool active = r * PS_ND + slot < D;
+    const int i = min(r * PS_ND + slot, D - 1);  // (a lane group beyond the tile's last destination: zero triplets of a valid one)
+    const int64_t drow = erow0 + d_edge[i];
+    // the destination's own row (the residual): requested now, consumed in the epilogue
+    f32x4 old4;
+    if constexpr (PRE) {  // columns c0 .. c0 + 3 of group m = c0 / 8: four f16 of the hi slot, four of the lo slot
+      const char *pp = reinterpret_cast<const char *>(a.edge_in + drow * FP + (c0 >> 3) * 8) + (c0 & 7) * 2;
+      const f16x4 hh = *reinterpret_cast<const f16x4 *>(pp), ll = *reinterpret_cast<const f16x4 *>(pp + 16);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sp += xf.v[k] * xf.v[k] + xc.v[k] * xc.v[k];  // zero-mean by construction
-        sp = lg_sum<LG>(sp);
-        // pd = p / gamma * (2 / 2Fe), pg = p * gamma;  var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
-        f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2];
-        {
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh], xf.v[2 * hh + 1] * igf.v[2 * hh + 1]};
-            pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh], xc.v[2 * hh + 1] * igc.v[2 * hh + 1]};
-            pf2[hh] = f32x2{xf.v[2 * hh] * g3f.v[2 * hh], xf.v[2 * hh + 1] * g3f.v[2 * hh + 1]};
-            pc2[hh] = f32x2{xc.v[2 * hh] * g3c.v[2 * hh], xc.v[2 * hh + 1] * g3c.v[2 * hh + 1]};
-          }
-        }
-        const float spe = sp * spscale + 1e-5f;
-        const int rb = d_rb[i], cnt = active ? d_cnt[i] : 0, rskip = d_skip[i];
-        const int half = (cnt + 1) >> 1;
-        const int t0 = part ? half : 0, t1 = part ? cnt : half;  // this group's half of the triplets
-        auto triplet = [&](const float *qr, float (&sumk)[4]) {
-          const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
-          const float qs = qr[sdelta];
-          const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
-          f32x2 d2 = pdf2[0] * qf2[0];
-          f32x2 d3 = pdc2[0] * qc2[0];
-          d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
-          d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
-          d2 += d3;
-          const float dot = lg_sum<LG>(d2.x + d2.y);
-          float ve = dot + (spe + qs);
-          ve = ve > 1e-5f ? ve : 1e-5f;
-          const float rstd = fast_rsq(ve);
-          const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const f32x2 xf2 = __builtin_elementwise_fma(pf2[hh] + qf2[hh], rstd2, bf2[hh]);
-            const f32x2 xc2 = __builtin_elementwise_fma(pc2[hh] + qc2[hh], rstd2, bc2[hh]);
-            const f32x2 e1 = {fast_exp2(xf2.x), fast_exp2(xf2.y)}, e2 = {fast_exp2(xc2.x), fast_exp2(xc2.y)};
-            const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
-            const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
-            const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
-            f32x2 sk = {sumk[2 * hh], sumk[2 * hh + 1]};
-            sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
-            sumk[2 * hh] = sk.x;
-            sumk[2 * hh + 1] = sk.y;
-          }
-        };
-        PS_TICK(11);
-#if RN_PS_CPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        // two independent triplets per iteration.  Source row of triplet t: rb + t, plus one from the reverse edge on
-        // (the numbering jumps over it); its ring slot is (that + the unit's ring base) mod PS_RING -- a compare, an
-        // add-with-carry, an AND and one 24-bit multiply per triplet, no branches and no running pointer to wrap
-        float acc2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int tskip = rskip - rb;
-        const int rbase = ub + rb;
-        auto row_of = [&](int t) {
-          const unsigned slot = (unsigned)(rbase + t + (t >= tskip ? 1 : 0)) & (unsigned)(PS_RING - 1);
-          return ringc + __umul24(slot, (unsigned)LDQ);
-        };
-        int t = (RN_PS_PROBE & 1) ? t1 : t0;
-        for (; t + 1 < t1; t += 2) {
-          triplet(row_of(t), acc);
-          triplet(row_of(t + 1), acc2);
-        }
-        if (t < t1) triplet(row_of(t), acc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
-      }
-      PS_TICK(12);
-#if RN_PS_CPRIO
-      __builtin_amdgcn_s_setprio(RN_PS_CPRIO);
-#endif
-      // the two halves of a destination sit in lane groups 16 apart: both end up with the whole sum
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = sum_xor16(acc[k]);
-      if (active && (RN_PS_PROBE & 4)) *reinterpret_cast<f32x2 *>(a.edge_out + drow * FP + cc) = f32x2{acc[0] + old2.x, acc[1] + old2.y};
-      if (active && !(RN_PS_PROBE & 4)) {
-        // from here on the two halves split the COLUMNS: this lane finishes columns cc, cc + 1
-        const f32x2 a2 = part ? f32x2{acc[2], acc[3]} : f32x2{acc[0], acc[1]};
-        if (a.agg_out) *reinterpret_cast<f32x2 *>(a.agg_out + drow * FP + cc) = a2;
-        const f32x2 c3 = ln_row2<PAD>(a2, k_c3g, k_c3b, invn, nvalid2);
-        // c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228); the pre-activation row has
-        // zero mean (centred weights) and exact zeros in its padded columns, so its variance is the plain sum of squares
-        const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
-        const f32x2 xf = *reinterpret_cast<const f32x2 *>(crow + cc), xc = *reinterpret_cast<const f32x2 *>(crow + FP + cc);
-        const float rstd2 = fast_rsq(lg_sum32(xf.x * xf.x + xf.y * xf.y + xc.x * xc.x + xc.y * xc.y) * inv2n + eps_c2);
-        const f32x2 gf = k_c21gf, bf = k_c21bf, gc = k_c21gc, bc = k_c21bc;
-        const f32x2 g2 = {gate(xf.x * rstd2 * gf.x + bf.x, xc.x * rstd2 * gc.x + bc.x), gate(xf.y * rstd2 * gf.y + bf.y, xc.y * rstd2 * gc.y + bc.y)};
-        const f32x2 c2 = ln_row2<PAD>(g2, k_c22g, k_c22b, invn, nvalid2);
-        const f32x2 y = {fast_tanh(old2.x + c2.x + c3.x), fast_tanh(old2.y + c2.y + c3.y)};
-        if constexpr (PRE) {
-          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-          h2 *pp = reinterpret_cast<h2 *>(a.edge_out + drow * FP + (cc >> 3) * 8) + ((cc & 7) >> 1);
-          const h2 hh = {(_Float16)y.x, (_Float16)y.y};
-          pp[0] = hh;
-          pp[4] = h2{(_Float16)(y.x - (float)hh[0]), (_Float16)(y.y - (float)hh[1])};
-        } else {
-          *reinterpret_cast<f32x2 *>(a.edge_out + drow * FP + cc) = y;
-        }
-      }
-      ps_arrive(sync_a + ((gr & 1u) ? C_DONE1 : C_DONE0), lane);  // this wave no longer reads round gr's buffers
-      PS_TICK(13);
+      for (int k = 0; k < 4; ++k) old4[k] = (float)hh[k] + (float)ll[k];
+    } else {
+      old4 = *reinterpret_cast<const f32x4 *>(a.edge_in + drow * FP + c0);
     }
-    ub = (ub + nrt * 16) & (PS_RING - 1);
+    // ---- the P' row -> registers, folded for the loop
+    f32x2 pf2[2], pc2[2], pdf2[2], pdc2[2];
+    float spe;
+    {
+      const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
+      const Vec4<float> xf = load4<float>(prow + c0), xc = load4<float>(prow + FP + c0);
+      float sp = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sp += xf.v[k] * xf.v[k] + xc.v[k] * xc.v[k];  // zero-mean by construction
+      sp = lg_sum<LG>(sp);
+      // pd = p / gamma * (2 / 2Fe), pg = p * gamma;  var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh], xf.v[2 * hh + 1] * igf.v[2 * hh + 1]};
+        pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh], xc.v[2 * hh + 1] * igc.v[2 * hh + 1]};
+        pf2[hh] = f32x2{xf.v[2 * hh] * g3f.v[2 * hh], xf.v[2 * hh + 1] * g3f.v[2 * hh + 1]};
+        pc2[hh] = f32x2{xc.v[2 * hh] * g3c.v[2 * hh], xc.v[2 * hh + 1] * g3c.v[2 * hh + 1]};
+      }
+      spe = sp * spscale + 1e-5f;
+    }
+    // ---- c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228).  It does not depend on the
+    // triplets, so it runs here and the round's P' / c2 buffers go back to the producers before the loop starts.  The
+    // pre-activation row has zero mean (centred weights) and exact zeros in its padded columns: its variance is the plain
+    // sum of squares (in the weights' prescale: eps scaled).
+    Vec4<float> c2v;
+    {
+      const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
+      const Vec4<float> xf = load4<float>(crow + c0), xc = load4<float>(crow + FP + c0);
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q += xf.v[k] * xf.v[k] + xc.v[k] * xc.v[k];
+      const float rstd2 = fast_rsq(lg_sum<LG>(q) * inv2n + eps_c2);
+      Vec4<float> g2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g2.v[k] = (RN_PS_PROBE & 4) ? xf.v[k] + xc.v[k]
+                                    : gate(xf.v[k] * rstd2 * k_c21f.g.v[k] + k_c21f.b.v[k], xc.v[k] * rstd2 * k_c21c.g.v[k] + k_c21c.b.v[k]);
+      }
+      c2v = (RN_PS_PROBE & 4) ? g2 : ln_row<LG, PAD, float>(g2, k_c22, invn, nvalid);
+    }
+    const int rb = d_rb[i], cnt = active ? d_cnt[i] : 0, rskip = d_skip[i];
+    ps_arrive(sync_a + ((gr & 1u) ? C_FREE1 : C_FREE0), lane);  // this wave holds what it needs of round gr's P' / c2 buffers
+    PS_TICK(11);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      auto triplet = [&](const float *qr, float (&sumk)[4]) {
+        const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
+        const float qs = qr[sdelta];
+        const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
+        f32x2 d2 = pdf2[0] * qf2[0];
+        f32x2 d3 = pdc2[0] * qc2[0];
+        d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
+        d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
+        d2 += d3;
+        const float dot = lg_sum<LG>(d2.x + d2.y);
+        float ve = dot + (spe + qs);
+        ve = ve > 1e-5f ? ve : 1e-5f;
+        const float rstd = fast_rsq(ve);
+        const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x2 xf2 = __builtin_elementwise_fma(pf2[hh] + qf2[hh], rstd2, bf2[hh]);
+          const f32x2 xc2 = __builtin_elementwise_fma(pc2[hh] + qc2[hh], rstd2, bc2[hh]);
+          const f32x2 e1 = {fast_exp2(xf2.x), fast_exp2(xf2.y)}, e2 = {fast_exp2(xc2.x), fast_exp2(xc2.y)};
+          const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+          const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
+          const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
+          f32x2 sk = {sumk[2 * hh], sumk[2 * hh + 1]};
+          sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
+          sumk[2 * hh] = sk.x;
+          sumk[2 * hh + 1] = sk.y;
+        }
+      };
+#if RN_PS_CPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      // two independent triplets per iteration.  Source row of triplet t: rb + t, plus one from the reverse edge on
+      // (the numbering jumps over it); its ring slot is (that + the unit's ring base) mod PS_RING -- a compare, an
+      // add-with-carry, an AND and one 24-bit multiply per triplet, no branches and no running pointer to wrap
+      float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+      const int tskip = rskip - rb;
+      const int rbase = ub + rb;
+      auto row_of = [&](int t) {
+        const unsigned rs = (unsigned)(rbase + t + (t >= tskip ? 1 : 0)) & (unsigned)(PS_RING - 1);
+        return ringc + __umul24(rs, (unsigned)LDQ);
+      };
+      int t = (RN_PS_PROBE & 1) ? cnt : 0;
+      for (; t + 1 < cnt; t += 2) {
+        triplet(row_of(t), acc);
+        triplet(row_of(t + 1), acc2);
+      }
+      if (t < cnt) triplet(row_of(t), acc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
+    }
+    PS_TICK(12);
+#if RN_PS_CPRIO
+    __builtin_amdgcn_s_setprio(RN_PS_CPRIO);
+#endif
+    // this wave no longer reads the ring rows of round gr (all its LDS reads are complete: ps_arrive waits for them)
+    ps_arrive(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), lane);
+    if (active) {
+      const Vec4<float> a4 = {{acc[0], acc[1], acc[2], acc[3]}};
+      if (a.agg_out) store4(a.agg_out + drow * FP + c0, a4);
+      const Vec4<float> c3 = (RN_PS_PROBE & 4) ? a4 : ln_row<LG, PAD, float>(a4, k_c3, invn, nvalid);
+      f32x4 y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        y[k] = (RN_PS_PROBE & 4) ? old4[k] + c2v.v[k] + c3.v[k] : fast_tanh(old4[k] + c2v.v[k] + c3.v[k]);
+        if (poisoned) y[k] = __int_as_float(0x7fc00000);
+      }
+      if constexpr (PRE) {
+        char *pp = reinterpret_cast<char *>(a.edge_out + drow * FP + (c0 >> 3) * 8) + (c0 & 7) * 2;
+        f16x4 hh, ll;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hh[k] = (_Float16)y[k];
+          ll[k] = (_Float16)(y[k] - (float)hh[k]);
+        }
+        *reinterpret_cast<f16x4 *>(pp) = hh;
+        *reinterpret_cast<f16x4 *>(pp + 16) = ll;
+      } else {
+        *reinterpret_cast<f32x4 *>(a.edge_out + drow * FP + c0) = y;
+      }
+    }
+    PS_TICK(13);
+    r += 2;
+    while (r >= nrounds) {
+      r -= nrounds;
+      ++u;
+      ub = (ub + nrt * 16) & (PS_RING - 1);
+    }
   }
 }
 
@@ -741,8 +784,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 size_t edge_ps_lds_bytes(int rows, int in_rows) { return ps_lds(rows, in_rows).total; }
 
 // Runs the producers' schedule for one tile (first destination index and end row per destination, sorted by atom)
-// and checks what the kernel takes for granted: never more than PS_MAXNEW source tiles in one step, and the ring
-// never holds a tile that a round still in flight reads when its slot is rewritten.
+// and checks what the kernel takes for granted: never more than PS_MAXNEW source tiles in one step, and no ring slot is
+// rewritten while a round that may still be in flight (g - 2, g - 1 at the step of round g) reads the tile it holds.
 bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
   if (D <= 0) return true;
   const int nrounds = (D + PS_ND - 1) / PS_ND;
@@ -759,7 +802,7 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
     lo[r] = first_row == (1 << 30) ? (hi[r] + 1) : first_row / 16;
   }
   const int nrt = std::max(hi[nrounds - 1] + 1, 1);
-  const int units = 3;
+  const int units = 4;
   PsSched s;
   ps_sched_init(s, nrounds, nrt, units, hi[0]);
   PsStep st;
@@ -770,10 +813,10 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
       if (st.tile0 + st.ntiles > PS_NRT) return false;
       continue;
     }
-    // consumers may still be reading round g - 1: its first tile and everything after it must survive this step
-    int u1 = st.u, r1 = st.r - 1;
-    if (r1 < 0) { r1 = nrounds - 1; --u1; }
-    const int oldest = u1 >= 0 ? u1 * nrt + std::min(lo[r1], hi[r1] + 1) : 0;
+    // the two consumer sets may still be reading rounds g - 2 and g - 1 (the step waits for round g - 3 only): the first tile
+    // of round g - 2 and everything after it must survive this step
+    const int g1 = std::max(st.g - 2, 0), u1 = g1 / nrounds, r1 = g1 % nrounds;
+    const int oldest = u1 * nrt + std::min(lo[r1], hi[r1] + 1);
     if (st.tile0 + st.ntiles - oldest > PS_NRT) return false;
     if (st.u * nrt + hi[st.r] + 1 > st.tile0 + st.ntiles) return false;  // the round's own rows exist
   }

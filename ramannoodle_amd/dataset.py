@@ -72,28 +72,28 @@ class PolarizabilityDataset(Dataset):
 
     @property
     def atomic_numbers(self) -> list[int]:
-        return self._species.tolist()
+        return self._species.cpu().tolist()
 
     @property
     def positions(self) -> NDArray[np.float64]:
-        return self._positions.numpy().copy()
+        return self._positions.cpu().numpy().copy()
 
     @property
     def polarizabilities(self) -> NDArray[np.float64]:
-        return self._alpha.numpy().copy()
+        return self._alpha.cpu().numpy().copy()
 
     # ---- scaling
     @property
     def scaled_polarizabilities(self) -> NDArray[np.float64]:
-        return self._targets.numpy().copy()
+        return self._targets.cpu().numpy().copy()
 
     @property
     def mean_polarizability(self) -> NDArray[np.float64]:
-        return _population_stats(self._alpha)[0][0].numpy()
+        return _population_stats(self._alpha)[0][0].cpu().numpy()
 
     @property
     def stddev_polarizability(self) -> NDArray[np.float64]:
-        return _population_stats(self._alpha)[1][0].numpy()
+        return _population_stats(self._alpha)[1][0].cpu().numpy()
 
     def scale_polarizabilities(self, mean: NDArray[np.float64], stddev: NDArray[np.float64]) -> None:
         """Standardise the targets with the statistics of another (the training) set instead of
