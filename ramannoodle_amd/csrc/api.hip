@@ -1131,13 +1131,13 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
       HIP_TRY(hipMemcpy(&fail, h->ps_fail.p, sizeof(int), hipMemcpyDeviceToHost));
 #ifdef RN_PS_TIMING
       {
-        long long t[32];
+        long long t[40];
         HIP_TRY(hipMemcpy(t, (const char *)h->ps_fail.p + 64, sizeof(t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset((char *)h->ps_fail.p + 64, 0, sizeof(t)));
-        static const char *names[16] = {"P sched+dma_wait", "P loads+split", "P split sync", "P seeds", "P request", "P guard",
-                                        "P P'+c2", "P Q'", "P norm sync+publish", "", "C ready wait", "C prologue", "C loop",
-                                        "C epilogue+done", "", ""};
-        for (int i = 0; i < 16; ++i)
+        static const char *names[20] = {"P sched+dma_wait", "P loads+split", "P split sync", "P seeds", "P request", "P guard",
+                                        "P P'+c2", "P Q' (product, loads landed + finish)", "P norm sync+publish", "P ring guard", "C ready wait", "C prologue", "C loop",
+                                        "C epilogue+done", "", "", "C(set B) ready wait", "C(set B) prologue", "C(set B) loop", "C(set B) epilogue+done"};
+        for (int i = 0; i < 20; ++i)
           if (t[2 * i + 1]) fprintf(stderr, "[ps timing] %-22s %10.1f cycles x %lld\n", names[i], (double)t[2 * i] / (double)t[2 * i + 1], t[2 * i + 1]);
       }
 #endif
@@ -2156,7 +2156,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // per round.  A launch runs floor(CUs / tiles) frame groups side by side, so the cost of a partition is (rounds of its
     // slowest tile) / (frame groups); a partition is admissible when every tile passes the producers' schedule check and
     // the kernel's LDS footprint fits the CU.
-    int pt_max_rows = 0, pt_max_in = 0;
+    int pt_max_rows = 0, pt_max_in = 0, pt_back = 2;
     const bool want_ps = getenv("RN_POTGNN_EDGE_PS") ? atoi(getenv("RN_POTGNN_EDGE_PS")) != 0 : true;
     if (fused_mode && want_ps) {
       int cus = 256;
@@ -2171,7 +2171,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
         const int mr = build_tiles(budget, tb);
         const int ntiles = (int)tb.size() - 1;
         int max_in = 0, max_rounds = 1;
-        bool ok = true;
+        bool ok = true, ok3 = !(getenv("RN_POTGNN_PS_BACK") && atoi(getenv("RN_POTGNN_PS_BACK")) == 2);
         for (int t = 0; t < ntiles && ok; ++t) {
           const int eo0 = hp->out_ptr[tb[t]];
           rb.clear();
@@ -2184,16 +2184,19 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
           const int din = (int)rb.size();
           max_in = std::max(max_in, din);
           max_rounds = std::max(max_rounds, (din + 15) / 16);
-          ok = edge_ps_tile_ok(rb.data(), re.data(), din);
+          ok3 = ok3 && edge_ps_tile_ok(rb.data(), re.data(), din, 3);
+          ok = ok3 || edge_ps_tile_ok(rb.data(), re.data(), din, 2);
         }
         if (!ok || edge_ps_lds_bytes(mr, max_in) > (size_t)160 * 1024) continue;
         const double groups = ntiles <= cus ? (double)(cus / ntiles) : 1.0 / (double)((ntiles + cus - 1) / cus);
-        const double cost = (double)max_rounds / groups;
+        // (a partition whose ring lets the producers run three rounds ahead of the slower consumer set is worth ~7 %)
+        const double cost = (double)max_rounds / groups * (ok3 ? 1.0 : 1.07);
         if (hp->pt_begin.empty() || cost < best * 0.999) {
           best = cost;
           hp->pt_begin = tb;
           pt_max_rows = mr;
           pt_max_in = max_in;
+          pt_back = ok3 ? 3 : 2;
         }
         if (mr >= E) break;  // one tile holds everything: larger budgets change nothing
       }
@@ -2270,6 +2273,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.pt_begin = base + o_pt;
     g.pt_max_out_rows = pt_max_rows;
     g.pt_max_in_rows = pt_max_in;
+    g.pt_back = pt_back;
     g.bt_num = hp->bt_begin.empty() ? 0 : (int)hp->bt_begin.size() - 1;
     g.bt_begin = base + o_bt;
     g.bt_max_out_rows = bt_max_rows;

@@ -32,9 +32,10 @@
 //                     starts): a producer overwrites those buffers for round g + 2 after all four waves of the set did
 //   c_rd[g & 1]       consumer waves that FINISHED round g (no longer read the ring)
 // Q' lives in a RING of source-row tiles (PS_NRT x 16 rows): destinations are sorted by their atom and so are the
-// source rows, so round g needs a sliding window of rows.  The step of round g writes its new tiles once round g - 3
-// is finished, i.e. while rounds g - 2 and g - 1 may still be reading: the host checks, by running the same
-// schedule, that no tile those rounds read is overwritten then (edge_ps_tile_ok).
+// source rows, so round g needs a sliding window of rows.  The step of round g writes its new tiles once round
+// g - back - 1 is finished (back = Graph::pt_back: 3 when the ring has the room, else 2), i.e. while rounds g - back .. g - 1
+// may still be reading: the host checks, by running the same schedule, that no tile those rounds read is overwritten
+// then (edge_ps_tile_ok).
 //
 // No LayerNorm mean anywhere: c3_linear / c2_linear are centred over their output columns on the host
 // (api.hip: centred_ops), LN(x) = LN(x - mean x) and mean x is linear in the inputs, so the projections come out
@@ -76,25 +77,39 @@ struct EdgePsArgs {
 #define RN_PS_SLEEP 1  // s_sleep between two polls of a signalling word (0: poll back to back)
 #endif
 #ifndef RN_PS_PRIO
-#define RN_PS_PRIO 2   // s_setprio of the producer waves (consumers: 0 in the triplet loop)
+#define RN_PS_PRIO 3   // s_setprio of the producer waves (consumers: 0 / RN_PS_LPRIO in the triplet loop, RN_PS_CPRIO outside)
 #endif
 #ifndef RN_PS_CPRIO
-#define RN_PS_CPRIO 1  // s_setprio of a consumer wave outside its triplet loop (+0.6 %: profiles/r04/edge_ps_experiments.txt)
+#define RN_PS_CPRIO 2  // s_setprio of a consumer wave outside its triplet loop (+0.6 %: profiles/r04/edge_ps_experiments.txt)
 #endif
+#ifndef RN_PS_LPRIO
+#define RN_PS_LPRIO 1  // s_setprio of a consumer wave in the SECOND half of its triplet loop (first half: 0).  The two consumer
+#endif                 // waves of a SIMD work on consecutive rounds; at equal priority the arbiter serves the older wave slot
+                       // first, so one set ran ahead and then waited for its next round while the other ran alone at half
+                       // the issue rate.  The wave that is further into its round -- the one the producers' ring guard waits
+                       // for -- now goes first, and the sets leapfrog.
 #if RN_PS_TIMING
-#define PS_T0() long long _t = (long long)__builtin_readcyclecounter()
+// (accumulated in wave-uniform locals -- SGPRs -- and written once when the role's loop ends: a read-modify-write of global
+//  memory per phase made the producers wait for their own instrumentation, profiles/r05/edge_ps_experiments.txt)
+#define PS_T0() long long _t = (long long)__builtin_readcyclecounter(); ++tn
 #define PS_TICK(i)                                                                       \
   do {                                                                                   \
     const long long _n = (long long)__builtin_readcyclecounter();                        \
-    if (timed) {                                                                         \
-      tacc[2 * (i)] += _n - _t;                                                          \
-      tacc[2 * (i) + 1] += 1;                                                            \
-    }                                                                                    \
+    tl[(i) & 15] += (unsigned)(_n - _t);                                                 \
     _t = (long long)__builtin_readcyclecounter();                                        \
+  } while (0)
+#define PS_TFLUSH(first, last, shift)                                                    \
+  do {                                                                                   \
+    if (timed)                                                                           \
+      for (int _i = (first); _i <= (last); ++_i) {                                       \
+        tacc[2 * (_i + (shift))] += (long long)tl[_i & 15];                              \
+        tacc[2 * (_i + (shift)) + 1] += (long long)tn;                                   \
+      }                                                                                  \
   } while (0)
 #else
 #define PS_T0() do {} while (0)
 #define PS_TICK(i) do {} while (0)
+#define PS_TFLUSH(first, last, shift) do {} while (0)
 #endif
 
 namespace {
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   const int eo0 = g.out_ptr[j0], R = g.out_ptr[j1] - eo0;
   const int di0 = g.in_ptr[j0], D = g.in_ptr[j1] - di0;
   const int nrounds = (D + PS_ND - 1) / PS_ND;
+  const int back = g.pt_back;
 
   // ---- once per launch: LayerNorm parameters, the tile topology, the round -> source tile table
   for (int c = tid; c < 2 * FP; c += PS_THREADS) {
@@ -416,6 +432,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #if RN_PS_TIMING
     long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
     const bool timed = blockIdx.x == 0 && wave == 0 && lane == 0;
+    unsigned tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tn = 0;
 #endif
     for (unsigned k = 0; have; ++k) {
       PS_T0();
@@ -542,11 +559,14 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         }
         // (issued after this step's requests: everything of this wave has landed then -- the requests are ~2000 cycles old)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qS[0]), "+v"(qS[1]), "+v"(accQ[0]), "+v"(accQ[1])::"memory");
-        // ---- the ring: this step's tiles overwrite rows that rounds <= g - 3 read (edge_ps_tile_ok) -- round g - 3 must be done
-        // (rounds of the parity of g + 1; there are ((g - 3) >> 1) + 1 of them up to g - 3).  Behind the product: hidden under it.
-        if (cur.has_dest && cur.g >= 3)
-          ps_wait_ge(sync_a + (((cur.g + 1) & 1) ? C_RD1 : C_RD0), (unsigned)PS_CSET * (unsigned)(((cur.g - 3) >> 1) + 1), sync_a + C_READY,
-                     a.fail, 3);
+        PS_TICK(7);
+        // ---- the ring: this step's tiles overwrite rows that rounds <= g - back - 1 read (edge_ps_tile_ok) -- that round must
+        // be done.  Behind the product: hidden under it.
+        if (cur.has_dest && cur.g > back) {
+          const int gdone = cur.g - back - 1;  // (the rounds of its parity up to it: (gdone >> 1) + 1)
+          ps_wait_ge(sync_a + ((gdone & 1) ? C_RD1 : C_RD0), (unsigned)PS_CSET * (unsigned)((gdone >> 1) + 1), sync_a + C_READY, a.fail, 3);
+        }
+        PS_TICK(9);
         if (ntl > 0) q_tile_finish(accQ, g3v, ringrow0);
       }
       if (ntl > 1) {  // a second tile in one step is rare (once per unit): its node terms are fetched here, by ordinary loads
@@ -578,6 +598,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       have = have_next;
     }
     dma_wait();  // (the last step's re-fetch)
+    PS_TFLUSH(0, 9, 0);
     return;
   }
 
@@ -625,7 +646,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   bool poisoned = false;  // a bounded wait ran out in this workgroup: store NaN from here on
 #if RN_PS_TIMING
   long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
-  const bool timed = blockIdx.x == 0 && wave == PS_PROD && lane == 0;
+  const bool timed = blockIdx.x == 0 && (cw & 3) == 0 && lane == 0;  // one wave of either set
+  unsigned tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tn = 0;
 #endif
   for (unsigned gr = (unsigned)cset; u < nunits; gr += 2) {
     PS_T0();
@@ -732,6 +754,14 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         return ringc + __umul24(rs, (unsigned)LDQ);
       };
       int t = (RN_PS_PROBE & 1) ? cnt : 0;
+      const int tmid = RN_PS_LPRIO ? ((cnt >> 1) & ~1) : 0;
+      for (; t + 1 < tmid; t += 2) {
+        triplet(row_of(t), acc);
+        triplet(row_of(t + 1), acc2);
+      }
+#if RN_PS_LPRIO
+      __builtin_amdgcn_s_setprio(RN_PS_LPRIO);
+#endif
       for (; t + 1 < cnt; t += 2) {
         triplet(row_of(t), acc);
         triplet(row_of(t + 1), acc2);
@@ -778,6 +808,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       ub = (ub + nrt * 16) & (PS_RING - 1);
     }
   }
+  PS_TFLUSH(10, 13, cset ? 6 : 0);  // (set A: slots 10-13, set B: 16-19)
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -785,8 +816,10 @@ size_t edge_ps_lds_bytes(int rows, int in_rows) { return ps_lds(rows, in_rows).t
 
 // Runs the producers' schedule for one tile (first destination index and end row per destination, sorted by atom)
 // and checks what the kernel takes for granted: never more than PS_MAXNEW source tiles in one step, and no ring slot is
-// rewritten while a round that may still be in flight (g - 2, g - 1 at the step of round g) reads the tile it holds.
-bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
+// rewritten while a round that may still be in flight (g - back .. g - 1 at the step of round g) reads the tile it holds.
+// back = 2 is the least the two consumer sets need; back = 3 (Graph::pt_back, when the ring has the room) lets the producers
+// run one more round ahead of the slower set: 7.44 -> 6.91 ms per launch on the benchmark cell.
+bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back) {
   if (D <= 0) return true;
   const int nrounds = (D + PS_ND - 1) / PS_ND;
   std::vector<int> hi(nrounds), lo(nrounds);
@@ -802,7 +835,7 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
     lo[r] = first_row == (1 << 30) ? (hi[r] + 1) : first_row / 16;
   }
   const int nrt = std::max(hi[nrounds - 1] + 1, 1);
-  const int units = 4;
+  const int units = 3 + back;
   PsSched s;
   ps_sched_init(s, nrounds, nrt, units, hi[0]);
   PsStep st;
@@ -813,9 +846,9 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D) {
       if (st.tile0 + st.ntiles > PS_NRT) return false;
       continue;
     }
-    // the two consumer sets may still be reading rounds g - 2 and g - 1 (the step waits for round g - 3 only): the first tile
-    // of round g - 2 and everything after it must survive this step
-    const int g1 = std::max(st.g - 2, 0), u1 = g1 / nrounds, r1 = g1 % nrounds;
+    // the consumer sets may still be reading rounds g - back .. g - 1 (the step waits for round g - back - 1 only): the first
+    // tile of round g - back and everything after it must survive this step
+    const int g1 = std::max(st.g - back, 0), u1 = g1 / nrounds, r1 = g1 % nrounds;
     const int oldest = u1 * nrt + std::min(lo[r1], hi[r1] + 1);
     if (st.tile0 + st.ntiles - oldest > PS_NRT) return false;
     if (st.u * nrt + hi[st.r] + 1 > st.tile0 + st.ntiles) return false;  // the round's own rows exist
