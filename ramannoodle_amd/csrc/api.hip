@@ -123,6 +123,7 @@ struct Lane {
   hipEvent_t done = nullptr;
   DeviceBuf unit4, node[2], edge[2], npc1, np3, bufA, bufB;
   DeviceBuf c2;  // frame-pipelined EdgeBlock: the finished c2 embedding of every edge [S*E, FeP]
+  DeviceBuf fbA, fbB;  // a block of frames' c2 / c3 edge projections for a pass the fused pipeline hands to the unfused EdgeBlock
 };
 
 template <typename T>
@@ -956,7 +957,11 @@ struct ChunkRun {
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
 #endif
         else if (role_split(w)) launch_edge_ps(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->ps_fail.as<int>(), st(), pair_rows());
-        else if (fused()) launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
+#if RN_EXPERIMENTS
+        else if (fused() && getenv("RN_POTGNN_EDGE_FRAME") && atoi(getenv("RN_POTGNN_EDGE_FRAME")) != 0)  // the retired per-frame kernel
+          launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
+#endif
+        else if (fused()) edge_unfused_in_blocks(p);
         else launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
       } else {
         launch_edge_agg<T>(bufB, np3, bufA, edge[cur], edge[nxt], S, h->g, h->d, w, tape_agg(p), st());
@@ -964,6 +969,39 @@ struct ChunkRun {
     }
     cur = nxt;
     snapshot(p + 1);
+  }
+
+  // A pass of the FUSED pipeline that the role-specialised EdgeBlock does not serve (a graph its ring refuses, a pass
+  // without the folded gate scale, exact-f32 products, RN_POTGNN_EDGE_PS=0 / RN_POTGNN_TAPE_PS=0): the unfused EdgeBlock --
+  // the two per-edge projections + edge_agg_kernel, what the float64 instantiation always runs -- block of frames by block
+  // of frames, because the fused pipeline's lean workspace holds no per-edge projection buffers (6 FeP floats per edge).
+  // Through round 4 these passes took the per-frame fused kernel (now experiments/kernels_edge_frame.hip).
+  void edge_unfused_in_blocks(int p) {
+    const PassW<T> &w = prec<T>(h).pass[p];
+    const Graph &g = h->g;
+    const Dims d = h->d;
+    const int nxt = cur ^ 1;
+    const size_t per_frame = (size_t)g.E * (size_t)(6 * d.FeP) * sizeof(T);
+    const int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, ((size_t)1 << 30) / std::max<size_t>(per_frame, 1)));
+    ln->fbA.ensure((size_t)block * g.E * 2 * d.FeP * sizeof(T));
+    ln->fbB.ensure((size_t)block * g.E * 4 * d.FeP * sizeof(T));
+    T *fa = ln->fbA.template as<T>(), *fb = ln->fbB.template as<T>();
+    T *agg = tape_agg(p);
+    for (int s0 = 0; s0 < S; s0 += block) {
+      const int sb = std::min(block, S - s0);
+      const int64_t rows = (int64_t)sb * g.E;
+      const T *e_in = edge[cur] + (size_t)s0 * g.E * d.FeP, *nd = node[nxt] + (size_t)s0 * g.N * d.FnP;
+      auto project = [&](const T *X, int K, const T *WT, int NOUT, T *Y, const T *bias, int amode, const T *ndp) {
+        if constexpr (sizeof(T) == 4) {
+          if (h->mfma_f16 && h->split_projections && launch_rowgemm_split(X, K, K, rows, WT, NOUT, Y, false, bias, amode, ndp, g, st())) return;
+        }
+        launch_rowgemm<T>(X, rows, K, WT, NOUT, Y, nullptr, bias, false, amode, ndp, g, st());
+      };
+      project(e_in, d.FeP, w.c3_WeT, 4 * d.FeP, fb, nullptr, 0, nullptr);
+      project(nullptr, d.FnP, w.c2_WT, 2 * d.FeP, fa, w.c2_bias, 1, nd);
+      launch_edge_agg<T>(fb, np3 + (size_t)s0 * g.N * 6 * d.FeP, fa, e_in, edge[nxt] + (size_t)s0 * g.E * d.FeP, sb, g, d, w,
+                         agg ? agg + (size_t)s0 * g.E * d.FeP : nullptr, st());
+    }
   }
 
   // readout MLP (_gnn.py:532-539): bufA <- ssp(BN(L0 edge)), bufB <- ssp(L3 .), bufA <- L5 .

@@ -13,7 +13,7 @@ mkdir -p "$here/$bdir"
 pids=()
 # RN_EXTRA_FLAGS=-DRN_EXPERIMENTS=1 adds the opt-in round-3 experiment kernels (experiments/); the product build has none.
 hip_srcs="api kernels_agg kernels_gemm kernels_fused kernels_edge_ps kernels_node_atom kernels_narrow kernels_bwd kernels_train spectrum"
-case " ${RN_EXTRA_FLAGS:-} " in *" -DRN_EXPERIMENTS=1 "*) hip_srcs="$hip_srcs experiments/kernels_fused_experiments";; esac
+case " ${RN_EXTRA_FLAGS:-} " in *" -DRN_EXPERIMENTS=1 "*) hip_srcs="$hip_srcs experiments/kernels_fused_experiments experiments/kernels_edge_frame";; esac
 objs=()
 for f in $hip_srcs; do
   o="$here/$bdir/$(basename "$f").o"

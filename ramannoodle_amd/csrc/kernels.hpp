@@ -278,11 +278,6 @@ void launch_node_atom(const float *edge, const float *node_in, const float *npc1
                       Dims d, const PassW<float> &w, hipStream_t st, bool pair_rows = false);
 void launch_node_fused(const float *edge, const float *node_in, const float *npc1, float *node_out, int S,
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, bool centred, hipStream_t st);
-// `agg_out` (taped runs, else null): the pre-LayerNorm triplet sums per destination edge
-void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
-                       float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
-                       hipStream_t st);
-
 // Role-specialised fused EdgeBlock (kernels_edge_ps.hip): float32, FnP == FeP == 64, split-f16 products, folded gate
 // scale; needs the centred weight copies of PassW and np3 projected with c3_WnT_c / c3_nshift_c.
 size_t edge_ps_lds_bytes(int tile_out_rows, int tile_in_rows);
@@ -299,6 +294,12 @@ void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, co
 #define RN_EXPERIMENTS 0
 #endif
 #if RN_EXPERIMENTS
+// Per-frame fused EdgeBlock (edge_block_fused_kernel, retired from the product build in round 5: experiments/kernels_edge_frame.hip)
+size_t edge_fused_lds_bytes(const Graph &g);
+// `agg_out` (taped runs, else null): the pre-LayerNorm triplet sums per destination edge
+void launch_edge_fused(const float *edge_in, float *edge_out, const float *node, const float *np3,
+                       float *agg_out, int S, const Graph &g, Dims d, const PassW<float> &w, bool f16,
+                       hipStream_t st);
 // Twelve-wave EdgeBlock (edge_block3_kernel + edge_c2_kernel): ONE 768-thread workgroup per CU with the CU's LDS.
 #ifndef RN_E3_WAVES
 #define RN_E3_WAVES 12

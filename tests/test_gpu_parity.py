@@ -512,9 +512,9 @@ def test_fused_edge_block_equals_unfused(monkeypatch):
 def test_repeated_evaluation_is_bit_identical(monkeypatch, edge_ps):
     """No kernel uses atomics: evaluating the same frames again must give the same bits, whichever
     workgroup a frame lands in.  Perf and parity widths; with the role-specialised EdgeBlock (the default, split
-    products on the K = 32 f16 MFMA like every other kernel) and with the per-frame EdgeBlock kernel
-    (``RN_POTGNN_EDGE_PS=0``), the one kernel that is NOT reproducible on the K = 32 instruction and therefore keeps
-    the two-instruction K = 16 form (``device_utils.hpp``; profiles/r02-r04)."""
+    products on the K = 32 f16 MFMA like every other kernel) and with ``RN_POTGNN_EDGE_PS=0``, which since round 5 hands
+    the EdgeBlock of the fused pipeline to the unfused chain (the per-frame fused kernel that was NOT reproducible on the
+    K = 32 instruction is retired from the product build: ``csrc/experiments/kernels_edge_frame.hip``)."""
     from bench import make_workload
     monkeypatch.setenv("RN_POTGNN_EDGE_PS", edge_ps)
     for hparams, frames in (("perf", 3000), ("parity", 3000)):
@@ -1344,8 +1344,9 @@ def test_bench_starts_its_own_ranks():
 ])
 def test_role_split_edge_block_against_oracle_and_per_frame_kernel(monkeypatch, case, cutoff, fn, fe, passes, frames):
     """The role-specialised fused EdgeBlock (producer + consumer waves, ``csrc/kernels_edge_ps.hip``) is what a 64-wide
-    float32 evaluation runs on; it agrees with the pinned oracle and with the per-frame kernel it replaces
-    (``RN_POTGNN_EDGE_PS=0``), and repeats bit for bit."""
+    float32 evaluation runs on; it agrees with the pinned oracle and with what serves the passes it does not take
+    (``RN_POTGNN_EDGE_PS=0``: the unfused EdgeBlock inside the fused pipeline, which replaced the retired per-frame
+    kernel in round 5), and repeats bit for bit."""
     from oracle import potgnn_oracle as O
     g = load_golden(case)
     rng = np.random.default_rng(5)
