@@ -19,7 +19,16 @@
  *     keeps its ordering guarantees per handle.  rn_potgnn_last_error() returns a pointer into the
  *     handle: read it before the next call on that handle from another thread.  The reference's
  *     PolarizabilityModel is single-threaded and synchronous (abstract.py:10-29).
+ *     The small getters / setters (config_flags, kernel_times, set_profiling, train_row_count, set_stat_reducer) and the
+ *     argument checks that read handle state take the same lock.
  *   - no C++ exception crosses this boundary: every failure is a negative rn_status.
+ *   - rn_potgnn_forward* / rn_potgnn_train_forward* evaluate in float32 (the *_f64 entries in float64).  A training
+ *     forward's tape lives in the handle's workspace until its backward: an evaluation, Jacobian or another training forward
+ *     on the same handle in between voids it, and the backward then fails with RN_ERR_INVALID_ARGUMENT.
+ *   - the role-specialised EdgeBlock bounds its internal spin waits; a wait that runs out is reported as a launch failure
+ *     by the first entry point that synchronises (evaluation with synchronize != 0, rn_potgnn_wait, the training entries,
+ *     the Jacobian, rn_potgnn_adam_step), and the rows the affected workgroup stored are NaN, so an entry point that does
+ *     not synchronise never hands back plausible numbers from such a launch.
  *   - "host" entry points take host buffers and include PCIe transfers;
  *     "device" entry points take device (HBM) pointers and a hipStream_t (as void*).
  */

@@ -153,7 +153,7 @@ struct TimedLaunch {
 }  // namespace
 
 struct rn_potgnn {
-  std::recursive_mutex lock;  // serialises the calls on this handle (guarded())
+  mutable std::recursive_mutex lock;  // serialises the calls on this handle (guarded(), the small getters / setters, set_error)
   rn_potgnn_config cfg{};
   Dims d{};
   int chunk = 1;
@@ -232,8 +232,12 @@ void set_error(rn_potgnn *h, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (h) h->error = buf;
-  else g_create_error = buf;
+  if (h) {  // (entry points report argument errors before they enter guarded(): the error text is handle state too)
+    std::lock_guard<std::recursive_mutex> hold(h->lock);
+    h->error = buf;
+  } else {
+    g_create_error = buf;
+  }
 }
 
 // ----------------------------------------------------------------------------- packing
@@ -1116,6 +1120,41 @@ void run_pair(rn_potgnn *h, ChunkRun<T> &a, ChunkRun<T> &b) {
   b.finish();
 }
 
+// The role-specialised EdgeBlock bounds its spin waits: a wait that runs out sets a word in HBM (and poisons the rows the
+// workgroup stores from then on with NaN) instead of hanging the GPU.  Every entry point that synchronises with the device
+// anyway looks at the word here, right after its synchronisation -- evaluation, the pipelined host entry's rn_potgnn_wait,
+// the taped forward / backward of a training step, the Jacobian, the Adam step -- and clears it, so a timeout is reported by
+// the call it happened in (or the first synchronising call behind it), never by an unrelated later one.  Entry points that do
+// not synchronise (device buffers with synchronize = 0) hand back NaN rows in that case.
+void check_ps_fail(rn_potgnn *h) {
+  if (!h->use_ps || !h->ps_fail.p) return;
+  int fail = 0;
+  HIP_TRY(hipMemcpy(&fail, h->ps_fail.p, sizeof(int), hipMemcpyDeviceToHost));
+#ifdef RN_PS_TIMING
+  {
+    long long t[40];
+    HIP_TRY(hipMemcpy(t, (const char *)h->ps_fail.p + 64, sizeof(t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char *)h->ps_fail.p + 64, 0, sizeof(t)));
+    static const char *names[20] = {"P sched+dma_wait", "P loads+split", "P split sync", "P seeds", "P request", "P guard",
+                                    "P P'+c2", "P Q' (product, loads landed + finish)", "P norm sync+publish", "P ring guard", "C ready wait", "C prologue", "C loop",
+                                    "C epilogue+done", "", "", "C(set B) ready wait", "C(set B) prologue", "C(set B) loop", "C(set B) epilogue+done"};
+    for (int i = 0; i < 20; ++i)
+      if (t[2 * i + 1]) fprintf(stderr, "[ps timing] %-22s %10.1f cycles x %lld\n", names[i], (double)t[2 * i] / (double)t[2 * i + 1], t[2 * i + 1]);
+  }
+#endif
+  if (fail == 0) return;
+  HIP_TRY(hipMemset(h->ps_fail.p, 0, sizeof(int)));
+  // (which wait: 1 = the producers' split sync, 2 = a producer waiting for round g - 2's P' / c2 rows to be taken,
+  //  3 = a producer waiting for round g - back - 1 to be finished, 4 = a consumer waiting for its round)
+  static const char *const which[5] = {
+      "role-specialised EdgeBlock: a wait between producer and consumer waves timed out",
+      "role-specialised EdgeBlock: the producers' split sync timed out",
+      "role-specialised EdgeBlock: a producer's wait for the consumers to take the rows of an earlier round timed out",
+      "role-specialised EdgeBlock: a producer's wait for the consumers to finish an earlier round (ring rows) timed out",
+      "role-specialised EdgeBlock: a consumer's wait for its round timed out"};
+  throw HipError{hipErrorLaunchFailure, which[fail >= 0 && fail <= 4 ? fail : 0]};
+}
+
 template <typename T>
 void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alpha, float *d_vec6,
                     double *d_alpha_raw, hipStream_t user, bool sync, const T *d_lat = nullptr,
@@ -1164,34 +1203,7 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
   if (sync) {
     HIP_TRY(hipStreamSynchronize(user));
     resolve_timers(h);
-    if (h->use_ps) {  // the role-specialised EdgeBlock bounds its spin waits and reports here instead of hanging the GPU
-      int fail = 0;
-      HIP_TRY(hipMemcpy(&fail, h->ps_fail.p, sizeof(int), hipMemcpyDeviceToHost));
-#ifdef RN_PS_TIMING
-      {
-        long long t[40];
-        HIP_TRY(hipMemcpy(t, (const char *)h->ps_fail.p + 64, sizeof(t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset((char *)h->ps_fail.p + 64, 0, sizeof(t)));
-        static const char *names[20] = {"P sched+dma_wait", "P loads+split", "P split sync", "P seeds", "P request", "P guard",
-                                        "P P'+c2", "P Q' (product, loads landed + finish)", "P norm sync+publish", "P ring guard", "C ready wait", "C prologue", "C loop",
-                                        "C epilogue+done", "", "", "C(set B) ready wait", "C(set B) prologue", "C(set B) loop", "C(set B) epilogue+done"};
-        for (int i = 0; i < 20; ++i)
-          if (t[2 * i + 1]) fprintf(stderr, "[ps timing] %-22s %10.1f cycles x %lld\n", names[i], (double)t[2 * i] / (double)t[2 * i + 1], t[2 * i + 1]);
-      }
-#endif
-      if (fail != 0) {
-        HIP_TRY(hipMemset(h->ps_fail.p, 0, sizeof(int)));
-        // (which wait: 1 = the producers' split sync, 2 = a producer waiting for round g - 2's P' / c2 rows to be taken,
-        //  3 = a producer waiting for round g - 3 to be finished, 4 = a consumer waiting for its round)
-        static const char *const which[5] = {
-            "role-specialised EdgeBlock: a wait between producer and consumer waves timed out",
-            "role-specialised EdgeBlock: the producers' split sync timed out",
-            "role-specialised EdgeBlock: a producer's wait for the consumers to take the rows of an earlier round timed out",
-            "role-specialised EdgeBlock: a producer's wait for the consumers to finish an earlier round (ring rows) timed out",
-            "role-specialised EdgeBlock: a consumer's wait for its round timed out"};
-        throw HipError{hipErrorLaunchFailure, which[fail >= 0 && fail <= 4 ? fail : 0]};
-      }
-    }
+    check_ps_fail(h);
   }
 }
 
@@ -1433,6 +1445,7 @@ void jacobian(rn_potgnn *h, const double *host_pos, double *host_jac /*[6][N*3]*
   Reverse<T> rv{1, 6, seeds.as<T>(), dposbuf.as<double>(), nullptr, false};
   reverse_pass<T>(h, c, rv);
   HIP_TRY(hipStreamSynchronize(st));
+  check_ps_fail(h);
   HIP_TRY(hipMemcpy(host_jac, dposbuf.p, (size_t)6 * N * 3 * sizeof(double), hipMemcpyDeviceToHost));
   (void)P;
 }
@@ -1593,6 +1606,7 @@ void train_forward(rn_potgnn *h, const double *host_pos, int S, T *vec6, T *batc
   hipStream_t st = c.st();
   DeviceBuf &mv = P.mv;
   HIP_TRY(hipStreamSynchronize(st));
+  check_ps_fail(h);
   if constexpr (sizeof(T) == 4) {
     HIP_TRY(hipMemcpy(vec6, h->io_vec6.p, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToHost));
   } else {  // (xx,yy,zz,xy,xz,yz) of the standardised tensor, at full precision
@@ -1672,6 +1686,7 @@ void train_backward(rn_potgnn *h, const T *dvec6, T *grads /* null: leave the gr
   Reverse<T> rv{S, 1, seeds.template as<T>(), nullptr, P.grad.template as<T>(), true};
   reverse_pass<T>(h, c, rv);
   HIP_TRY(hipStreamSynchronize(st));
+  check_ps_fail(h);
   h->train_S = 0;
   if (sizeof(T) == 4) h->grads_on_device = true;
   if (!grads) return;
@@ -2514,6 +2529,7 @@ int rn_potgnn_wait(rn_potgnn *h) {
         sl.busy = false;
       }
     resolve_timers(h);
+    check_ps_fail(h);
   });
 }
 
@@ -2710,6 +2726,7 @@ int rn_potgnn_train_forward(rn_potgnn *h, const double *positions, int64_t S, fl
     set_error(h, "invalid arguments to train_forward");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (S > h->chunk) {
     set_error(h, "training batch of %lld frames exceeds max_chunk_structures = %d", (long long)S,
               h->chunk);
@@ -2736,6 +2753,7 @@ int rn_potgnn_train_forward_samples(rn_potgnn *h, const double *lattices, const 
     set_error(h, "invalid arguments to train_forward_samples");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (S > h->chunk) {
     set_error(h, "training batch of %lld frames exceeds max_chunk_structures = %d", (long long)S, h->chunk);
     return RN_ERR_INVALID_ARGUMENT;
@@ -2751,6 +2769,7 @@ int rn_potgnn_train_forward_samples_f64(rn_potgnn *h, const double *lattices, co
     set_error(h, "invalid arguments to train_forward_samples_f64");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (S > chunk_frames<double>(h)) {
     set_error(h, "training batch of %lld frames exceeds the float64 chunk of %d frames", (long long)S, chunk_frames<double>(h));
     return RN_ERR_INVALID_ARGUMENT;
@@ -2768,6 +2787,7 @@ int rn_potgnn_train_forward_samples_device(rn_potgnn *h, const float *d_lattices
     set_error(h, "invalid arguments to train_forward_samples_device");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (!h->device_training) {
     set_error(h, "train_forward_samples_device needs device-resident training (rn_potgnn_set_device_training)");
     return RN_ERR_INVALID_ARGUMENT;
@@ -2784,6 +2804,7 @@ int rn_potgnn_train_backward_samples_device(rn_potgnn *h, const float *d_dvec6, 
     set_error(h, "invalid arguments to train_backward_samples_device");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (!h->device_training || h->train_S <= 0 || h->train_prec != 4) {
     set_error(h, "train_backward_samples_device needs device-resident training and a preceding float32 train_forward");
     return RN_ERR_INVALID_ARGUMENT;
@@ -2811,6 +2832,7 @@ int rn_potgnn_train_forward_f64(rn_potgnn *h, const double *positions, int64_t S
     set_error(h, "invalid arguments to train_forward_f64");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (S > chunk_frames<double>(h)) {
     set_error(h, "training batch of %lld frames exceeds the float64 chunk of %d frames", (long long)S,
               chunk_frames<double>(h));
@@ -2827,6 +2849,7 @@ int rn_potgnn_train_backward_f64(rn_potgnn *h, const double *dvec6, double *grad
     set_error(h, "invalid arguments to train_backward_f64");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (h->train_S <= 0 || h->train_prec != 8) {
     set_error(h, "train_backward_f64 needs a preceding train_forward_f64");
     return RN_ERR_INVALID_ARGUMENT;
@@ -2836,6 +2859,7 @@ int rn_potgnn_train_backward_f64(rn_potgnn *h, const double *dvec6, double *grad
 
 int rn_potgnn_set_device_training(rn_potgnn *h, int enabled) {
   if (!h) return RN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   h->device_training = enabled != 0;
   return RN_OK;
 }
@@ -2845,6 +2869,7 @@ int rn_potgnn_train_backward_device(rn_potgnn *h, const float *dvec6) {
     set_error(h, "invalid arguments to train_backward_device");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (h->train_S <= 0 || h->train_prec != 4) {
     set_error(h, "train_backward_device needs a preceding train_forward (an evaluation or Jacobian call "
                  "in between discards its tape)");
@@ -2869,6 +2894,7 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
     set_error(h, "invalid arguments to adam_step");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (!h->grads_on_device) {
     set_error(h, "adam_step needs the gradients of a preceding train_backward_device");
     return RN_ERR_INVALID_ARGUMENT;
@@ -2933,6 +2959,7 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
         std::memcpy(h->packed.data() + seg[i], h->step_host + seg[i + 1], (size_t)seg[i + 2] * sizeof(float));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    check_ps_fail(h);  // (the taped forward of this step ran the role-specialised EdgeBlock and nothing has looked since)
     h->host_stale = true;
     refresh_pass_flags<float>(h);
     refresh_mfma_mode(h);
@@ -2953,18 +2980,24 @@ int rn_potgnn_get_weights(rn_potgnn *h, float *weights, size_t num_weights) {
 
 int rn_potgnn_set_stat_reducer(rn_potgnn *h, rn_potgnn_reduce_fn fn, void *ctx) {
   if (!h) return RN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);
   h->reducer = fn;
   h->reducer_ctx = ctx;
   return RN_OK;
 }
 
-double rn_potgnn_train_row_count(const rn_potgnn *h) { return h ? h->bn_count : 0.0; }
+double rn_potgnn_train_row_count(const rn_potgnn *h) {
+  if (!h) return 0.0;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);
+  return h->bn_count;
+}
 
 int rn_potgnn_train_backward(rn_potgnn *h, const float *dvec6, float *grads) {
   if (!h || !dvec6 || !grads) {
     set_error(h, "invalid arguments to train_backward");
     return RN_ERR_INVALID_ARGUMENT;
   }
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (h->train_S <= 0 || h->train_prec != 4) {
     set_error(h, "train_backward needs a preceding train_forward (an evaluation or Jacobian call in "
                  "between discards its tape)");
@@ -3003,6 +3036,7 @@ int rn_potgnn_radius_graph(const double *lattice, const double *positions, int32
 
 int rn_potgnn_config_flags(const rn_potgnn *h) {
   if (!h) return -1;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the pass flags are rewritten when weights change)
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
               ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0) | (h->use_edge3 ? 64 : 0) | (RN_EXPERIMENTS ? 128 : 0);
   {  // bit 8: every pass of a float32 evaluation takes the role-specialised EdgeBlock (kernels_edge_ps.hip)
@@ -3045,6 +3079,7 @@ int rn_potgnn_debug_triplets(rn_potgnn *h, int32_t *idx_i, int32_t *idx_j, int32
 int rn_potgnn_debug_stage(rn_potgnn *h, int stage, int index, float *out, size_t out_capacity,
                           int64_t *rows, int64_t *cols) {
   if (!h || !out || !rows || !cols) return RN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);  // (the checks below read handle state)
   if (h->last_was_f64) {
     set_error(h, "debug_stage only reads the float32 path");
     return RN_ERR_UNSUPPORTED;
@@ -3080,6 +3115,7 @@ int rn_potgnn_debug_stage(rn_potgnn *h, int stage, int index, float *out, size_t
 
 int rn_potgnn_set_profiling(rn_potgnn *h, int enabled) {
   if (!h) return RN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);
   resolve_timers(h);
   h->profiling = enabled;
   for (int k = 0; k < K_COUNT; ++k) {
@@ -3092,6 +3128,7 @@ int rn_potgnn_set_profiling(rn_potgnn *h, int enabled) {
 int rn_potgnn_kernel_times(rn_potgnn *h, const char **names, double *millis, int64_t *launches,
                            int cap) {
   if (!h || !names || !millis || !launches) return RN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> hold(h->lock);
   (void)hipSetDevice(h->cfg.device);
   resolve_timers(h);
   int n = 0;

@@ -21,7 +21,10 @@ for f in $hip_srcs; do
   if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/fused_common.hpp" -nt "$o" ] || \
      [ "$here/kernels.hpp" -nt "$o" ] || [ "$here/device_utils.hpp" -nt "$o" ] || \
      [ "$here/../../include/rn_potgnn.h" -nt "$o" ]; then
-    $HIPCC $FLAGS -c "$here/$f.hip" -o "$o" &
+    extra=""
+    # (the two kernels with hand-counted vmcnt waits keep their assembly listing for tools/check_ps_isa.py, below)
+    case "$f" in kernels_edge_ps|kernels_node_atom) extra="-save-temps=obj";; esac
+    $HIPCC $FLAGS $extra -c "$here/$f.hip" -o "$o" &
     pids+=($!)
   fi
 done
@@ -34,5 +37,14 @@ for f in ingest ingest_vasprun; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+# The hand-counted `s_waitcnt vmcnt(N)` of kernels_edge_ps.hip / kernels_node_atom.hip are right only for the instruction stream
+# this compiler emitted: check it, and fail the build on a violation (probe builds switch requests off on purpose: skipped).
+case " ${RN_EXTRA_FLAGS:-} " in
+  *RN_PS_PROBE*|*RN_NA_PROBE*) ;;
+  *) python3 "$here/../../tools/check_ps_isa.py" "$here/$bdir/kernels_edge_ps-hip-amdgcn-amd-amdhsa-gfx950.s" \
+       "$here/$bdir/kernels_node_atom-hip-amdgcn-amd-amdhsa-gfx950.s" | tail -n 1
+     [ "${PIPESTATUS[0]}" -eq 0 ] || { echo "build.sh: tools/check_ps_isa.py found violations (run it for the list)"; exit 1; } ;;
+esac
+rm -f "$here/$bdir"/*.hipi "$here/$bdir"/*.bc "$here/$bdir"/*.out "$here/$bdir"/*.resolution.txt "$here/$bdir"/*-host-*.s "$here/$bdir"/*.hipfb
 $HIPCC -shared -fPIC --offload-arch=gfx950 -o "$out" "${objs[@]}" "$here/$bdir/ingest.o" "$here/$bdir/ingest_vasprun.o" -lpthread -ldl
 echo "built $out"

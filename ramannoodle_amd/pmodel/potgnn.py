@@ -443,6 +443,15 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         topology is the reference structure's.  An atomic number the model has no atom type for raises
         ``IndexError``, as the reference's ``Embedding`` does.
 
+        Arithmetic: ``forward`` evaluates in float32 and returns a float32 tensor whatever ``torch.get_default_dtype()`` is
+        (evaluation and training mode, host and CUDA tensors alike) -- the reference computes in the dtype of its parameters,
+        float32 unless the caller changed torch's default before constructing the model.  The float64 instantiation of the
+        kernels is reached through ``calc_polarizabilities(..., dtype=torch.float64)`` (which follows the default dtype when
+        ``dtype`` is ``None``, ``_gnn.py:705-710``), ``calc_polarizabilities_device`` and ``train_gradients_f64``.
+        An evaluation-mode ``forward`` (or any other evaluation) between a training-mode ``forward`` and its ``backward()``
+        reuses the device workspace the pending step's tape refers to: run ``backward()`` first -- the backward of a step
+        whose tape was overwritten raises ``ValueError`` ("needs a preceding train_forward").
+
         The result lives where the inputs live, as the reference's does (``_train.py:51-75`` moves a batch to the
         device and takes the loss there; ``test/tests/torch/test_gnn.py:130-160``): CUDA tensors are evaluated in
         place in HBM (``rn_potgnn_forward_samples_device``: no copy through the host) and a CUDA tensor comes back;

@@ -1701,3 +1701,23 @@ def test_train_single_epoch_under_cuda_default_device(cuda_default_device, optim
             np.testing.assert_allclose(got_sd[k], v, rtol=1e-4, atol=2e-6, err_msg=k)
         else:
             np.testing.assert_allclose(got_sd[k], v, rtol=0, atol=6.5 * lr, err_msg=k)
+
+
+def test_eight_message_passes_on_the_default_path_against_the_float64_oracle():
+    """The default float32 path keeps the edge embedding between passes as split-f16 pair rows (22 significant bits): the
+    rounding accumulates per pass, and the fixtures stop at four passes.  Eight passes (``_gnn.py:648-650`` runs the
+    blocks ``num_message_passes`` times) on the 64-atom cell at the perf widths against the oracle in float64: the
+    standardised polarizability stays within 1e-5 of it, and so does the same evaluation on plain float32 rows."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("rocksalt64_perf")
+    rng = np.random.default_rng(17)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=6)] + rng.normal(scale=2e-3, size=(6,) + base.shape[1:])
+    model, oracle = _random_model(g, 3.2, 64, 64, 8, seed=88)
+    got = model.calc_polarizabilities(pos)
+    flags = model.config_flags()
+    assert flags["role_split_edge_block"] and flags["atom_owning_node_block"] and flags["split_f16_pair_rows"]
+    want = O.calc_polarizabilities(oracle.to(torch.float64), pos, faithful=False)
+    std_got, std_want = (got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std
+    assert _rel_err(std_got, std_want) < REL, _rel_err(std_got, std_want)
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos), got)
