@@ -152,7 +152,7 @@ CONFIGS = {
     3: dict(cells=(4, 4, 2), frames=10_000, seed=33, scaling="strong"),
     2: dict(cells=(4, 2, 2), frames=1_000, seed=22, scaling="weak"),
 }
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
 
 
 def algorithmic_bytes_edge_block(n, e, fn, fe):
