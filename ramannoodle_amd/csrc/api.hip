@@ -1142,6 +1142,20 @@ void check_ps_fail(rn_potgnn *h) {
       if (t[2 * i + 1]) fprintf(stderr, "[ps timing] %-22s %10.1f cycles x %lld\n", names[i], (double)t[2 * i] / (double)t[2 * i + 1], t[2 * i + 1]);
   }
 #endif
+#ifdef RN_PS_GRAM_DEBUG
+  {
+    int cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, (const char *)h->ps_fail.p + 127 * 4, sizeof(int), hipMemcpyDeviceToHost));
+    float dbg[144];
+    HIP_TRY(hipMemcpy(dbg, (const char *)h->ps_fail.p + 128 * 4, sizeof(dbg), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[gram debug] %d mismatches\n", cnt);
+    for (int k = 0; k < std::min(cnt, 12); ++k)
+      fprintf(stderr, "  ref %g tab %g parts %g %g %g %g  d %g er %g tl %g urow %g r %g gr %g\n", dbg[12 * k], dbg[12 * k + 1], dbg[12 * k + 2],
+              dbg[12 * k + 3], dbg[12 * k + 4], dbg[12 * k + 5], dbg[12 * k + 6], dbg[12 * k + 7], dbg[12 * k + 8], dbg[12 * k + 9],
+              dbg[12 * k + 10], dbg[12 * k + 11]);
+    HIP_TRY(hipMemset((char *)h->ps_fail.p + 127 * 4, 0, 4 + sizeof(dbg)));
+  }
+#endif
   if (fail == 0) return;
   HIP_TRY(hipMemset(h->ps_fail.p, 0, sizeof(int)));
   // (which wait: 1 = the producers' split sync, 2 = a producer waiting for round g - 2's P' / c2 rows to be taken,
@@ -2209,7 +2223,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     // per round.  A launch runs floor(CUs / tiles) frame groups side by side, so the cost of a partition is (rounds of its
     // slowest tile) / (frame groups); a partition is admissible when every tile passes the producers' schedule check and
     // the kernel's LDS footprint fits the CU.
-    int pt_max_rows = 0, pt_max_in = 0, pt_back = 2;
+    int pt_max_rows = 0, pt_max_in = 0, pt_back = 2, pt_gram = 0;
     const bool want_ps = getenv("RN_POTGNN_EDGE_PS") ? atoi(getenv("RN_POTGNN_EDGE_PS")) != 0 : true;
     if (fused_mode && want_ps) {
       int cus = 256;
@@ -2220,36 +2234,52 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       double best = 0;
       std::vector<int> tb, rb, re;
       const int forced = getenv("RN_POTGNN_PS_TILE_ROWS") ? atoi(getenv("RN_POTGNN_PS_TILE_ROWS")) : 0;  // experiment knob
+      const bool want_back3 = !(getenv("RN_POTGNN_PS_BACK") && atoi(getenv("RN_POTGNN_PS_BACK")) == 2);
+      // GRAM is opt-in (RN_POTGNN_PS_GRAM=1): parity-green, but the producers' Gram phase costs them more than the consumers' loop
+      // gains while the producers are the slower role with it (profiles/r05/edge_ps_experiments.txt: 7.38 against 7.01 ms per launch)
+      const bool want_gram = getenv("RN_POTGNN_PS_GRAM") && atoi(getenv("RN_POTGNN_PS_GRAM")) != 0;
+      // One variant of the kernel for a partition: {gram, back}.  GRAM (the LayerNorm cross terms on the matrix pipe) has a ring
+      // of 7 tiles and needs every round's window to span <= 3 of them, every destination <= 32 source rows, and its tables
+      // inside the CU's LDS; back = 3 (the producers three rounds ahead of the slower consumer set) needs the room in the ring.
+      struct Variant { bool gram; int back; double factor; };
+      const Variant variants[4] = {{true, 3, 0.88}, {true, 2, 0.94}, {false, 3, 1.0}, {false, 2, 1.07}};
       for (size_t budget = forced > 0 ? forced : 8; budget <= (size_t)(forced > 0 ? forced : 1024); budget += 2) {
         const int mr = build_tiles(budget, tb);
         const int ntiles = (int)tb.size() - 1;
-        int max_in = 0, max_rounds = 1;
-        bool ok = true, ok3 = !(getenv("RN_POTGNN_PS_BACK") && atoi(getenv("RN_POTGNN_PS_BACK")) == 2);
-        for (int t = 0; t < ntiles && ok; ++t) {
-          const int eo0 = hp->out_ptr[tb[t]];
-          rb.clear();
-          re.clear();
-          for (int i = hp->in_ptr[tb[t]]; i < hp->in_ptr[tb[t + 1]]; ++i) {
-            const int bd = edge_b[hp->in_edge[i]];
-            rb.push_back(hp->out_ptr[bd] - eo0);
-            re.push_back(hp->out_ptr[bd + 1] - eo0);
+        for (const Variant &v : variants) {
+          if ((v.gram && !want_gram) || (v.back == 3 && !want_back3)) continue;
+          int max_in = 0, max_rounds = 1;
+          bool ok = true;
+          for (int t = 0; t < ntiles && ok; ++t) {
+            const int eo0 = hp->out_ptr[tb[t]];
+            rb.clear();
+            re.clear();
+            int longest = 0;
+            for (int i = hp->in_ptr[tb[t]]; i < hp->in_ptr[tb[t + 1]]; ++i) {
+              const int bd = edge_b[hp->in_edge[i]];
+              rb.push_back(hp->out_ptr[bd] - eo0);
+              re.push_back(hp->out_ptr[bd + 1] - eo0);
+              longest = std::max(longest, re.back() - rb.back());
+            }
+            const int din = (int)rb.size();
+            max_in = std::max(max_in, din);
+            max_rounds = std::max(max_rounds, (din + 15) / 16);
+            int window = 0;
+            ok = edge_ps_tile_ok(rb.data(), re.data(), din, v.back, edge_ps_ring_tiles(v.gram), &window);
+            if (v.gram) ok = ok && window <= edge_ps_gram_window() && longest <= 32;
           }
-          const int din = (int)rb.size();
-          max_in = std::max(max_in, din);
-          max_rounds = std::max(max_rounds, (din + 15) / 16);
-          ok3 = ok3 && edge_ps_tile_ok(rb.data(), re.data(), din, 3);
-          ok = ok3 || edge_ps_tile_ok(rb.data(), re.data(), din, 2);
-        }
-        if (!ok || edge_ps_lds_bytes(mr, max_in) > (size_t)160 * 1024) continue;
-        const double groups = ntiles <= cus ? (double)(cus / ntiles) : 1.0 / (double)((ntiles + cus - 1) / cus);
-        // (a partition whose ring lets the producers run three rounds ahead of the slower consumer set is worth ~7 %)
-        const double cost = (double)max_rounds / groups * (ok3 ? 1.0 : 1.07);
-        if (hp->pt_begin.empty() || cost < best * 0.999) {
-          best = cost;
-          hp->pt_begin = tb;
-          pt_max_rows = mr;
-          pt_max_in = max_in;
-          pt_back = ok3 ? 3 : 2;
+          if (!ok || edge_ps_lds_bytes(mr, max_in, v.gram) > (size_t)160 * 1024) continue;
+          const double groups = ntiles <= cus ? (double)(cus / ntiles) : 1.0 / (double)((ntiles + cus - 1) / cus);
+          const double cost = (double)max_rounds / groups * v.factor;
+          if (hp->pt_begin.empty() || cost < best * 0.999) {
+            best = cost;
+            hp->pt_begin = tb;
+            pt_max_rows = mr;
+            pt_max_in = max_in;
+            pt_back = v.back;
+            pt_gram = v.gram ? 1 : 0;
+          }
+          break;  // (the variants are ordered by their factor: the first admissible one is this partition's)
         }
         if (mr >= E) break;  // one tile holds everything: larger budgets change nothing
       }
@@ -2327,6 +2357,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.pt_max_out_rows = pt_max_rows;
     g.pt_max_in_rows = pt_max_in;
     g.pt_back = pt_back;
+    g.pt_gram = pt_gram;
     g.bt_num = hp->bt_begin.empty() ? 0 : (int)hp->bt_begin.size() - 1;
     g.bt_begin = base + o_bt;
     g.bt_max_out_rows = bt_max_rows;
@@ -2352,8 +2383,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     (void)want_edge3;
 #endif
     hp->use_ps = hp->use_fused && !hp->use_edge2 && !hp->use_edge3 && hp->g.pt_num > 0;
-    hp->ps_fail.ensure(1024);  // [0] the failure word; timing builds (RN_PS_TIMING) keep their cycle counters from byte 64 on
-    HIP_TRY(hipMemset(hp->ps_fail.p, 0, 1024));
+    hp->ps_fail.ensure(2048);  // [0] the failure word; timing builds (RN_PS_TIMING) keep their cycle counters from byte 64 on
+    HIP_TRY(hipMemset(hp->ps_fail.p, 0, 2048));
     hp->split_projections = getenv("RN_POTGNN_SPLIT_PROJ") ? atoi(getenv("RN_POTGNN_SPLIT_PROJ")) != 0 : true;
     hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;

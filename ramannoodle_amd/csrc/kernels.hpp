@@ -41,6 +41,7 @@ struct Graph {
   const int *pt_begin;    // [pt_num+1] node ranges
   int pt_max_out_rows, pt_max_in_rows;
   int pt_back;            // rounds that may still read the ring when a step rewrites it (2 or 3: edge_ps_tile_ok)
+  int pt_gram;            // 1: the GRAM instantiation (LayerNorm cross terms on the matrix pipe; a 7-tile ring + the Gram tables)
   // node tiles of the EdgeBlock reverse kernel (edge_bwd_tile2_kernel): small enough for TWO workgroups per CU
   int bt_num;
   const int *bt_begin;    // [bt_num+1] node ranges
@@ -280,10 +281,13 @@ void launch_node_fused(const float *edge, const float *node_in, const float *npc
                        const Graph &g, Dims d, const PassW<float> &w, bool f16, bool centred, hipStream_t st);
 // Role-specialised fused EdgeBlock (kernels_edge_ps.hip): float32, FnP == FeP == 64, split-f16 products, folded gate
 // scale; needs the centred weight copies of PassW and np3 projected with c3_WnT_c / c3_nshift_c.
-size_t edge_ps_lds_bytes(int tile_out_rows, int tile_in_rows);
+size_t edge_ps_lds_bytes(int tile_out_rows, int tile_in_rows, bool gram);
+int edge_ps_ring_tiles(bool gram);  // ring capacity in 16-row tiles
+int edge_ps_gram_window();          // source tiles a round's window may span in the GRAM instantiation
 // one tile's destinations (first and end source row of each, sorted by atom): does the producers' schedule hold?
-// `back`: rounds g - back .. g - 1 may still be reading the ring when the step of round g rewrites it (2 or 3)
-bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back);
+// `back`: rounds g - back .. g - 1 may still be reading the ring when the step of round g rewrites it (2 or 3); `ring`: its
+// capacity in tiles; `window` (optional, out): the most source tiles one round's window spans
+bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back, int ring, int *window);
 // `fail`: device int, set to a nonzero code if a bounded spin wait inside the kernel ran out (never in a correct run)
 void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
                     const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows = false);

@@ -116,9 +116,10 @@ namespace {
 constexpr int PS_THREADS = 768;
 constexpr int PS_PROD = 4;   // producer waves
 constexpr int PS_ND = 16;    // destinations per round (two per consumer wave)
-constexpr int PS_NRT = 8;    // ring capacity, in 16-row source tiles
-constexpr int PS_RING = PS_NRT * 16;
-constexpr int PS_RINGF = PS_RING * LDQ;  // floats
+constexpr int PS_NRT = 8;    // ring capacity, in 16-row source tiles (GRAM instantiations: PS_NRT_GRAM)
+constexpr int PS_NRT_GRAM = 7;  // ... with the Gram tables in LDS next to it: one tile less, slots wrap by compare-and-subtract
+constexpr int PS_GW = 3;     // Gram tables: source tiles a round's window may span
+constexpr int PS_GSTRIDE = PS_GW * 16 * 16;  // floats of one producer's partial table for one round: [tile][e][d]
 constexpr int PS_MAXNEW = 2;             // source tiles a step produces at most
 constexpr int PS_TILE = 16 * FP;         // floats of one operand tile
 constexpr int PS_BUF = (2 + PS_MAXNEW) * PS_TILE;  // one DMA buffer: edge_d | node[b] | PS_MAXNEW x edge_e
@@ -130,21 +131,23 @@ constexpr unsigned PS_FAILBIT = 0x80000000u;  // in the C_READY word: a bounded 
 enum { C_SPLIT = 0, C_NORM = 16, C_READY = 32, C_FREE0 = 48, C_FREE1 = 64, C_RD0 = 80, C_RD1 = 96 };
 
 struct PsLds {
-  size_t ring, qnp, bufP, bufC, atile, lnp, ints, sync, total;
+  size_t ring, qnp, bufP, bufC, atile, lnp, ints, sync, gram, total;
 };
-__host__ __device__ inline PsLds ps_lds(int maxR, int maxD) {
+__host__ __device__ inline PsLds ps_lds(int maxR, int maxD, bool gram) {
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   const size_t maxR16 = ((size_t)maxR + 15) & ~size_t(15), rounds = ((size_t)maxD + PS_ND - 1) / PS_ND;
   PsLds L;
   size_t off = 0;
-  L.ring = off; off += (size_t)PS_RINGF * 4;
-  L.qnp = off; off += (size_t)PS_RING * 4 * 4;
+  const size_t ring_rows = (size_t)(gram ? PS_NRT_GRAM : PS_NRT) * 16;
+  L.ring = off; off += ring_rows * LDQ * 4;
+  L.qnp = off; off += ring_rows * 4 * 4;
   L.bufP = off; off += (size_t)2 * PS_ND * LDQ * 4;
   L.bufC = off; off += (size_t)2 * PS_ND * LDQ * 4;
   L.atile = off; off += ((size_t)2 * PS_BUF + PS_TILE) * 4;  // two buffers + the node[a] tile they share
-  L.lnp = off; off += (size_t)16 * FP * 4;
+  L.lnp = off; off += (size_t)6 * FP * 4;  // what the producers read every step: the c2 bias, the Q' fold, the Gram's P' fold
   L.ints = off; off += up((maxR16 + 7 * (size_t)maxD + 2 * rounds + 8) * 4);
   L.sync = off; off += 128;
+  L.gram = off; off += gram ? (size_t)2 * PS_PROD * PS_GSTRIDE * 4 : 0;  // [2 rounds][4 producers][PS_GW tiles][16 e][16 d] partial p.q
   L.total = off;
   return L;
 }
@@ -160,33 +163,43 @@ struct PsStep {
   int u, r, g;
   int ntiles, tile0;  // source tiles produced: monotonic indices tile0 .. tile0 + ntiles - 1
   int tu0, tt0, tu1, tt1;  // their units and local tile indices (the second pair repeats the first when there is one tile)
+  int slot0, slot1;   // the ring slots (16-row tiles) they go to: tile index mod the ring's capacity
+  int ubs;            // ring slot of local tile 0 of the step's unit u (the round's window: slots ubs + lo .. ubs + hi, wrapped)
 };
 struct PsSched {
   int nrounds, nrt, nunits;
   int P, pu, pt;  // tiles scheduled so far; unit and local index of the next one (P = pu nrt + pt)
   int u, r, g;    // next destination round
   int h0, hc;     // hi[0]; hi[r] of the next destination round
+  int ring, ps, ubs;  // ring capacity in tiles; slot of the next tile (P mod ring); slot of unit u's local tile 0
 };
-__host__ __device__ inline void ps_sched_init(PsSched &s, int nrounds, int nrt, int nunits, int hi0) {
+__host__ __device__ inline int ps_wrap(int x, int ring) { return x >= ring ? x - ring : x; }  // (x < 2 ring)
+__host__ __device__ inline void ps_sched_init(PsSched &s, int nrounds, int nrt, int nunits, int hi0, int ring) {
   s.nrounds = nrounds;
   s.nrt = nrt;
   s.nunits = nunits;
   s.P = s.pu = s.pt = s.u = s.r = s.g = 0;
   s.h0 = s.hc = hi0;
+  s.ring = ring;
+  s.ps = s.ubs = 0;
 }
 __host__ __device__ inline void ps_sched_take(PsSched &s, PsStep &st, int n) {  // the next n (<= 2) tiles go to this step
   st.ntiles = n;
   st.tile0 = s.P;
   st.tu0 = st.tu1 = s.pu;
   st.tt0 = st.tt1 = s.pt;
+  st.slot0 = st.slot1 = s.ps;
   if (n >= 1) {
     ++s.P;
+    s.ps = ps_wrap(s.ps + 1, s.ring);
     if (++s.pt == s.nrt) { s.pt = 0; ++s.pu; }
   }
   if (n >= 2) {
     st.tu1 = s.pu;
     st.tt1 = s.pt;
+    st.slot1 = s.ps;
     ++s.P;
+    s.ps = ps_wrap(s.ps + 1, s.ring);
     if (++s.pt == s.nrt) { s.pt = 0; ++s.pu; }
   }
 }
@@ -199,6 +212,7 @@ __host__ __device__ inline bool ps_sched_next(PsSched &s, HiFn hi, PsStep &st) {
     const int miss = s.h0 + 1 - s.P;
     st.has_dest = 0;
     st.u = st.r = st.g = 0;
+    st.ubs = 0;
     ps_sched_take(s, st, miss < PS_MAXNEW ? miss : PS_MAXNEW);
     return true;
   }
@@ -214,7 +228,12 @@ __host__ __device__ inline bool ps_sched_next(PsSched &s, HiFn hi, PsStep &st) {
   st.u = s.u;
   st.r = s.r;
   st.g = s.g;
+  st.ubs = s.ubs;
   ps_sched_take(s, st, n);
+  if (u2 != s.u) {  // (nrt may exceed the ring: the host check refuses such a tile, the arithmetic stays defined)
+    int b = s.ubs + s.nrt % s.ring;
+    s.ubs = ps_wrap(b, s.ring);
+  }
   s.u = u2;
   s.r = r2;
   s.hc = h2;
@@ -267,6 +286,22 @@ __device__ __forceinline__ unsigned ps_arrive_ticket(unsigned word, int lane) {
   if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(word), "v"(1u) : "memory");
   return (unsigned)__builtin_amdgcn_readfirstlane((int)old);
 }
+// eight floats (two f32x4) -> two bf16 halves each: hi = bf16(x) (round to nearest even), lo = bf16(x - hi): 16 significant
+// bits over the whole f32 exponent range.  20 VALU: v_cvt_pk_bf16_f32 x 4, the halves back to f32 by shift / mask, packed subtract.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16x8(const f32x4 &x0, const f32x4 &x1, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 v = j < 2 ? f32x2{x0[2 * j], x0[2 * j + 1]} : f32x2{x1[2 * j - 4], x1[2 * j - 3]};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const bf16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), bf16x2);
+    hi[2 * j] = h[0];
+    hi[2 * j + 1] = h[1];
+    lo[2 * j] = l[0];
+    lo[2 * j + 1] = l[1];
+  }
+}
 // (an unsigned maximum, not a write: the failure bit of C_READY survives later publications)
 __device__ __forceinline__ void ps_publish(unsigned word, unsigned value, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -276,11 +311,19 @@ __device__ __forceinline__ void ps_publish(unsigned word, unsigned value, int la
 
 // PRE: edge rows in and out are split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs): the producers' edge tiles are MFMA-ready
 // as they land, the consumers read / write the (hi, lo) halves of their two columns
-template <bool PAD, bool PRE>
+// GRAM: the LayerNorm cross term p.q of every (destination, source row) pair of a round on the matrix pipe (the producers'
+// Gram phase below) instead of a 128-column dot product and a 16-lane reduction per triplet in the consumers' loop
+template <bool PAD, bool PRE, bool GRAM>
 __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int NRT = GRAM ? PS_NRT_GRAM : PS_NRT, RING = NRT * 16;
+  // ring row / tile slot arithmetic: a mask for the power-of-two ring, compare-and-subtract (x < 2 capacity) otherwise
+  auto wrap_row = [](unsigned x) -> unsigned {
+    if constexpr ((RING & (RING - 1)) == 0) return x & (unsigned)(RING - 1);
+    else return min(x, x - (unsigned)RING);  // (unsigned: x - RING wraps to a huge value when x < RING)
+  };
   const Graph &g = a.g;
-  const PsLds L = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows);
+  const PsLds L = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows, GRAM);
   float *ring = reinterpret_cast<float *>(smem_raw + L.ring);   // [PS_RING][LDQ] folded source rows, |q|^2 in the pad
   float *qnp = reinterpret_cast<float *>(smem_raw + L.qnp);     // [PS_RING][4] per-producer parts of |q|^2 / 2Fe
   float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);   // [2][16][LDQ] P' rows of a round
@@ -288,20 +331,24 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   float *atile = reinterpret_cast<float *>(smem_raw + L.atile); // 2 x PS_BUF operand tiles + node[a] tile
   float *na_tile = atile + 2 * PS_BUF;
   float *lnp = reinterpret_cast<float *>(smem_raw + L.lnp);
-  float *s_c3n2g = lnp, *s_c3n2b = lnp + FP, *s_c2n1g = lnp + 2 * FP, *s_c2n1b = lnp + 4 * FP,
-        *s_c2n2g = lnp + 6 * FP, *s_c2n2b = lnp + 7 * FP, *s_g3 = lnp + 8 * FP, *s_ig3 = lnp + 10 * FP, *s_c2b = lnp + 12 * FP,
-        *s_g3q = lnp + 14 * FP;
+  // per-column tables the PRODUCERS read every step: the centred c2 bias, the fold of a Q' row on its way to the ring, and
+  // the fold 1 / gamma * 2 / 2Fe of a P' row for the cross term (the consumers keep theirs in registers)
+  float *s_c2b = lnp, *s_g3q = lnp + 2 * FP, *s_igp = lnp + 4 * FP;
   int *ints = reinterpret_cast<int *>(smem_raw + L.ints);
   unsigned *sync = reinterpret_cast<unsigned *>(smem_raw + L.sync);
   const unsigned sync_a = lds_addr(sync);  // LDS byte address of the signalling words
   const unsigned atile_a = lds_addr(atile), lnp_a = lds_addr(lnp), qnp_a = lds_addr(qnp), ints_a = lds_addr(ints);
+  const unsigned bufP_a = lds_addr(bufP), ring_a = lds_addr(ring);
+  float *gram_f = reinterpret_cast<float *>(smem_raw + L.gram);  // [2 rounds][4 producers][PS_GW tiles][16 e][16 d] partial cross terms
   const int maxD = g.pt_max_in_rows, maxR16 = (g.pt_max_out_rows + 15) & ~15;
   int *qb = ints;  // [maxR16] b_e of the tile's source rows
   int *d_edge = qb + maxR16, *d_a = d_edge + maxD, *d_b = d_a + maxD, *d_rb = d_b + maxD, *d_cnt = d_rb + maxD,
       *d_skip = d_cnt + maxD, *d_re = d_skip + maxD;
   int *hi_t = d_re + maxD;                          // [rounds] last source tile a round reads
-  int *misc = hi_t + (maxD + PS_ND - 1) / PS_ND;    // [0] nrt
+  int *lo_t = hi_t + (maxD + PS_ND - 1) / PS_ND;    // [rounds] first source tile a round reads (hi + 1: none)
+  int *misc = lo_t + (maxD + PS_ND - 1) / PS_ND;    // [0] nrt
   const int hi_off = maxR16 + 7 * maxD;             // index of hi_t[0] in ints
+  const int lo_off = hi_off + (maxD + PS_ND - 1) / PS_ND;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,21 +367,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 
   // ---- once per launch: LayerNorm parameters, the tile topology, the round -> source tile table
   for (int c = tid; c < 2 * FP; c += PS_THREADS) {
-    s_c2n1g[c] = a.w.c2_norm_1.g[c];
-    s_c2n1b[c] = a.w.c2_norm_1.b[c];
     s_c2b[c] = a.w.c2_bias_c[c] * a.w.mfma_scale_c[4];  // (in the c2 weight's prescale: the accumulator's seed as it is)
     const float gam = a.w.c3_norm_1s.g[c];  // c3_norm_1's scale times the gate's exp2 factor (-log2e | 2 log2e)
     // The producers leave their accumulators in the weights' power-of-two prescale: P' rows carry 1/inv4, Q' rows are
     // multiplied by gamma / s5 as they go to the ring, c2 rows carry 1/invc2 (LayerNorm does not see it: eps scaled)
-    s_g3[c] = gam * a.w.mfma_scale_c[1];
-    s_ig3[c] = ((c % FP) < a.d.Fe) ? a.w.mfma_scale_c[1] / gam : 0.0f;
     s_g3q[c] = gam * a.w.mfma_scale_c[3];
-    if (c < FP) {
-      s_c3n2g[c] = a.w.c3_norm_2.g[c];
-      s_c3n2b[c] = a.w.c3_norm_2.b[c];
-      s_c2n2g[c] = a.w.c2_norm_2.g[c];
-      s_c2n2b[c] = a.w.c2_norm_2.b[c];
-    }
+    // pd = p / gamma * (2 / 2Fe) from a stored P' row: pd . (q gamma) is the cross term of the variance
+    s_igp[c] = ((c % FP) < a.d.Fe) ? a.w.mfma_scale_c[1] / gam * (1.0f / (float)a.d.Fe) : 0.0f;
   }
   for (int r = tid; r < maxR16; r += PS_THREADS) qb[r] = g.edge_b[eo0 + min(r, max(R - 1, 0))];
   for (int i = tid; i < D; i += PS_THREADS) {
@@ -353,10 +392,14 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   if (tid < 32) sync[tid] = 0u;
   __syncthreads();
   if (tid < nrounds) {  // destinations are sorted by atom, so the rows a round reads end where its last atom's do
-    int top = 0;
+    int top = 0, first = 1 << 30;
     const int last = min((tid + 1) * PS_ND, D);
-    for (int i = 0; i < last; ++i) top = max(top, d_re[i]);
+    for (int i = 0; i < last; ++i) {
+      top = max(top, d_re[i]);
+      if (i >= tid * PS_ND && d_re[i] > d_rb[i]) first = min(first, d_rb[i]);
+    }
     hi_t[tid] = (top + 15) / 16 - 1;
+    lo_t[tid] = first == (1 << 30) ? (top + 15) / 16 : first / 16;
   }
   __syncthreads();
   if (tid == 0) misc[0] = max(hi_t[nrounds > 0 ? nrounds - 1 : 0] + 1, 1);
@@ -425,7 +468,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 
     auto hi = [&](int r) { return __builtin_amdgcn_readfirstlane(lds_read1(ints_a + (unsigned)(hi_off + r) * 4u)); };  // hi_t[r]
     PsSched sched;
-    ps_sched_init(sched, nrounds, nrt, nunits, __builtin_amdgcn_readfirstlane(hi_t[0]));
+    ps_sched_init(sched, nrounds, nrt, nunits, __builtin_amdgcn_readfirstlane(hi_t[0]), NRT);
     PsStep cur, nxt;
     bool have = ps_sched_next(sched, hi, cur);
     if (have) request(cur, 0, lane);
@@ -466,7 +509,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
           }
         }
         q_src = np3_q + oq;
-        ringrow0 = (cur.tile0 & (PS_NRT - 1)) * 16 + l15;
+        ringrow0 = cur.slot0 * 16 + l15;
       }
       const bool have_next = ps_sched_next(sched, hi, nxt);  // (its one table read hides under the loads above)
       if (!(RN_PS_PROBE & 16)) split_landed(buf, ln);
@@ -526,7 +569,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       if (cur.has_dest) {
         f16x8 ah[2], al[2];
         f32x4 accC[2];
-        load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (12 * FP + mycol) * 4, lnp_a + (12 * FP + mycol + 16) * 4,
+        load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (unsigned)mycol * 4u, lnp_a + (unsigned)(mycol + 16) * 4u,
                      accC[0], accC[1]);  // + the centred c2 bias
         if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
 #pragma unroll
@@ -553,8 +596,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         f32x4 accQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, g3v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (ntl > 0) {
           f16x8 ah[2], al[2];
-          load_pair_a2(tb_a + (unsigned)(2 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (14 * FP + mycol) * 4,
-                       lnp_a + (14 * FP + mycol + 16) * 4, g3v[0], g3v[1]);  // + s_g3q
+          load_pair_a2(tb_a + (unsigned)(2 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
+                       lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);  // + s_g3q
           if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
         }
         // (issued after this step's requests: everything of this wave has landed then -- the requests are ~2000 cycles old)
@@ -576,17 +619,68 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         for (int t = 0; t < 2; ++t) qS[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
         f16x8 ah[2], al[2];
         f32x4 accQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, g3v[2];
-        load_pair_a2(tb_a + (unsigned)(3 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (14 * FP + mycol) * 4,
-                     lnp_a + (14 * FP + mycol + 16) * 4, g3v[0], g3v[1]);
+        load_pair_a2(tb_a + (unsigned)(3 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
+                     lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);
         if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
-        q_tile_finish(accQ, g3v, ((cur.tile0 + 1) & (PS_NRT - 1)) * 16 + l15);
+        q_tile_finish(accQ, g3v, cur.slot1 * 16 + l15);
+      }
+      if constexpr (GRAM) {
+        // ---- the Gram phase: p.q of the round's 16 destinations with every source row of the round's window, this wave's 32
+        // columns of it, on the matrix pipe.  Operands: the P' rows this wave stored above (its own LDS stores: in order) times
+        // 1 / gamma * 2 / 2Fe, and the folded Q' rows (q gamma) of the window's tiles out of the ring -- this wave's columns of
+        // them are its own stores too, of this step or of earlier ones, so the phase needs no other wave.  Both are in the
+        // model's own units (no bounded range), so they are split into two bf16 halves each (16 significant bits, the f32
+        // exponent range) and multiplied as lo hi + hi lo + hi hi with f32 accumulation: the cross term to ~2^-16 of
+        // sum |p_c q_c|, a few 1e-7 of the variance it enters.  The lane ends with (e = row l15 of the tile, d = 4 quad .. + 3):
+        // one 16-byte store into this producer's partial table; the consumers add the four tables (their prologue).
+        if (cur.has_dest) {
+          const unsigned prow_a = bufP_a + (unsigned)((slot0 + l15) * LDQ + mycol) * 4u;
+          const unsigned ig_a = lnp_a + (unsigned)(4 * FP + mycol) * 4u;
+          const int lo = __builtin_amdgcn_readfirstlane(lds_read1(ints_a + (unsigned)(lo_off + cur.r) * 4u));
+          const int hiw = __builtin_amdgcn_readfirstlane(lds_read1(ints_a + (unsigned)(hi_off + cur.r) * 4u));
+          // always PS_GW tiles, as one straight instruction sequence: a window of fewer tiles multiplies its last one again
+          // (into a table slot nobody reads); every operand row of the phase is requested before the first is waited for
+          unsigned qa[PS_GW];
+#pragma unroll
+          for (int k = 0; k < PS_GW; ++k) {
+            int sl = cur.ubs + min(lo + k, max(hiw, lo));  // (< 3 NRT: edge_ps_tile_ok)
+            sl = sl >= NRT ? sl - NRT : sl;
+            sl = sl >= NRT ? sl - NRT : sl;
+            qa[k] = ring_a + (unsigned)((sl * 16 + l15) * LDQ + mycol) * 4u;
+          }
+          static_assert(PS_GW == 3, "the Gram phase is written for three window tiles");
+          f32x4 p0, p1, i0, i1, q0[PS_GW], q1[PS_GW];
+          asm volatile(
+              "ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:64\n\tds_read_b128 %2, %11\n\tds_read_b128 %3, %11 offset:64\n\t"
+              "ds_read_b128 %4, %12\n\tds_read_b128 %5, %12 offset:64\n\tds_read_b128 %6, %13\n\tds_read_b128 %7, %13 offset:64\n\t"
+              "ds_read_b128 %8, %14\n\tds_read_b128 %9, %14 offset:64\n\ts_waitcnt lgkmcnt(0)"
+              : "=&v"(p0), "=&v"(p1), "=&v"(i0), "=&v"(i1), "=&v"(q0[0]), "=&v"(q1[0]), "=&v"(q0[1]), "=&v"(q1[1]), "=&v"(q0[2]), "=&v"(q1[2])
+              : "v"(prow_a), "v"(ig_a), "v"(qa[0]), "v"(qa[1]), "v"(qa[2])
+              : "memory");
+          bf16x8 ph, pl, qh[PS_GW], ql[PS_GW];
+          split_bf16x8(p0 * i0, p1 * i1, ph, pl);
+#pragma unroll
+          for (int k = 0; k < PS_GW; ++k) split_bf16x8(q0[k], q1[k], qh[k], ql[k]);
+          f32x4 gacc[PS_GW];
+#pragma unroll
+          for (int k = 0; k < PS_GW; ++k) gacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qh[k], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < PS_GW; ++k) gacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ql[k], gacc[k], 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < PS_GW; ++k) gacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qh[k], gacc[k], 0, 0, 0);
+          // (plain stores, like the P' / c2 / ring rows: the compiler then covers the MFMA -> LDS-write hazard itself; an asm
+          //  ds_write of the accumulators went out before the chain had finished)
+          const int gout = ((cur.g & 1) * PS_PROD + wave) * PS_GSTRIDE + l15 * 16 + 4 * quad;
+#pragma unroll
+          for (int k = 0; k < PS_GW; ++k) *reinterpret_cast<f32x4 *>(gram_f + gout + k * 256) = gacc[k];
+        }
       }
       PS_TICK(7);
       // ---- the LAST producer to get here completes |q|^2 of the step's new rows (every producer's part is in LDS by then)
       // and publishes the round; the others go straight on to the next step
       if (ps_arrive_ticket(sync_a + C_NORM, ln) == 4u * k + 3u) {
         if (ln < 16 * cur.ntiles) {
-          const int rrow = ((cur.tile0 + (ln >> 4)) & (PS_NRT - 1)) * 16 + l15;
+          const int rrow = ((ln >> 4) ? cur.slot1 : cur.slot0) * 16 + l15;
           f32x4 v, v2;
           lds_read2(qnp_a + (unsigned)rrow * 16u, qnp_a + (unsigned)rrow * 16u, v, v2);
           ring[rrow * LDQ + 2 * FP] = (v[0] + v[1]) + (v[2] + v[3]);
@@ -622,26 +716,34 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     //  every round's own loads and stores are outstanding too)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf2[0]), "+v"(bf2[1]), "+v"(bc2[0]), "+v"(bc2[1]));
   }
-  // LayerNorm parameters of this lane's four columns: registers (a consumer has ~40 to spare), not LDS reads per round
-  const LnParams<float> k_c3 = {load4<float>(s_c3n2g + c0), load4<float>(s_c3n2b + c0)};
-  const LnParams<float> k_c21f = {load4<float>(s_c2n1g + c0), load4<float>(s_c2n1b + c0)};
-  const LnParams<float> k_c21c = {load4<float>(s_c2n1g + FP + c0), load4<float>(s_c2n1b + FP + c0)};
-  const LnParams<float> k_c22 = {load4<float>(s_c2n2g + c0), load4<float>(s_c2n2b + c0)};
-  Vec4<float> igf = load4<float>(s_ig3 + c0), igc = load4<float>(s_ig3 + FP + c0);  // (the folds of a P' row:
-  const Vec4<float> g3f = load4<float>(s_g3 + c0), g3c = load4<float>(s_g3 + FP + c0);  //  1/gamma with the 2 / 2Fe of p.q)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    igf.v[k] *= 2.0f * inv2n;
-    igc.v[k] *= 2.0f * inv2n;
+  // LayerNorm parameters and fold tables of this lane's four columns: registers (a consumer has ~40 to spare), straight from
+  // the weight blob -- not LDS reads per round, and no LDS copy of the tables either
+  LnParams<float> k_c3 = {load4<float>(a.w.c3_norm_2.g + c0), load4<float>(a.w.c3_norm_2.b + c0)};
+  LnParams<float> k_c21f = {load4<float>(a.w.c2_norm_1.g + c0), load4<float>(a.w.c2_norm_1.b + c0)};
+  LnParams<float> k_c21c = {load4<float>(a.w.c2_norm_1.g + FP + c0), load4<float>(a.w.c2_norm_1.b + FP + c0)};
+  LnParams<float> k_c22 = {load4<float>(a.w.c2_norm_2.g + c0), load4<float>(a.w.c2_norm_2.b + c0)};
+  Vec4<float> g3f = load4<float>(a.w.c3_norm_1s.g + c0), g3c = load4<float>(a.w.c3_norm_1s.g + FP + c0);
+  {  // (consumed here, like bf2 / bc2 above)
+    auto pin = [](Vec4<float> &x) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3])); };
+    pin(k_c3.g); pin(k_c3.b); pin(k_c21f.g); pin(k_c21f.b); pin(k_c21c.g); pin(k_c21c.b); pin(k_c22.g); pin(k_c22.b);
+    pin(g3f); pin(g3c);
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // p gamma from a stored P' row (which carries the weights' prescale)
+    g3f.v[k] *= a.w.mfma_scale_c[1];
+    g3c.v[k] *= a.w.mfma_scale_c[1];
+  }
+  // (not GRAM) the fold of a P' row for the cross term, 1 / gamma * 2 / 2Fe: the producers' table (written before the barrier)
+  Vec4<float> igf = load4<float>(s_igp + c0), igc = load4<float>(s_igp + FP + c0);
   const float *ringc = ring + c0;
   const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
   // this set's first round: global round `cset` = (unit u, local round r); ub = ring row of unit u's first source row
   int u = 0, r = cset, ub = 0;
+  const int ustep = (nrt * 16) % RING;  // ring rows from one unit's first source row to the next unit's
   while (r >= nrounds) {
     r -= nrounds;
     ++u;
-    ub = (ub + nrt * 16) & (PS_RING - 1);
+    ub = (int)wrap_row((unsigned)(ub + ustep));
   }
   bool poisoned = false;  // a bounded wait ran out in this workgroup: store NaN from here on
 #if RN_PS_TIMING
@@ -680,8 +782,10 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       // pd = p / gamma * (2 / 2Fe), pg = p * gamma;  var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh], xf.v[2 * hh + 1] * igf.v[2 * hh + 1]};
-        pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh], xc.v[2 * hh + 1] * igc.v[2 * hh + 1]};
+        if constexpr (!GRAM) {
+          pdf2[hh] = f32x2{xf.v[2 * hh] * igf.v[2 * hh], xf.v[2 * hh + 1] * igf.v[2 * hh + 1]};
+          pdc2[hh] = f32x2{xc.v[2 * hh] * igc.v[2 * hh], xc.v[2 * hh + 1] * igc.v[2 * hh + 1]};
+        }
         pf2[hh] = f32x2{xf.v[2 * hh] * g3f.v[2 * hh], xf.v[2 * hh + 1] * g3f.v[2 * hh + 1]};
         pc2[hh] = f32x2{xc.v[2 * hh] * g3c.v[2 * hh], xc.v[2 * hh + 1] * g3c.v[2 * hh + 1]};
       }
@@ -708,23 +812,72 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       c2v = (RN_PS_PROBE & 4) ? g2 : ln_row<LG, PAD, float>(g2, k_c22, invn, nvalid);
     }
     const int rb = d_rb[i], cnt = active ? d_cnt[i] : 0, rskip = d_skip[i];
+    const int rbase = (int)wrap_row(wrap_row((unsigned)(ub + rb)));  // ring row of the destination's first source row
+    // ---- GRAM: 1 / sqrt(var + eps) of every (this destination, source row) pair, sixteen source rows per instruction: lane j
+    // of the group takes source rows j and j + 16 of the destination's list (the reverse edge's row among them: computed,
+    // never used), adds the four producers' partial cross terms, |p|^2 and |q|^2, and keeps the two results; the loop
+    // fetches the one it needs from the lane that has it (ds_bpermute: the LDS crossbar, no LDS memory).
+    float rs0 = 0.f, rs1 = 0.f;
+    if constexpr (GRAM) {
+      const int nrow = d_re[i] - rb;  // (<= 32: edge_ps_gram_ok)
+      const int lo_r = __builtin_amdgcn_readfirstlane(lo_t[r]);
+      const float *gtab = reinterpret_cast<const float *>(smem_raw + L.gram) + (int)(gr & 1u) * (PS_PROD * PS_GSTRIDE) + slot;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int er = min(l15 + 16 * pass, max(nrow - 1, 0));
+        const int urow = rb + er;                                     // row of the unit
+        const int tl = min(max((urow >> 4) - lo_r, 0), PS_GW - 1);    // tile of the round's window
+        const float *gp = gtab + (tl * 16 + (urow & 15)) * 16;
+        const float qs = ring[wrap_row((unsigned)(rbase + er)) * LDQ + 2 * FP];
+#ifdef RN_PS_GRAM_DEBUG  // (debug builds: the cross term by a serial dot product instead of the tables)
+        float gsum = 0.f;
+        {
+          const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ, *qrow = ring + wrap_row((unsigned)(rbase + er)) * LDQ;
+          for (int c = 0; c < 2 * FP; ++c) gsum = fmaf(prow[c] * s_igp[c], qrow[c], gsum);
+        }
+        {  // (debug: the first few mismatches between the tables and the serial dot product go to fail[128 ..])
+          const float gt = (gp[0] + gp[PS_GSTRIDE]) + (gp[2 * PS_GSTRIDE] + gp[3 * PS_GSTRIDE]);
+          if (active && l15 + 16 * pass < nrow && fabsf(gt - gsum) > 1e-4f * (fabsf(gsum) + 1e-3f)) {
+            const int k = atomicAdd(a.fail + 127, 1);
+            if (k < 12) {
+              float *dbg = reinterpret_cast<float *>(a.fail + 128 + 12 * k);
+              dbg[0] = gsum; dbg[1] = gt; dbg[2] = gp[0]; dbg[3] = gp[PS_GSTRIDE]; dbg[4] = gp[2 * PS_GSTRIDE]; dbg[5] = gp[3 * PS_GSTRIDE];
+              dbg[6] = (float)slot; dbg[7] = (float)er; dbg[8] = (float)tl; dbg[9] = (float)urow; dbg[10] = (float)r; dbg[11] = (float)gr;
+            }
+          }
+        }
+        float ve = gsum + (spe + qs);
+#else
+        float ve = (gp[0] + gp[PS_GSTRIDE]) + (gp[2 * PS_GSTRIDE] + gp[3 * PS_GSTRIDE]) + (spe + qs);
+#endif
+        ve = ve > 1e-5f ? ve : 1e-5f;
+        (pass ? rs1 : rs0) = fast_rsq(ve);
+      }
+    }
     ps_arrive(sync_a + ((gr & 1u) ? C_FREE1 : C_FREE0), lane);  // this wave holds what it needs of round gr's P' / c2 buffers
     PS_TICK(11);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     {
-      auto triplet = [&](const float *qr, float (&sumk)[4]) {
+      // `er` (GRAM): index of the source row in the destination's list = which lane of the group holds its rstd, and in which register
+      auto triplet = [&](const float *qr, int er, float (&sumk)[4]) {
         const float4 qfv = *reinterpret_cast<const float4 *>(qr), qcv = *reinterpret_cast<const float4 *>(qr + FP);
-        const float qs = qr[sdelta];
         const f32x2 qf2[2] = {{qfv.x, qfv.y}, {qfv.z, qfv.w}}, qc2[2] = {{qcv.x, qcv.y}, {qcv.z, qcv.w}};
-        f32x2 d2 = pdf2[0] * qf2[0];
-        f32x2 d3 = pdc2[0] * qc2[0];
-        d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
-        d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
-        d2 += d3;
-        const float dot = lg_sum<LG>(d2.x + d2.y);
-        float ve = dot + (spe + qs);
-        ve = ve > 1e-5f ? ve : 1e-5f;
-        const float rstd = fast_rsq(ve);
+        float rstd;
+        if constexpr (GRAM) {
+          const int src = ((lane & 48) | (er & 15)) << 2;
+          rstd = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(er < 16 ? rs0 : rs1)));
+        } else {
+          const float qs = qr[sdelta];
+          f32x2 d2 = pdf2[0] * qf2[0];
+          f32x2 d3 = pdc2[0] * qc2[0];
+          d2 = __builtin_elementwise_fma(pdf2[1], qf2[1], d2);
+          d3 = __builtin_elementwise_fma(pdc2[1], qc2[1], d3);
+          d2 += d3;
+          const float dot = lg_sum<LG>(d2.x + d2.y);
+          float ve = dot + (spe + qs);
+          ve = ve > 1e-5f ? ve : 1e-5f;
+          rstd = fast_rsq(ve);
+        }
         const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -744,29 +897,31 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       __builtin_amdgcn_s_setprio(0);
 #endif
       // two independent triplets per iteration.  Source row of triplet t: rb + t, plus one from the reverse edge on
-      // (the numbering jumps over it); its ring slot is (that + the unit's ring base) mod PS_RING -- a compare, an
-      // add-with-carry, an AND and one 24-bit multiply per triplet, no branches and no running pointer to wrap
+      // (the numbering jumps over it); its ring row is (that + the unit's ring base) wrapped -- a compare, an add-with-carry,
+      // the wrap and one 24-bit multiply per triplet, no branches and no running pointer to wrap
       float acc2[4] = {0.f, 0.f, 0.f, 0.f};
       const int tskip = rskip - rb;
-      const int rbase = ub + rb;
-      auto row_of = [&](int t) {
-        const unsigned rs = (unsigned)(rbase + t + (t >= tskip ? 1 : 0)) & (unsigned)(PS_RING - 1);
-        return ringc + __umul24(rs, (unsigned)LDQ);
-      };
+      auto er_of = [&](int t) { return t + (t >= tskip ? 1 : 0); };
+      auto row_of = [&](int er) { return ringc + __umul24(wrap_row((unsigned)(rbase + er)), (unsigned)LDQ); };
       int t = (RN_PS_PROBE & 1) ? cnt : 0;
       const int tmid = RN_PS_LPRIO ? ((cnt >> 1) & ~1) : 0;
       for (; t + 1 < tmid; t += 2) {
-        triplet(row_of(t), acc);
-        triplet(row_of(t + 1), acc2);
+        const int e0 = er_of(t), e1 = er_of(t + 1);
+        triplet(row_of(e0), e0, acc);
+        triplet(row_of(e1), e1, acc2);
       }
 #if RN_PS_LPRIO
       __builtin_amdgcn_s_setprio(RN_PS_LPRIO);
 #endif
       for (; t + 1 < cnt; t += 2) {
-        triplet(row_of(t), acc);
-        triplet(row_of(t + 1), acc2);
+        const int e0 = er_of(t), e1 = er_of(t + 1);
+        triplet(row_of(e0), e0, acc);
+        triplet(row_of(e1), e1, acc2);
       }
-      if (t < cnt) triplet(row_of(t), acc);
+      if (t < cnt) {
+        const int e0 = er_of(t);
+        triplet(row_of(e0), e0, acc);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] += acc2[k];
     }
@@ -805,21 +960,23 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     while (r >= nrounds) {
       r -= nrounds;
       ++u;
-      ub = (ub + nrt * 16) & (PS_RING - 1);
+      ub = (int)wrap_row((unsigned)(ub + ustep));
     }
   }
   PS_TFLUSH(10, 13, cset ? 6 : 0);  // (set A: slots 10-13, set B: 16-19)
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
-size_t edge_ps_lds_bytes(int rows, int in_rows) { return ps_lds(rows, in_rows).total; }
+size_t edge_ps_lds_bytes(int rows, int in_rows, bool gram) { return ps_lds(rows, in_rows, gram).total; }
+int edge_ps_ring_tiles(bool gram) { return gram ? PS_NRT_GRAM : PS_NRT; }
+int edge_ps_gram_window() { return PS_GW; }
 
 // Runs the producers' schedule for one tile (first destination index and end row per destination, sorted by atom)
 // and checks what the kernel takes for granted: never more than PS_MAXNEW source tiles in one step, and no ring slot is
 // rewritten while a round that may still be in flight (g - back .. g - 1 at the step of round g) reads the tile it holds.
 // back = 2 is the least the two consumer sets need; back = 3 (Graph::pt_back, when the ring has the room) lets the producers
 // run one more round ahead of the slower set: 7.44 -> 6.91 ms per launch on the benchmark cell.
-bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back) {
+bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back, int ring, int *window) {
   if (D <= 0) return true;
   const int nrounds = (D + PS_ND - 1) / PS_ND;
   std::vector<int> hi(nrounds), lo(nrounds);
@@ -835,22 +992,28 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back) {
     lo[r] = first_row == (1 << 30) ? (hi[r] + 1) : first_row / 16;
   }
   const int nrt = std::max(hi[nrounds - 1] + 1, 1);
+  if (nrt > 2 * ring) return false;  // (the kernel wraps ring positions by at most two subtractions)
   const int units = 3 + back;
   PsSched s;
-  ps_sched_init(s, nrounds, nrt, units, hi[0]);
+  if (window) {  // most source tiles a round's window spans (what the Gram tables must hold)
+    int w = 0;
+    for (int r = 0; r < nrounds; ++r) w = std::max(w, hi[r] - std::min(lo[r], hi[r] + 1) + 1);
+    *window = w;
+  }
+  ps_sched_init(s, nrounds, nrt, units, hi[0], ring);
   PsStep st;
   auto hif = [&](int r) { return hi[r]; };
   while (ps_sched_next(s, hif, st)) {
     if (st.ntiles > PS_MAXNEW) return false;
     if (!st.has_dest) {
-      if (st.tile0 + st.ntiles > PS_NRT) return false;
+      if (st.tile0 + st.ntiles > ring) return false;
       continue;
     }
     // the consumer sets may still be reading rounds g - back .. g - 1 (the step waits for round g - back - 1 only): the first
     // tile of round g - back and everything after it must survive this step
     const int g1 = std::max(st.g - back, 0), u1 = g1 / nrounds, r1 = g1 % nrounds;
     const int oldest = u1 * nrt + std::min(lo[r1], hi[r1] + 1);
-    if (st.tile0 + st.ntiles - oldest > PS_NRT) return false;
+    if (st.tile0 + st.ntiles - oldest > ring) return false;
     if (st.u * nrt + hi[st.r] + 1 > st.tile0 + st.ntiles) return false;  // the round's own rows exist
   }
   return true;
@@ -860,10 +1023,13 @@ void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, co
                     const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows) {
   if (S == 0 || g.E == 0) return;
   EdgePsArgs a{edge_in, edge_out, node, np3, agg_out, fail, S, g, d, w};
-  const size_t lds = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows).total;
+  const bool gram = g.pt_gram != 0;
+  const size_t lds = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows, gram).total;
   const bool pad = d.Fe != d.FeP;
-  auto kern = pair_rows ? (pad ? &edge_block_ps_kernel<true, true> : &edge_block_ps_kernel<false, true>)
-                        : (pad ? &edge_block_ps_kernel<true, false> : &edge_block_ps_kernel<false, false>);
+  auto kern = gram ? (pair_rows ? (pad ? &edge_block_ps_kernel<true, true, true> : &edge_block_ps_kernel<false, true, true>)
+                                : (pad ? &edge_block_ps_kernel<true, false, true> : &edge_block_ps_kernel<false, false, true>))
+                   : (pair_rows ? (pad ? &edge_block_ps_kernel<true, true, false> : &edge_block_ps_kernel<false, true, false>)
+                                : (pad ? &edge_block_ps_kernel<true, false, false> : &edge_block_ps_kernel<false, false, false>));
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int cus = 0;
   if (cus == 0) {
