@@ -46,7 +46,12 @@ void widen_for_fused(rn::Dims &d) {
   static const int widen = getenv("RN_POTGNN_WIDEN") ? atoi(getenv("RN_POTGNN_WIDEN")) : 1;
   if (widen == 0) return;
   if (d.FeP == 64 && d.FnP < 64) d.FnP = 64;
-  if (widen >= 2 && std::max(d.FnP, d.FeP) == 32) d.FnP = d.FeP = 64;
+  // round 5: with the role-specialised EdgeBlock at 3.4 us the 64-wide fused kernels also beat the unfused chain at
+  // Fn in 33..64 / Fe in 17..32 (8.3 against 9.1 us per 128-atom structure; Fn <= 32 stays: 7.7 unfused against 8.3,
+  // profiles/r05/width_sweep.txt)
+  if (d.FeP == 32 && d.FnP == 64) d.FeP = 64;
+  if (widen >= 2 && d.FeP == 32 && d.FnP <= 64) d.FnP = d.FeP = 64;            // Fe in 17..32, any Fn up to 64
+  if (widen >= 3 && d.FeP <= 16 && d.FnP >= 32 && d.FnP <= 64) d.FnP = d.FeP = 64;  // (experiment) Fe <= 16 with Fn in 17..64
 }
 
 struct HipError {

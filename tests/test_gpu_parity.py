@@ -1721,3 +1721,30 @@ def test_eight_message_passes_on_the_default_path_against_the_float64_oracle():
     std_got, std_want = (got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std
     assert _rel_err(std_got, std_want) < REL, _rel_err(std_got, std_want)
     np.testing.assert_array_equal(model.calc_polarizabilities(pos), got)
+
+
+@pytest.mark.parametrize("case,cutoff,fn,fe,passes,frames", [
+    ("rocksalt64_parity", 3.2, 64, 64, 2, 23),   # regular graph: 7-tile ring, windows of two and three tiles, several units
+    ("triclinic20", 3.0, 40, 50, 2, 3),          # ragged graph, padded columns
+])
+def test_gram_instantiation_of_the_role_split_edge_block(monkeypatch, case, cutoff, fn, fe, passes, frames):
+    """The opt-in GRAM instantiation of the role-specialised EdgeBlock (``RN_POTGNN_PS_GRAM=1``: the LayerNorm cross terms
+    ``p.q`` as a bf16-split Gram block on the matrix pipe, a 7-tile ring, one ``rstd`` per triplet fetched with
+    ``ds_bpermute``) computes what the default instantiation computes (``_gnn.py:270-291``): within 1e-5 of the oracle, and
+    of the default path, and bit for bit the same twice.  It is not the default because it is slower."""
+    from oracle import potgnn_oracle as O
+    g = load_golden(case)
+    rng = np.random.default_rng(6)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=frames)] + rng.normal(scale=2e-3, size=(frames,) + base.shape[1:])
+    plain, oracle = _random_model(g, cutoff, fn, fe, passes, seed=fn * 11 + fe)
+    ref = plain.calc_polarizabilities(pos)
+    monkeypatch.setenv("RN_POTGNN_PS_GRAM", "1")
+    model, _ = _random_model(g, cutoff, fn, fe, passes, seed=fn * 11 + fe)
+    got = model.calc_polarizabilities(pos)
+    assert model.config_flags()["role_split_edge_block"]
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    assert _rel_err((got - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL
+    assert _rel_err((got - oracle.mean) / oracle.std, (ref - oracle.mean) / oracle.std) < REL
+    assert np.abs(got - ref).max() > 0  # (it really is another instantiation)
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos), got)
