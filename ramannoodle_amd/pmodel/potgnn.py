@@ -357,9 +357,14 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         verify_ndarray_shape("positions_batch", positions_batch, (None, self.num_atoms, 3))
         return np.ascontiguousarray(positions_batch, dtype=np.float64)
 
-    def calc_polarizabilities(self, positions_batch: NDArray[np.float64], dtype=None) -> NDArray[np.float64]:
+    def calc_polarizabilities(self, positions_batch: NDArray[np.float64], dtype=None,
+                              progress: bool = False) -> NDArray[np.float64]:
         """Polarizabilities ``(S,3,3)`` for fractional positions ``(S,N,3)``
         (``_gnn.py:667-721``): host arrays in, host arrays out.
+
+        ``progress=True`` shows the reference's progress bar (``tqdm``, unit " configs", ``_gnn.py:692,714-717``): the
+        batch is then evaluated in blocks through the pipelined entry so that the bar moves; off by default -- one call
+        is a fraction of a second for 10 000 frames.
 
         ``dtype`` is the arithmetic the model is evaluated in.  ``None`` follows
         ``torch.get_default_dtype()`` as the reference does (``_gnn.py:705-710``): float32 unless the
@@ -369,6 +374,18 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         self.eval()  # as the reference does (_gnn.py:686)
         out = np.empty((pos.shape[0], 3, 3), dtype=np.float64)
         handle = self._ensure_handle()
+        if progress and pos.shape[0] > 0:
+            from tqdm import tqdm
+            entry = (_lib.load().rn_potgnn_calc_polarizabilities_f64 if _wants_float64(dtype)
+                     else _lib.load().rn_potgnn_calc_polarizabilities)
+            block = max(1, min(pos.shape[0], 2000))
+            with tqdm(total=pos.shape[0], unit=" configs") as progress_bar:
+                for first in range(0, pos.shape[0], block):
+                    n = min(block, pos.shape[0] - first)
+                    rc = entry(handle, _ptr(pos[first:first + n]), n, _ptr(out[first:first + n]))
+                    _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities")
+                    progress_bar.update(n)
+            return out
         if _wants_float64(dtype):
             rc = _lib.load().rn_potgnn_calc_polarizabilities_f64(handle, _ptr(pos), pos.shape[0], _ptr(out))
             _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities_f64")

@@ -81,6 +81,7 @@ def test_calc_polarizabilities_matches_reference_and_oracle(golden):
     alpha = model.calc_polarizabilities(pos)
     assert alpha.dtype == np.float64 and alpha.shape == (pos.shape[0], 3, 3)
     np.testing.assert_array_equal(alpha, np.swapaxes(alpha, 1, 2))
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos, progress=True), alpha)  # the reference's tqdm bar, opt-in
     # standardised part within 1e-5 relative; de-standardised alpha likewise
     std_part = (alpha - g["mean"]) / g["std"]
     ref_part = (g["f32/alpha"] - g["mean"]) / g["std"]
