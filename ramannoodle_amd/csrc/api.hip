@@ -965,7 +965,7 @@ struct ChunkRun {
         else if (fused() && h->use_edge2)
           launch_edge2(edge[cur], edge[nxt], np3, c2, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
 #endif
-        else if (role_split(w)) launch_edge_ps(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->ps_fail.as<int>(), st(), pair_rows());
+        else if (role_split(w)) launch_edge_ps(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->ps_fail.as<int>(), st(), pair_rows(), h->mfma_f16);
 #if RN_EXPERIMENTS
         else if (fused() && getenv("RN_POTGNN_EDGE_FRAME") && atoi(getenv("RN_POTGNN_EDGE_FRAME")) != 0)  // the retired per-frame kernel
           launch_edge_fused(edge[cur], edge[nxt], node[nxt], np3, tape_agg(p), S, h->g, h->d, w, h->mfma_f16, st());
@@ -1069,7 +1069,8 @@ struct ChunkRun {
   // every projection from the taped node / edge rows, so it never sees the centred copies); RN_POTGNN_TAPE_PS=0 keeps
   // them on the per-frame kernel and the row-ordered NodeBlock
   bool role_split(const PassW<T> &w) const {
-    return sizeof(T) == 4 && fused() && h->use_ps && h->mfma_f16 && (w.c3_fast & 1) != 0 && (!prec<T>(h).tape_on || h->tape_ps);
+    // (round 5: also with exact-f32 products -- RN_POTGNN_MFMA=f32, the range guard's fallback -- on the kernel's F16 = false form)
+    return sizeof(T) == 4 && fused() && h->use_ps && (w.c3_fast & 1) != 0 && (!prec<T>(h).tape_on || h->tape_ps);
   }
   // Edge rows as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs): when EVERY kernel that touches them in this run is one
   // that speaks the format -- the role-specialised EdgeBlock in every pass, the atom-owning NodeBlock, the fused readout --
@@ -3076,7 +3077,7 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
   int flags = (h->use_fused ? 1 : 0) | ((h->use_fused && h->mfma_f16) ? 4 : 0) | (h->use_narrow ? 8 : 0) |
               ((h->use_fused && h->mfma_range_fallback) ? 16 : 0) | (h->use_edge2 ? 32 : 0) | (h->use_edge3 ? 64 : 0) | (RN_EXPERIMENTS ? 128 : 0);
   {  // bit 8: every pass of a float32 evaluation takes the role-specialised EdgeBlock (kernels_edge_ps.hip)
-    bool ps = h->use_fused && h->use_ps && h->mfma_f16 && !h->f32.pass.empty();
+    bool ps = h->use_fused && h->use_ps && !h->f32.pass.empty();  // (split-f16 or exact-f32 products: the same kernel)
     for (const auto &p : h->f32.pass) ps = ps && (p.c3_fast & 1);
     flags |= ps ? 256 : 0;
   }

@@ -330,6 +330,24 @@ __device__ __forceinline__ void load_pair_a2(unsigned tile_addr, int l15, int qu
         "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16), "v"(x0), "v"(x1)
       : "memory");
 }
+// exact-f32 products: this lane's sixteen consecutive k = 16 quad .. + 15 of row l15 of a float32 operand tile as the LDS-DMA
+// left it (slot J of row r at physical position J ^ r), plus two more 16-byte reads (a bias / scale pair) under the one wait
+__device__ __forceinline__ void load_f32_a2(unsigned tile_addr, int l15, int quad, float (&af)[16], unsigned x0, unsigned x1,
+                                            f32x4 &e0, f32x4 &e1) {
+  const unsigned row = tile_addr + (unsigned)l15 * (FP * 4);
+  f32x4 u[4];
+  asm volatile(
+      "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+      "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(e0), "=&v"(e1)
+      : "v"(row + (((4 * quad + 0) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 1) ^ l15) & 15) * 16),
+        "v"(row + (((4 * quad + 2) ^ l15) & 15) * 16), "v"(row + (((4 * quad + 3) ^ l15) & 15) * 16), "v"(x0), "v"(x1)
+      : "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[4 * j + i] = u[j][i];
+}
 }  // namespace
 
 // _NodeBlock.forward (_gnn.py:122-151) in one launch: for the edges e entering the tile's

@@ -290,7 +290,8 @@ int edge_ps_gram_window();          // source tiles a round's window may span in
 bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back, int ring, int *window);
 // `fail`: device int, set to a nonzero code if a bounded spin wait inside the kernel ran out (never in a correct run)
 void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
-                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows = false);
+                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows = false,
+                    bool f16 = true /* false: exact-f32 MFMA products (float32 rows, no Gram tables) */);
 
 // Opt-in experiment kernels (experiments/kernels_fused_experiments.hip): compiled and reachable only with
 // -DRN_EXPERIMENTS=1; the product build has neither the kernels nor the RN_POTGNN_EDGE2 / EDGE3 / NODE_WAVE knobs.

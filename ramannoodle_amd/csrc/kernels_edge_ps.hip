@@ -313,8 +313,11 @@ __device__ __forceinline__ void ps_publish(unsigned word, unsigned value, int la
 // as they land, the consumers read / write the (hi, lo) halves of their two columns
 // GRAM: the LayerNorm cross term p.q of every (destination, source row) pair of a round on the matrix pipe (the producers'
 // Gram phase below) instead of a 128-column dot product and a 16-lane reduction per triplet in the consumers' loop
-template <bool PAD, bool PRE, bool GRAM>
+// F16 = false: every matrix product on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, RN_POTGNN_MFMA=f32 or the range guard's
+// fallback): f32 weight fragments, f32 operand tiles as they land, no prescales; PRE and GRAM are then false
+template <bool PAD, bool PRE, bool GRAM, bool F16 = true>
 __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a) {
+  static_assert(F16 || (!PRE && !GRAM), "the exact-f32 instantiation keeps float32 rows and the in-loop cross term");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NRT = GRAM ? PS_NRT_GRAM : PS_NRT, RING = NRT * 16;
   // ring row / tile slot arithmetic: a mask for the power-of-two ring, compare-and-subtract (x < 2 capacity) otherwise
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   };
   const Graph &g = a.g;
   const PsLds L = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows, GRAM);
+  auto wsc = [&](int i) { return F16 ? a.w.mfma_scale_c[i] : 1.0f; };  // the split-f16 products' power-of-two prescale pairs (s, 1 / s)
   float *ring = reinterpret_cast<float *>(smem_raw + L.ring);   // [PS_RING][LDQ] folded source rows, |q|^2 in the pad
   float *qnp = reinterpret_cast<float *>(smem_raw + L.qnp);     // [PS_RING][4] per-producer parts of |q|^2 / 2Fe
   float *bufP = reinterpret_cast<float *>(smem_raw + L.bufP);   // [2][16][LDQ] P' rows of a round
@@ -367,13 +371,13 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 
   // ---- once per launch: LayerNorm parameters, the tile topology, the round -> source tile table
   for (int c = tid; c < 2 * FP; c += PS_THREADS) {
-    s_c2b[c] = a.w.c2_bias_c[c] * a.w.mfma_scale_c[4];  // (in the c2 weight's prescale: the accumulator's seed as it is)
+    s_c2b[c] = a.w.c2_bias_c[c] * wsc(4);  // (in the c2 weight's prescale: the accumulator's seed as it is)
     const float gam = a.w.c3_norm_1s.g[c];  // c3_norm_1's scale times the gate's exp2 factor (-log2e | 2 log2e)
     // The producers leave their accumulators in the weights' power-of-two prescale: P' rows carry 1/inv4, Q' rows are
     // multiplied by gamma / s5 as they go to the ring, c2 rows carry 1/invc2 (LayerNorm does not see it: eps scaled)
-    s_g3q[c] = gam * a.w.mfma_scale_c[3];
+    s_g3q[c] = gam * wsc(3);
     // pd = p / gamma * (2 / 2Fe) from a stored P' row: pd . (q gamma) is the cross term of the variance
-    s_igp[c] = ((c % FP) < a.d.Fe) ? a.w.mfma_scale_c[1] / gam * (1.0f / (float)a.d.Fe) : 0.0f;
+    s_igp[c] = ((c % FP) < a.d.Fe) ? wsc(1) / gam * (1.0f / (float)a.d.Fe) : 0.0f;
   }
   for (int r = tid; r < maxR16; r += PS_THREADS) qb[r] = g.edge_b[eo0 + min(r, max(R - 1, 0))];
   for (int i = tid; i < D; i += PS_THREADS) {
@@ -414,10 +418,10 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     const int colbase = wave * 32;  // this wave's 32 of the 128 pre-activation columns
     // (uniform values: kept in SGPRs -- as VGPR operands of packed multiplies each would cost a register pair)
     auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-    const float s4 = uni(a.w.mfma_scale_c[0]);
-    const float s5 = uni(a.w.mfma_scale_c[2]), inv5 = uni(a.w.mfma_scale_c[3]);
-    const float sc2 = uni(a.w.mfma_scale_c[4]);
-    WaveB<true> bW4, bW5, bWc;
+    const float s4 = uni(wsc(0));
+    const float s5 = uni(wsc(2)), inv5 = uni(wsc(3));
+    const float sc2 = uni(wsc(4));
+    WaveB<F16> bW4, bW5, bWc;
     bW4.load(a.w.c3_WeT_c, 4 * FP, colbase, l15, quad, s4);
     bW5.load(a.w.c3_WeT_c + 2 * FP, 4 * FP, colbase, l15, quad, s5);
     bWc.load(a.w.c2_WT_c, 2 * FP, colbase, l15, quad, sc2);
@@ -455,14 +459,19 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       const unsigned tb = atile_a + (unsigned)(buf * PS_BUF) * 4u;
       const unsigned sa = tb + (unsigned)(wave * 256 + ln * 4) * 4u;
       f32x4 u, v, w;
-      if constexpr (!PRE) {
+      if constexpr (!PRE && F16) {
         lds_read3(sa, sa + 2 * PS_TILE * 4, sa + 3 * PS_TILE * 4, u, v, w);
         write_pair(tb, row, phys, u);
         write_pair(tb + 2 * PS_TILE * 4, row, phys, v);
         write_pair(tb + 3 * PS_TILE * 4, row, phys, w);
       }
       lds_read2(sa + PS_TILE * 4, atile_a + (unsigned)(2 * PS_BUF + wave * 256 + ln * 4) * 4u, u, v);
-      write_pair(tb + PS_TILE * 4, row, phys, u * v);
+      if constexpr (F16) {
+        write_pair(tb + PS_TILE * 4, row, phys, u * v);
+      } else {  // (float32 tiles: the product replaces node[b]'s slot as it is)
+        const f32x4 pr = u * v;
+        lds_write4(sa + PS_TILE * 4, float4{pr[0], pr[1], pr[2], pr[3]});
+      }
     };
     static_assert(PS_MAXNEW == 2, "split_landed / request are written for two source tiles per step");
 
@@ -548,9 +557,16 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       {
         f32x4 accP[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (cur.has_dest) {
-          f16x8 ah[2], al[2];
-          load_pair_a(tb_a, l15, quad, ah, al);
-          if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
+          if constexpr (F16) {
+            f16x8 ah[2], al[2];
+            load_pair_a(tb_a, l15, quad, ah, al);
+            if (!(RN_PS_PROBE & 2)) bW4.product_split(ah, al, accP);
+          } else {
+            float af[KS];
+            f32x4 unused0, unused1;
+            load_f32_a2(tb_a, l15, quad, af, lnp_a, lnp_a, unused0, unused1);
+            if (!(RN_PS_PROBE & 2)) bW4.product(af, accP);
+          }
         }
         seeds_landed(accP);
         if (cur.has_dest) {
@@ -567,11 +583,17 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qS[1]) : "v"(q_src + 16) : "memory");
       }
       if (cur.has_dest) {
-        f16x8 ah[2], al[2];
         f32x4 accC[2];
-        load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (unsigned)mycol * 4u, lnp_a + (unsigned)(mycol + 16) * 4u,
-                     accC[0], accC[1]);  // + the centred c2 bias
-        if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
+        if constexpr (F16) {
+          f16x8 ah[2], al[2];
+          load_pair_a2(tb_a + PS_TILE * 4, l15, quad, ah, al, lnp_a + (unsigned)mycol * 4u, lnp_a + (unsigned)(mycol + 16) * 4u,
+                       accC[0], accC[1]);  // + the centred c2 bias
+          if (!(RN_PS_PROBE & 2)) bWc.product_split(ah, al, accC);
+        } else {
+          float af[KS];
+          load_f32_a2(tb_a + PS_TILE * 4, l15, quad, af, lnp_a + (unsigned)mycol * 4u, lnp_a + (unsigned)(mycol + 16) * 4u, accC[0], accC[1]);
+          if (!(RN_PS_PROBE & 2)) bWc.product(af, accC);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           *reinterpret_cast<f32x4 *>(bufC + (slot0 + l15) * LDQ + mycol + 16 * t) = accC[t];
@@ -595,10 +617,17 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       {
         f32x4 accQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, g3v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (ntl > 0) {
-          f16x8 ah[2], al[2];
-          load_pair_a2(tb_a + (unsigned)(2 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
-                       lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);  // + s_g3q
-          if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+          if constexpr (F16) {
+            f16x8 ah[2], al[2];
+            load_pair_a2(tb_a + (unsigned)(2 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
+                         lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);  // + s_g3q
+            if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+          } else {
+            float af[KS];
+            load_f32_a2(tb_a + (unsigned)(2 * PS_TILE) * 4u, l15, quad, af, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
+                        lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);
+            if (!(RN_PS_PROBE & 2)) bW5.product(af, accQ);
+          }
         }
         // (issued after this step's requests: everything of this wave has landed then -- the requests are ~2000 cycles old)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qS[0]), "+v"(qS[1]), "+v"(accQ[0]), "+v"(accQ[1])::"memory");
@@ -617,11 +646,18 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         const unsigned oq = (unsigned)lds_read1(ints_a + (unsigned)min(cur.tt1 * 16 + l15, R - 1) * 4u) * (6 * FP) + mycol;  // qb[]
 #pragma unroll
         for (int t = 0; t < 2; ++t) qS[t] = *reinterpret_cast<const f32x4 *>(np3_q + oq + 16 * t);
-        f16x8 ah[2], al[2];
         f32x4 accQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, g3v[2];
-        load_pair_a2(tb_a + (unsigned)(3 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
-                     lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);
-        if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+        if constexpr (F16) {
+          f16x8 ah[2], al[2];
+          load_pair_a2(tb_a + (unsigned)(3 * PS_TILE) * 4u, l15, quad, ah, al, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
+                       lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);
+          if (!(RN_PS_PROBE & 2)) bW5.product_split(ah, al, accQ);
+        } else {
+          float af[KS];
+          load_f32_a2(tb_a + (unsigned)(3 * PS_TILE) * 4u, l15, quad, af, lnp_a + (unsigned)(2 * FP + mycol) * 4u,
+                      lnp_a + (unsigned)(2 * FP + mycol + 16) * 4u, g3v[0], g3v[1]);
+          if (!(RN_PS_PROBE & 2)) bW5.product(af, accQ);
+        }
         q_tile_finish(accQ, g3v, cur.slot1 * 16 + l15);
       }
       if constexpr (GRAM) {
@@ -703,8 +739,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   const int c0 = 4 * l15;                   // lane l15 of a group owns columns c0 .. c0 + 3 of the filter and of the core half
   const int nvalid = min(max(a.d.Fe - c0, 0), 4);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
-  const float spscale = a.w.mfma_scale_c[1] * a.w.mfma_scale_c[1] * inv2n;  // P' rows arrive prescaled (see s_g3)
-  const float eps_c2 = 1e-5f * a.w.mfma_scale_c[4] * a.w.mfma_scale_c[4];     // so do the c2 rows
+  const float spscale = wsc(1) * wsc(1) * inv2n;  // P' rows arrive prescaled (see s_g3q)
+  const float eps_c2 = 1e-5f * wsc(4) * wsc(4);   // so do the c2 rows
   f32x2 bf2[2], bc2[2];  // c3_norm_1's shift with the exp2 scale of the gate folded in
   {
     const Vec4<float> bf = load4<float>(a.w.c3_norm_1s.b + c0), bc = load4<float>(a.w.c3_norm_1s.b + FP + c0);
@@ -730,8 +766,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {  // p gamma from a stored P' row (which carries the weights' prescale)
-    g3f.v[k] *= a.w.mfma_scale_c[1];
-    g3c.v[k] *= a.w.mfma_scale_c[1];
+    g3f.v[k] *= wsc(1);
+    g3c.v[k] *= wsc(1);
   }
   // (not GRAM) the fold of a P' row for the cross term, 1 / gamma * 2 / 2Fe: the producers' table (written before the barrier)
   Vec4<float> igf = load4<float>(s_igp + c0), igc = load4<float>(s_igp + FP + c0);
@@ -1020,16 +1056,18 @@ bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back, int ring, in
 }
 
 void launch_edge_ps(const float *edge_in, float *edge_out, const float *node, const float *np3, float *agg_out, int S,
-                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows) {
+                    const Graph &g, Dims d, const PassW<float> &w, int *fail, hipStream_t st, bool pair_rows, bool f16) {
   if (S == 0 || g.E == 0) return;
   EdgePsArgs a{edge_in, edge_out, node, np3, agg_out, fail, S, g, d, w};
-  const bool gram = g.pt_gram != 0;
+  const bool gram = g.pt_gram != 0 && f16;
+  if (!f16) pair_rows = false;
   const size_t lds = ps_lds(g.pt_max_out_rows, g.pt_max_in_rows, gram).total;
   const bool pad = d.Fe != d.FeP;
-  auto kern = gram ? (pair_rows ? (pad ? &edge_block_ps_kernel<true, true, true> : &edge_block_ps_kernel<false, true, true>)
-                                : (pad ? &edge_block_ps_kernel<true, false, true> : &edge_block_ps_kernel<false, false, true>))
-                   : (pair_rows ? (pad ? &edge_block_ps_kernel<true, true, false> : &edge_block_ps_kernel<false, true, false>)
-                                : (pad ? &edge_block_ps_kernel<true, false, false> : &edge_block_ps_kernel<false, false, false>));
+  auto kern = !f16 ? (pad ? &edge_block_ps_kernel<true, false, false, false> : &edge_block_ps_kernel<false, false, false, false>)
+              : gram ? (pair_rows ? (pad ? &edge_block_ps_kernel<true, true, true> : &edge_block_ps_kernel<false, true, true>)
+                                  : (pad ? &edge_block_ps_kernel<true, false, true> : &edge_block_ps_kernel<false, false, true>))
+                     : (pair_rows ? (pad ? &edge_block_ps_kernel<true, true, false> : &edge_block_ps_kernel<false, true, false>)
+                                  : (pad ? &edge_block_ps_kernel<true, false, false> : &edge_block_ps_kernel<false, false, false>));
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int cus = 0;
   if (cus == 0) {
