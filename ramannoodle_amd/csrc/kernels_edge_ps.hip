@@ -82,6 +82,10 @@ struct EdgePsArgs {
 #ifndef RN_PS_CPRIO
 #define RN_PS_CPRIO 2  // s_setprio of a consumer wave outside its triplet loop (+0.6 %: profiles/r04/edge_ps_experiments.txt)
 #endif
+#ifndef RN_PS_TICKET
+#define RN_PS_TICKET 1  // 1: a consumer wave takes the next QUARTER round (four destinations) off a shared counter instead of
+#endif                  // owning every other round with three fixed partners: the wave slots the arbiter serves first simply
+                        // take more quarters, and nobody waits for a round while a slower wave still works on the one before
 #ifndef RN_PS_LPRIO
 #define RN_PS_LPRIO 1  // s_setprio of a consumer wave in the SECOND half of its triplet loop (first half: 0).  The two consumer
 #endif                 // waves of a SIMD work on consecutive rounds; at equal priority the arbiter serves the older wave slot
@@ -128,7 +132,7 @@ constexpr int PS_CSET = 4;   // consumer waves per set (even rounds: waves 4-7, 
 constexpr unsigned PS_FAILBIT = 0x80000000u;  // in the C_READY word: a bounded wait ran out, everything stored from now on is NaN
 
 // byte offsets of the signalling words
-enum { C_SPLIT = 0, C_NORM = 16, C_READY = 32, C_FREE0 = 48, C_FREE1 = 64, C_RD0 = 80, C_RD1 = 96 };
+enum { C_SPLIT = 0, C_NORM = 16, C_READY = 32, C_FREE0 = 48, C_FREE1 = 64, C_RD0 = 80, C_RD1 = 96, C_TICKET = 112 };
 
 struct PsLds {
   size_t ring, qnp, bufP, bufC, atile, lnp, ints, sync, gram, total;
@@ -735,7 +739,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   // ============================================================================================= CONSUMER
   const int cw = wave - PS_PROD;            // 0..7
   const int cset = cw >> 2;                 // 0: the even global rounds, 1: the odd ones
-  const int slot = 4 * (cw & 3) + quad;     // the destination of a round this 16-lane group owns
   const int c0 = 4 * l15;                   // lane l15 of a group owns columns c0 .. c0 + 3 of the filter and of the core half
   const int nvalid = min(max(a.d.Fe - c0, 0), 4);
   const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
@@ -773,22 +776,36 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   Vec4<float> igf = load4<float>(s_igp + c0), igc = load4<float>(s_igp + FP + c0);
   const float *ringc = ring + c0;
   const int sdelta = 2 * FP - c0;  // from this lane's filter columns of a row to the row's |q|^2
-  // this set's first round: global round `cset` = (unit u, local round r); ub = ring row of unit u's first source row
-  int u = 0, r = cset, ub = 0;
-  const int ustep = (nrt * 16) % RING;  // ring rows from one unit's first source row to the next unit's
-  while (r >= nrounds) {
-    r -= nrounds;
-    ++u;
-    ub = (int)wrap_row((unsigned)(ub + ustep));
-  }
+  // Which round a wave works on.  RN_PS_TICKET: the next quarter round off the workgroup's counter (quarter q = destinations
+  // 4 (q & 3) .. + 3 of global round q >> 2); else the wave's set owns every other round and the wave a fixed quarter of it.
+  // Global round gr = (unit u, local round r); ub = ring row of unit u's first source row.
+  const unsigned total_rounds = (unsigned)nunits * (unsigned)nrounds;
+  auto locate = [&](unsigned gr, int &u, int &r, int &ub) {  // (uniform arithmetic, once per round)
+    u = (int)(gr / (unsigned)nrounds);
+    r = (int)(gr - (unsigned)u * (unsigned)nrounds);
+    ub = (int)(((unsigned)u * (unsigned)(nrt % NRT)) % (unsigned)NRT) * 16;
+  };
+  int u = 0, r = 0, ub = 0;
   bool poisoned = false;  // a bounded wait ran out in this workgroup: store NaN from here on
 #if RN_PS_TIMING
   long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
   const bool timed = blockIdx.x == 0 && (cw & 3) == 0 && lane == 0;  // one wave of either set
   unsigned tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tn = 0;
 #endif
-  for (unsigned gr = (unsigned)cset; u < nunits; gr += 2) {
+  for (unsigned turn = 0;; ++turn) {
     PS_T0();
+    unsigned gr;
+    int slot;  // the destination of the round this 16-lane group owns
+    if (RN_PS_TICKET) {
+      const unsigned q = ps_arrive_ticket(sync_a + C_TICKET, lane);
+      gr = q >> 2;
+      slot = 4 * (int)(q & 3u) + quad;
+    } else {
+      gr = 2u * turn + (unsigned)cset;
+      slot = 4 * (cw & 3) + quad;
+    }
+    if (gr >= total_rounds) break;
+    locate(gr, u, r, ub);
     poisoned |= (ps_wait_ge(sync_a + C_READY, gr + 1u, sync_a + C_READY, a.fail, 4) & PS_FAILBIT) != 0;
     PS_TICK(10);
     const int64_t erow0 = (int64_t)(sg + u * nsg) * g.E;
@@ -965,7 +982,10 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 #if RN_PS_CPRIO
     __builtin_amdgcn_s_setprio(RN_PS_CPRIO);
 #endif
-    // this wave no longer reads the ring rows of round gr (all its LDS reads are complete: ps_arrive waits for them)
+    // this wave no longer reads the ring rows of round gr (all its LDS reads are complete: ps_arrive waits for them).  The
+    // counter is cumulative over the rounds of gr's parity, and a producer reads "count >= 4 n" as "the first n of them are
+    // finished": so a wave adds its arrival for round gr only when every arrival for the earlier ones is in (it almost always is).
+    poisoned |= (ps_wait_ge(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), (unsigned)PS_CSET * (gr >> 1), sync_a + C_READY, a.fail, 6) & PS_FAILBIT) != 0;
     ps_arrive(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), lane);
     if (active) {
       const Vec4<float> a4 = {{acc[0], acc[1], acc[2], acc[3]}};
@@ -992,12 +1012,6 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       }
     }
     PS_TICK(13);
-    r += 2;
-    while (r >= nrounds) {
-      r -= nrounds;
-      ++u;
-      ub = (int)wrap_row((unsigned)(ub + ustep));
-    }
   }
   PS_TFLUSH(10, 13, cset ? 6 : 0);  // (set A: slots 10-13, set B: 16-19)
 }
