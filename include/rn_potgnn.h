@@ -374,6 +374,17 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * EdgeBlocks, the NodeBlocks and the readout; needs bits 8 and 9; RN_POTGNN_PAIR_ROWS=0 at create time keeps float32 rows. */
 int rn_potgnn_config_flags(const rn_potgnn *h);
 
+/*
+ * Host-only (no device is touched): the schedule check the library runs per atom tile before it lets the role-specialised
+ * EdgeBlock (csrc/kernels_edge_ps.hip) take a graph.  rb[i], re[i] = first and end source row of destination i of the tile
+ * (destinations sorted by atom, rows counted within the tile); back = rounds that may still read the ring when a step
+ * rewrites it (2 or 3); ring_tiles = the ring's capacity in 16-row tiles (8; 7 for the GRAM instantiation).  Returns 1 when
+ * the producers' schedule holds (never more than two source tiles per step, no ring slot rewritten under a round in
+ * flight), 0 when not, a negative rn_status on bad arguments; *window (optional) = the most tiles one round's source rows span.
+ */
+int rn_potgnn_debug_ps_schedule(const int32_t *rb, const int32_t *re, int32_t num_destinations, int32_t back,
+                                int32_t ring_tiles, int32_t *window);
+
 /* Number of edge triplets T of the frozen graph. */
 int64_t rn_potgnn_num_triplets(const rn_potgnn *h);
 

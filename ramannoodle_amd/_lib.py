@@ -79,6 +79,7 @@ SIGNATURES = {
     "rn_potgnn_train_backward_f64": (C.c_int, [_P, _P, _P]),
     "rn_potgnn_num_triplets": (C.c_int64, [_P]),
     "rn_potgnn_debug_triplets": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "rn_potgnn_debug_ps_schedule": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "rn_potgnn_debug_stage": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t,
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rn_potgnn_set_profiling": (C.c_int, [_P, C.c_int]),

@@ -3093,6 +3093,15 @@ int rn_potgnn_config_flags(const rn_potgnn *h) {
   return flags | (fast ? 2 : 0);
 }
 
+int rn_potgnn_debug_ps_schedule(const int32_t *rb, const int32_t *re, int32_t num_destinations, int32_t back, int32_t ring_tiles,
+                                int32_t *window) {
+  if (!rb || !re || num_destinations < 0 || back < 1 || back > 8 || ring_tiles < 1 || ring_tiles > 64) return RN_ERR_INVALID_ARGUMENT;
+  int w = 0;
+  const bool ok = edge_ps_tile_ok(rb, re, num_destinations, back, ring_tiles, &w);
+  if (window) *window = w;
+  return ok ? 1 : 0;
+}
+
 int64_t rn_potgnn_num_triplets(const rn_potgnn *h) { return h ? h->g.T : -1; }
 
 int rn_potgnn_debug_triplets(rn_potgnn *h, int32_t *idx_i, int32_t *idx_j, int32_t *idx_k,

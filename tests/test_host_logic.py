@@ -527,3 +527,46 @@ def test_role_split_producers_leave_in_flight_registers_alone():
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert " 0 violation(s)" in out.stdout and "0 in-flight loads" not in out.stdout
+
+
+def _tile_rows(atoms, degree):
+    """First / end source row of every destination of a tile of `atoms` atoms with `degree` in- and out-edges each."""
+    rb = np.repeat(np.arange(atoms) * degree, degree).astype(np.int32)
+    return rb, (rb + degree).astype(np.int32)
+
+
+def test_role_split_schedule_check_on_the_host():
+    """The schedule check behind the role-specialised EdgeBlock (``rn_potgnn_debug_ps_schedule``, host-only: it is what
+    decides at model creation whether a graph takes ``csrc/kernels_edge_ps.hip``, and with how much lookahead).  On the
+    benchmark cell's tile -- 8 atoms with 18 in- and out-edges, 9 rounds of 16 destinations -- the ring must
+    hold 5 / 6 / 7 tiles for 1 / 2 / 3 rounds still reading when a step rewrites it, a round's window spans at most 3
+    tiles, and a 47-neighbour atom (TiO2 at 5 A) does not fit the 8-tile ring at all."""
+    import ctypes as C
+    from ramannoodle_amd import _lib
+    lib = _lib.load()
+
+    def check(rb, re, back, ring):
+        window = C.c_int32(-1)
+        rc = lib.rn_potgnn_debug_ps_schedule(C.c_void_p(rb.ctypes.data), C.c_void_p(re.ctypes.data), len(rb), back, ring,
+                                             C.byref(window))
+        assert rc in (0, 1), rc
+        return bool(rc), window.value
+
+    rb, re = _tile_rows(8, 18)
+    need = {}
+    for back in (1, 2, 3):
+        need[back] = next(ring for ring in range(1, 17) if check(rb, re, back, ring)[0])
+        assert all(check(rb, re, back, ring)[0] for ring in range(need[back], 17))  # (monotone in the capacity)
+    assert need == {1: 5, 2: 6, 3: 7}
+    assert check(rb, re, 3, 8) == (True, 3) and check(rb, re, 3, 7) == (True, 3) and not check(rb, re, 3, 6)[0]
+    # fewer neighbours (a round of 16 destinations then spans three or four atoms); a ragged tile is decided without a device too
+    assert check(*_tile_rows(16, 6), 3, 8) == (True, 3)
+    rng = np.random.default_rng(3)
+    deg = rng.integers(1, 12, size=10)
+    start = np.concatenate([[0], np.cumsum(deg)])
+    rb_r = np.repeat(start[:-1], deg).astype(np.int32)
+    re_r = np.repeat(start[1:], deg).astype(np.int32)
+    assert check(rb_r, re_r, 2, 8)[0]
+    # TiO2 at 5 A: 47 out-edges per atom -- a round's window spans seven tiles, two rounds in flight need nine
+    assert check(*_tile_rows(4, 47), 2, 8) == (False, 7) and check(*_tile_rows(4, 47), 2, 9)[0]
+    assert lib.rn_potgnn_debug_ps_schedule(None, None, 0, 2, 8, None) < 0
