@@ -2495,12 +2495,21 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
   }
   if (S == 0) return RN_OK;
   return guarded(h, [&]() {
-    const size_t pb = (size_t)S * h->cfg.num_atoms * 3 * sizeof(double);
-    h->io_pos.ensure(pb);
+    const size_t frame_b = (size_t)h->cfg.num_atoms * 3 * sizeof(double);
+    h->io_pos.ensure((size_t)S * frame_b);
     h->io_alpha.ensure((size_t)S * 9 * sizeof(double));
-    HIP_TRY(hipMemcpy(h->io_pos.p, positions, pb, hipMemcpyHostToDevice));
-    forward_device<float>(h, h->io_pos.as<double>(), S, h->io_alpha.as<double>(), nullptr, nullptr,
-                          nullptr, true);
+    // Caller-owned (usually pageable) host memory: the copy of work chunk k + 1 blocks this thread while the kernels of
+    // chunk k run (they are enqueued on the handle's own non-blocking streams, which a blocking hipMemcpy does not wait
+    // for), so only the first chunk's transfer is exposed: 10 000 frames of 256 atoms are 61 MB, ~10 ms of PCIe.
+    // (the kernels are ordered behind a stream of the handle's own, not the null stream: a blocking copy waits for that one)
+    if (!h->exec_stream) HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
+    const int64_t chunk = std::max<int64_t>(1, h->chunk);
+    for (int64_t first = 0; first < S; first += chunk) {
+      const int64_t n = std::min<int64_t>(chunk, S - first);
+      double *d_pos = h->io_pos.as<double>() + first * h->cfg.num_atoms * 3;
+      HIP_TRY(hipMemcpy(d_pos, positions + first * h->cfg.num_atoms * 3, (size_t)n * frame_b, hipMemcpyHostToDevice));
+      forward_device<float>(h, d_pos, n, h->io_alpha.as<double>() + first * 9, nullptr, nullptr, h->exec_stream, first + n >= S);
+    }
     HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
   });
 }
@@ -2533,7 +2542,7 @@ int rn_potgnn_calc_polarizabilities_async(rn_potgnn *h, const double *positions,
   return guarded(h, [&]() {
     if (!h->copy_stream) {
       HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
+      if (!h->exec_stream) HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
       for (auto &sl : h->slots) {
         HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
