@@ -2247,13 +2247,16 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       // One variant of the kernel for a partition: {gram, back}.  GRAM (the LayerNorm cross terms on the matrix pipe) has a ring
       // of 7 tiles and needs every round's window to span <= 3 of them, every destination <= 32 source rows, and its tables
       // inside the CU's LDS; back = 3 (the producers three rounds ahead of the slower consumer set) needs the room in the ring.
+      // (back = 4: with eight destinations per consumer wave four rounds are in flight at a time -- the eight-lane form of
+      //  the kernel --, and a step that may only rewrite the ring behind round g - 4 would stall the producers)
       struct Variant { bool gram; int back; double factor; };
-      const Variant variants[4] = {{true, 3, 0.88}, {true, 2, 0.94}, {false, 3, 1.0}, {false, 2, 1.07}};
+      const int max_back = getenv("RN_POTGNN_PS_BACK") ? atoi(getenv("RN_POTGNN_PS_BACK")) : 4;
+      const Variant variants[5] = {{true, 3, 0.88}, {true, 2, 0.94}, {false, 4, 0.96}, {false, 3, 1.0}, {false, 2, 1.07}};
       for (size_t budget = forced > 0 ? forced : 8; budget <= (size_t)(forced > 0 ? forced : 1024); budget += 2) {
         const int mr = build_tiles(budget, tb);
         const int ntiles = (int)tb.size() - 1;
         for (const Variant &v : variants) {
-          if ((v.gram && !want_gram) || (v.back == 3 && !want_back3)) continue;
+          if ((v.gram && !want_gram) || (v.back == 3 && !want_back3) || v.back > max_back) continue;
           int max_in = 0, max_rounds = 1;
           bool ok = true;
           for (int t = 0; t < ntiles && ok; ++t) {

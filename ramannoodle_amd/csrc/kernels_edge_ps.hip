@@ -82,6 +82,11 @@ struct EdgePsArgs {
 #ifndef RN_PS_CPRIO
 #define RN_PS_CPRIO 2  // s_setprio of a consumer wave outside its triplet loop (+0.6 %: profiles/r04/edge_ps_experiments.txt)
 #endif
+#ifndef RN_PS_LG8
+#define RN_PS_LG8 1     // 1 (split-f16, not GRAM): EIGHT lanes per destination, eight filter + eight core columns per lane, eight
+#endif                  // destinations per wave: what a triplet costs whatever the columns a lane holds -- the row address, the
+                        // 16-lane (now 8-lane, three-step) reduction of the cross term, the variance, the rsq -- is paid once
+                        // per 16 gates instead of once per 8
 #ifndef RN_PS_TICKET
 #define RN_PS_TICKET 1  // 1: a consumer wave takes the next QUARTER round (four destinations) off a shared counter instead of
 #endif                  // owning every other round with three fixed partners: the wave slots the arbiter serves first simply
@@ -148,7 +153,9 @@ __host__ __device__ inline PsLds ps_lds(int maxR, int maxD, bool gram) {
   L.bufP = off; off += (size_t)2 * PS_ND * LDQ * 4;
   L.bufC = off; off += (size_t)2 * PS_ND * LDQ * 4;
   L.atile = off; off += ((size_t)2 * PS_BUF + PS_TILE) * 4;  // two buffers + the node[a] tile they share
-  L.lnp = off; off += (size_t)6 * FP * 4;  // what the producers read every step: the c2 bias, the Q' fold, the Gram's P' fold
+  // per-column tables: what the producers read every step (the c2 bias, the Q' fold, the P' fold of the cross term) and,
+  // where the Gram tables do not need the room, the consumers' LayerNorm / fold tables (eight-lane form: read per quarter)
+  L.lnp = off; off += (size_t)(gram ? 6 : 16) * FP * 4;
   L.ints = off; off += up((maxR16 + 7 * (size_t)maxD + 2 * rounds + 8) * 4);
   L.sync = off; off += 128;
   L.gram = off; off += gram ? (size_t)2 * PS_PROD * PS_GSTRIDE * 4 : 0;  // [2 rounds][4 producers][PS_GW tiles][16 e][16 d] partial p.q
@@ -324,6 +331,8 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   static_assert(F16 || (!PRE && !GRAM), "the exact-f32 instantiation keeps float32 rows and the in-loop cross term");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NRT = GRAM ? PS_NRT_GRAM : PS_NRT, RING = NRT * 16;
+  constexpr bool LG8 = RN_PS_LG8 && F16 && !GRAM;  // eight-lane destination groups (below)
+  constexpr unsigned CPR = LG8 ? 2u : (unsigned)PS_CSET;  // consumer waves that arrive per round (c_free, c_rd)
   // ring row / tile slot arithmetic: a mask for the power-of-two ring, compare-and-subtract (x < 2 capacity) otherwise
   auto wrap_row = [](unsigned x) -> unsigned {
     if constexpr ((RING & (RING - 1)) == 0) return x & (unsigned)(RING - 1);
@@ -342,6 +351,9 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   // per-column tables the PRODUCERS read every step: the centred c2 bias, the fold of a Q' row on its way to the ring, and
   // the fold 1 / gamma * 2 / 2Fe of a P' row for the cross term (the consumers keep theirs in registers)
   float *s_c2b = lnp, *s_g3q = lnp + 2 * FP, *s_igp = lnp + 4 * FP;
+  // (not GRAM) the consumers' tables: p gamma fold, c2_norm_1, c2_norm_2, c3_norm_2
+  float *s_g3p = lnp + 6 * FP, *s_c21g = lnp + 8 * FP, *s_c21b = lnp + 10 * FP, *s_c22g = lnp + 12 * FP, *s_c22b = lnp + 13 * FP,
+        *s_c3g = lnp + 14 * FP, *s_c3b = lnp + 15 * FP;
   int *ints = reinterpret_cast<int *>(smem_raw + L.ints);
   unsigned *sync = reinterpret_cast<unsigned *>(smem_raw + L.sync);
   const unsigned sync_a = lds_addr(sync);  // LDS byte address of the signalling words
@@ -382,6 +394,17 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     s_g3q[c] = gam * wsc(3);
     // pd = p / gamma * (2 / 2Fe) from a stored P' row: pd . (q gamma) is the cross term of the variance
     s_igp[c] = ((c % FP) < a.d.Fe) ? wsc(1) / gam * (1.0f / (float)a.d.Fe) : 0.0f;
+    if constexpr (!GRAM) {
+      s_g3p[c] = gam * wsc(1);
+      s_c21g[c] = a.w.c2_norm_1.g[c];
+      s_c21b[c] = a.w.c2_norm_1.b[c];
+      if (c < FP) {
+        s_c22g[c] = a.w.c2_norm_2.g[c];
+        s_c22b[c] = a.w.c2_norm_2.b[c];
+        s_c3g[c] = a.w.c3_norm_2.g[c];
+        s_c3b[c] = a.w.c3_norm_2.b[c];
+      }
+    }
   }
   for (int r = tid; r < maxR16; r += PS_THREADS) qb[r] = g.edge_b[eo0 + min(r, max(R - 1, 0))];
   for (int i = tid; i < D; i += PS_THREADS) {
@@ -552,7 +575,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
       PS_TICK(4);
       // ---- the P' / c2 buffers of round g were last read by round g - 2: its set has taken the rows into registers
       if (cur.has_dest)
-        ps_wait_ge(sync_a + ((cur.g & 1) ? C_FREE1 : C_FREE0), (unsigned)PS_CSET * (unsigned)(cur.g >> 1), sync_a + C_READY, a.fail, 2);
+        ps_wait_ge(sync_a + ((cur.g & 1) ? C_FREE1 : C_FREE0), CPR * (unsigned)(cur.g >> 1), sync_a + C_READY, a.fail, 2);
       PS_TICK(5);
       ln = launder(ln);
       const int l15 = ln & 15, quad = ln >> 4, mycol = colbase + 4 * quad;  // + 16 t: the four columns of tile t this lane ends up with
@@ -640,7 +663,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
         // be done.  Behind the product: hidden under it.
         if (cur.has_dest && cur.g > back) {
           const int gdone = cur.g - back - 1;  // (the rounds of its parity up to it: (gdone >> 1) + 1)
-          ps_wait_ge(sync_a + ((gdone & 1) ? C_RD1 : C_RD0), (unsigned)PS_CSET * (unsigned)((gdone >> 1) + 1), sync_a + C_READY, a.fail, 3);
+          ps_wait_ge(sync_a + ((gdone & 1) ? C_RD1 : C_RD0), CPR * (unsigned)((gdone >> 1) + 1), sync_a + C_READY, a.fail, 3);
         }
         PS_TICK(9);
         if (ntl > 0) q_tile_finish(accQ, g3v, ringrow0);
@@ -738,6 +761,266 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
 
   // ============================================================================================= CONSUMER
   const int cw = wave - PS_PROD;            // 0..7
+  if constexpr (LG8) {
+    // ---- eight lanes per destination: lane q of a group owns columns 4 q .. 4 q + 3 and 32 + 4 q .. 32 + 4 q + 3 ("chunks" 0, 1)
+    // of the filter and of the core half, a wave owns EIGHT destinations -- half a round -- and takes the next half round off
+    // the ticket counter.  Same arithmetic per column as the sixteen-lane form below; what changes is that a triplet's fixed
+    // cost (row address, cross-term reduction -- three DPP steps now --, variance, rsq) is spread over sixteen gates per lane.
+    const int l7 = lane & 7, grp = lane >> 3;
+    const float inv2n = 1.0f / (float)(2 * a.d.Fe), invn = 1.0f / (float)a.d.Fe;
+    const float spscale = wsc(1) * wsc(1) * inv2n;  // P' rows arrive prescaled (see s_g3q)
+    const float eps_c2 = 1e-5f * wsc(4) * wsc(4);   // so do the c2 rows
+    int nval[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) nval[j] = min(max(a.d.Fe - (4 * l7 + 32 * j), 0), 4);
+    f32x2 bf2[2][2], bc2[2][2];  // c3_norm_1's shift with the exp2 scale of the gate folded in
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const Vec4<float> bf = load4<float>(a.w.c3_norm_1s.b + 4 * l7 + 32 * j), bc = load4<float>(a.w.c3_norm_1s.b + FP + 4 * l7 + 32 * j);
+      bf2[j][0] = f32x2{bf.v[0], bf.v[1]};
+      bf2[j][1] = f32x2{bf.v[2], bf.v[3]};
+      bc2[j][0] = f32x2{bc.v[0], bc.v[1]};
+      bc2[j][1] = f32x2{bc.v[2], bc.v[3]};
+      // (consumed here: left pending, these loads get their vmcnt waits INSIDE the triplet loop -- their first use)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf2[j][0]), "+v"(bf2[j][1]), "+v"(bc2[j][0]), "+v"(bc2[j][1]));
+    }
+    const float *ringc = ring + 4 * l7;
+    const int sdelta = 2 * FP - 4 * l7;  // from this lane's first filter columns of a row to the row's |q|^2
+    const unsigned total_rounds = (unsigned)nunits * (unsigned)nrounds;
+    // LayerNorm of a 64-column row spread over the group's eight lanes, two chunks of four columns per lane
+    auto ln64 = [&](const Vec4<float> (&x)[2], const float *gt, const float *bt, Vec4<float> (&y)[2]) {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sum += (x[j].v[0] + x[j].v[1]) + (x[j].v[2] + x[j].v[3]);
+      const float mean = lg_sum<8>(sum) * invn;
+      float dv[2][4], qq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dv[j][k] = x[j].v[k] - mean;
+          if (PAD && k >= nval[j]) dv[j][k] = 0.f;
+          qq = fmaf(dv[j][k], dv[j][k], qq);
+        }
+      const float rstd = fast_rsq(lg_sum<8>(qq) * invn + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const Vec4<float> gv = load4<float>(gt + 4 * l7 + 32 * j), bv = load4<float>(bt + 4 * l7 + 32 * j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[j].v[k] = dv[j][k] * rstd * gv.v[k] + bv.v[k];
+      }
+    };
+    bool poisoned = false;  // a bounded wait ran out in this workgroup: store NaN from here on
+#if RN_PS_TIMING
+    long long *tacc = reinterpret_cast<long long *>(a.fail + 16);
+    const bool timed = blockIdx.x == 0 && (cw & 3) == 0 && lane == 0;  // waves 4 and 8
+    unsigned tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tn = 0;
+#endif
+    for (;;) {
+      PS_T0();
+      const unsigned tk = ps_arrive_ticket(sync_a + C_TICKET, lane);
+      const unsigned gr = tk >> 1;
+      if (gr >= total_rounds) break;
+      const int slot = 8 * (int)(tk & 1u) + grp;  // the destination of the round this 8-lane group owns
+      const int u = (int)(gr / (unsigned)nrounds), r = (int)(gr - (unsigned)u * (unsigned)nrounds);
+      const int ub = (int)(((unsigned)u * (unsigned)(nrt % NRT)) % (unsigned)NRT) * 16;  // ring row of the unit's first source row
+      poisoned |= (ps_wait_ge(sync_a + C_READY, gr + 1u, sync_a + C_READY, a.fail, 4) & PS_FAILBIT) != 0;
+      PS_TICK(10);
+      const int64_t erow0 = (int64_t)(sg + u * nsg) * g.E;
+      const bool active = r * PS_ND + slot < D;
+      const int i = min(r * PS_ND + slot, D - 1);  // (a lane group beyond the tile's last destination: zero triplets of a valid one)
+      const int64_t drow = erow0 + d_edge[i];
+      // ---- the P' row -> registers, folded for the loop: pd = p / gamma * (2 / 2Fe), pg = p * gamma;
+      //      var + eps = pd.qg + (|p|^2 / 2Fe + eps) + |q|^2 / 2Fe
+      f32x2 pf2[2][2], pc2[2][2], pdf2[2][2], pdc2[2][2];
+      float spe;
+      {
+        const float *prow = bufP + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
+        float sp = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cj = 4 * l7 + 32 * j;
+          const Vec4<float> xf = load4<float>(prow + cj), xc = load4<float>(prow + FP + cj);
+          const Vec4<float> gf = load4<float>(s_g3p + cj), gc = load4<float>(s_g3p + FP + cj);
+          const Vec4<float> jf = load4<float>(s_igp + cj), jc = load4<float>(s_igp + FP + cj);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sp += xf.v[k] * xf.v[k] + xc.v[k] * xc.v[k];  // zero-mean by construction
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            pdf2[j][hh] = f32x2{xf.v[2 * hh] * jf.v[2 * hh], xf.v[2 * hh + 1] * jf.v[2 * hh + 1]};
+            pdc2[j][hh] = f32x2{xc.v[2 * hh] * jc.v[2 * hh], xc.v[2 * hh + 1] * jc.v[2 * hh + 1]};
+            pf2[j][hh] = f32x2{xf.v[2 * hh] * gf.v[2 * hh], xf.v[2 * hh + 1] * gf.v[2 * hh + 1]};
+            pc2[j][hh] = f32x2{xc.v[2 * hh] * gc.v[2 * hh], xc.v[2 * hh + 1] * gc.v[2 * hh + 1]};
+          }
+        }
+        spe = lg_sum<8>(sp) * spscale + 1e-5f;
+      }
+      // ---- c2: gate(LayerNorm(c2_linear(node[b]*node[a]))) -> LayerNorm   (_gnn.py:223-228), before the loop: the round's
+      // P' / c2 buffers then go back to the producers.  Zero-mean pre-activation row (centred weights), exact zeros in its
+      // padded columns: its variance is the plain sum of squares (in the weights' prescale: eps scaled).
+      Vec4<float> c2v[2];
+      {
+        const float *crow = bufC + ((int)(gr & 1u) * PS_ND + slot) * LDQ;
+        Vec4<float> xf[2], xc[2];
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          xf[j] = load4<float>(crow + 4 * l7 + 32 * j);
+          xc[j] = load4<float>(crow + FP + 4 * l7 + 32 * j);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q += xf[j].v[k] * xf[j].v[k] + xc[j].v[k] * xc[j].v[k];
+        }
+        const float rstd2 = fast_rsq(lg_sum<8>(q) * inv2n + eps_c2);
+        Vec4<float> g2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cj = 4 * l7 + 32 * j;
+          const Vec4<float> gf = load4<float>(s_c21g + cj), bf = load4<float>(s_c21b + cj);
+          const Vec4<float> gc = load4<float>(s_c21g + FP + cj), bc = load4<float>(s_c21b + FP + cj);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            g2[j].v[k] = (RN_PS_PROBE & 4) ? xf[j].v[k] + xc[j].v[k]
+                                           : gate(xf[j].v[k] * rstd2 * gf.v[k] + bf.v[k], xc[j].v[k] * rstd2 * gc.v[k] + bc.v[k]);
+        }
+        if (RN_PS_PROBE & 4) {
+          c2v[0] = g2[0];
+          c2v[1] = g2[1];
+        } else {
+          ln64(g2, s_c22g, s_c22b, c2v);
+        }
+      }
+      const int rb = d_rb[i], cnt = active ? d_cnt[i] : 0, rskip = d_skip[i];
+      const int rbase = (int)wrap_row(wrap_row((unsigned)(ub + rb)));  // ring row of the destination's first source row
+      ps_arrive(sync_a + ((gr & 1u) ? C_FREE1 : C_FREE0), lane);  // this wave holds what it needs of round gr's P' / c2 buffers
+      PS_TICK(11);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      {
+        auto triplet = [&](const float *qr, float (&sumk)[8]) {
+          f32x2 qf2[2][2], qc2[2][2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float4 qfv = *reinterpret_cast<const float4 *>(qr + 32 * j), qcv = *reinterpret_cast<const float4 *>(qr + FP + 32 * j);
+            qf2[j][0] = f32x2{qfv.x, qfv.y};
+            qf2[j][1] = f32x2{qfv.z, qfv.w};
+            qc2[j][0] = f32x2{qcv.x, qcv.y};
+            qc2[j][1] = f32x2{qcv.z, qcv.w};
+          }
+          const float qs = qr[sdelta];
+          f32x2 d2 = pdf2[0][0] * qf2[0][0], d3 = pdc2[0][0] * qc2[0][0];
+          d2 = __builtin_elementwise_fma(pdf2[0][1], qf2[0][1], d2);
+          d3 = __builtin_elementwise_fma(pdc2[0][1], qc2[0][1], d3);
+          d2 = __builtin_elementwise_fma(pdf2[1][0], qf2[1][0], d2);
+          d3 = __builtin_elementwise_fma(pdc2[1][0], qc2[1][0], d3);
+          d2 = __builtin_elementwise_fma(pdf2[1][1], qf2[1][1], d2);
+          d3 = __builtin_elementwise_fma(pdc2[1][1], qc2[1][1], d3);
+          d2 += d3;
+          const float dot = lg_sum<8>(d2.x + d2.y);
+          float ve = dot + (spe + qs);
+          ve = ve > 1e-5f ? ve : 1e-5f;
+          const float rstd = fast_rsq(ve);
+          const f32x2 rstd2 = {rstd, rstd}, one2 = {1.0f, 1.0f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const f32x2 xf2 = __builtin_elementwise_fma(pf2[j][hh] + qf2[j][hh], rstd2, bf2[j][hh]);
+              const f32x2 xc2 = __builtin_elementwise_fma(pc2[j][hh] + qc2[j][hh], rstd2, bc2[j][hh]);
+              const f32x2 e1 = {fast_exp2(xf2.x), fast_exp2(xf2.y)}, e2 = {fast_exp2(xc2.x), fast_exp2(xc2.y)};
+              const f32x2 t2 = e2 + one2;  // (1 + e1)(1 + e2) = t2 + e1 t2: one fma
+              const f32x2 den = __builtin_elementwise_fma(e1, t2, t2);
+              const f32x2 rd = {fast_rcp(den.x), fast_rcp(den.y)};
+              f32x2 sk = {sumk[4 * j + 2 * hh], sumk[4 * j + 2 * hh + 1]};
+              sk = __builtin_elementwise_fma(e2 - one2, rd, sk);
+              sumk[4 * j + 2 * hh] = sk.x;
+              sumk[4 * j + 2 * hh + 1] = sk.y;
+            }
+        };
+#if RN_PS_CPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        float acc2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int tskip = rskip - rb;
+        auto row_of = [&](int t) { return ringc + __umul24(wrap_row((unsigned)(rbase + t + (t >= tskip ? 1 : 0))), (unsigned)LDQ); };
+        int t = (RN_PS_PROBE & 1) ? cnt : 0;
+        const int tmid = RN_PS_LPRIO ? ((cnt >> 1) & ~1) : 0;
+        for (; t + 1 < tmid; t += 2) {
+          triplet(row_of(t), acc);
+          triplet(row_of(t + 1), acc2);
+        }
+#if RN_PS_LPRIO
+        __builtin_amdgcn_s_setprio(RN_PS_LPRIO);
+#endif
+        for (; t + 1 < cnt; t += 2) {
+          triplet(row_of(t), acc);
+          triplet(row_of(t + 1), acc2);
+        }
+        if (t < cnt) triplet(row_of(t), acc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += acc2[k];
+      }
+      PS_TICK(12);
+#if RN_PS_CPRIO
+      __builtin_amdgcn_s_setprio(RN_PS_CPRIO);
+#endif
+      // the destination's own row (the residual): requested behind the loop (eight registers less across it), consumed after c3's LayerNorm
+      f32x4 old4[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cj = 4 * l7 + 32 * j;
+        if constexpr (PRE) {  // columns cj .. cj + 3 of group m = cj / 8: four f16 of the hi slot, four of the lo slot
+          const char *pp = reinterpret_cast<const char *>(a.edge_in + drow * FP + (cj >> 3) * 8) + (cj & 7) * 2;
+          const f16x4 hh = *reinterpret_cast<const f16x4 *>(pp), ll = *reinterpret_cast<const f16x4 *>(pp + 16);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) old4[j][k] = (float)hh[k] + (float)ll[k];
+        } else {
+          old4[j] = *reinterpret_cast<const f32x4 *>(a.edge_in + drow * FP + cj);
+        }
+      }
+      // this wave no longer reads the ring rows of round gr; arrivals ordered by round (see the sixteen-lane form)
+      poisoned |= (ps_wait_ge(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), CPR * (gr >> 1), sync_a + C_READY, a.fail, 6) & PS_FAILBIT) != 0;
+      ps_arrive(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), lane);
+      if (active) {
+        Vec4<float> a4[2], c3[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          a4[j] = Vec4<float>{{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]}};
+          if (a.agg_out) store4(a.agg_out + drow * FP + 4 * l7 + 32 * j, a4[j]);
+        }
+        if (RN_PS_PROBE & 4) {
+          c3[0] = a4[0];
+          c3[1] = a4[1];
+        } else {
+          ln64(a4, s_c3g, s_c3b, c3);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cj = 4 * l7 + 32 * j;
+          f32x4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            y[k] = (RN_PS_PROBE & 4) ? old4[j][k] + c2v[j].v[k] + c3[j].v[k] : fast_tanh(old4[j][k] + c2v[j].v[k] + c3[j].v[k]);
+            if (poisoned) y[k] = __int_as_float(0x7fc00000);
+          }
+          if constexpr (PRE) {
+            char *pp = reinterpret_cast<char *>(a.edge_out + drow * FP + (cj >> 3) * 8) + (cj & 7) * 2;
+            f16x4 hh, ll;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              hh[k] = (_Float16)y[k];
+              ll[k] = (_Float16)(y[k] - (float)hh[k]);
+            }
+            *reinterpret_cast<f16x4 *>(pp) = hh;
+            *reinterpret_cast<f16x4 *>(pp + 16) = ll;
+          } else {
+            *reinterpret_cast<f32x4 *>(a.edge_out + drow * FP + cj) = y;
+          }
+        }
+      }
+      PS_TICK(13);
+    }
+    PS_TFLUSH(10, 13, (cw >> 2) ? 6 : 0);  // (wave 4: slots 10-13, wave 8: 16-19)
+    return;
+  }
   const int cset = cw >> 2;                 // 0: the even global rounds, 1: the odd ones
   const int c0 = 4 * l15;                   // lane l15 of a group owns columns c0 .. c0 + 3 of the filter and of the core half
   const int nvalid = min(max(a.d.Fe - c0, 0), 4);
@@ -985,7 +1268,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
     // this wave no longer reads the ring rows of round gr (all its LDS reads are complete: ps_arrive waits for them).  The
     // counter is cumulative over the rounds of gr's parity, and a producer reads "count >= 4 n" as "the first n of them are
     // finished": so a wave adds its arrival for round gr only when every arrival for the earlier ones is in (it almost always is).
-    poisoned |= (ps_wait_ge(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), (unsigned)PS_CSET * (gr >> 1), sync_a + C_READY, a.fail, 6) & PS_FAILBIT) != 0;
+    poisoned |= (ps_wait_ge(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), CPR * (gr >> 1), sync_a + C_READY, a.fail, 6) & PS_FAILBIT) != 0;
     ps_arrive(sync_a + ((gr & 1u) ? C_RD1 : C_RD0), lane);
     if (active) {
       const Vec4<float> a4 = {{acc[0], acc[1], acc[2], acc[3]}};
