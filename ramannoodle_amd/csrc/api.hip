@@ -2250,8 +2250,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       // (back = 4: with eight destinations per consumer wave four rounds are in flight at a time -- the eight-lane form of
       //  the kernel --, and a step that may only rewrite the ring behind round g - 4 would stall the producers)
       struct Variant { bool gram; int back; double factor; };
-      const int max_back = getenv("RN_POTGNN_PS_BACK") ? atoi(getenv("RN_POTGNN_PS_BACK")) : 4;
-      const Variant variants[5] = {{true, 3, 0.88}, {true, 2, 0.94}, {false, 4, 0.96}, {false, 3, 1.0}, {false, 2, 1.07}};
+      const int max_back = getenv("RN_POTGNN_PS_BACK") ? atoi(getenv("RN_POTGNN_PS_BACK")) : 5;
+      const Variant variants[6] = {{true, 3, 0.88}, {true, 2, 0.94}, {false, 5, 0.94}, {false, 4, 0.96}, {false, 3, 1.0}, {false, 2, 1.07}};
       for (size_t budget = forced > 0 ? forced : 8; budget <= (size_t)(forced > 0 ? forced : 1024); budget += 2) {
         const int mr = build_tiles(budget, tb);
         const int ntiles = (int)tb.size() - 1;

@@ -125,7 +125,10 @@ namespace {
 constexpr int PS_THREADS = 768;
 constexpr int PS_PROD = 4;   // producer waves
 constexpr int PS_ND = 16;    // destinations per round (two per consumer wave)
-constexpr int PS_NRT = 8;    // ring capacity, in 16-row source tiles (GRAM instantiations: PS_NRT_GRAM)
+#ifndef RN_PS_NRT
+#define RN_PS_NRT 8   // (9 fits the CU's LDS too and buys a fifth round of lookahead: level, 6.63-6.66 against 6.65-6.67 ms per launch)
+#endif
+constexpr int PS_NRT = RN_PS_NRT;  // ring capacity, in 16-row source tiles (GRAM instantiations: PS_NRT_GRAM)
 constexpr int PS_NRT_GRAM = 7;  // ... with the Gram tables in LDS next to it: one tile less, slots wrap by compare-and-subtract
 constexpr int PS_GW = 3;     // Gram tables: source tiles a round's window may span
 constexpr int PS_GSTRIDE = PS_GW * 16 * 16;  // floats of one producer's partial table for one round: [tile][e][d]
