@@ -83,7 +83,7 @@ struct EdgePsArgs {
 #define RN_PS_CPRIO 2  // s_setprio of a consumer wave outside its triplet loop (+0.6 %: profiles/r04/edge_ps_experiments.txt)
 #endif
 #ifndef RN_PS_LG8
-#define RN_PS_LG8 1     // 1 (split-f16, not GRAM): EIGHT lanes per destination, eight filter + eight core columns per lane, eight
+#define RN_PS_LG8 1     // 1 (not GRAM): EIGHT lanes per destination, eight filter + eight core columns per lane, eight
 #endif                  // destinations per wave: what a triplet costs whatever the columns a lane holds -- the row address, the
                         // 16-lane (now 8-lane, three-step) reduction of the cross term, the variance, the rsq -- is paid once
                         // per 16 gates instead of once per 8
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(PS_THREADS) void edge_block_ps_kernel(EdgePsArgs a)
   static_assert(F16 || (!PRE && !GRAM), "the exact-f32 instantiation keeps float32 rows and the in-loop cross term");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NRT = GRAM ? PS_NRT_GRAM : PS_NRT, RING = NRT * 16;
-  constexpr bool LG8 = RN_PS_LG8 && F16 && !GRAM;  // eight-lane destination groups (below)
+  constexpr bool LG8 = RN_PS_LG8 && !GRAM;  // eight-lane destination groups (below)
   constexpr unsigned CPR = LG8 ? 2u : (unsigned)PS_CSET;  // consumer waves that arrive per round (c_free, c_rd)
   // ring row / tile slot arithmetic: a mask for the power-of-two ring, compare-and-subtract (x < 2 capacity) otherwise
   auto wrap_row = [](unsigned x) -> unsigned {
