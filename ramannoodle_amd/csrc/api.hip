@@ -37,20 +37,20 @@ int pad_pow2(int f) {
   return p;
 }
 
-// Fe padded to 64 with a narrower Fn (e.g. Fn = 32 / Fe = 64, Fn = 20 / Fe = 48): padding Fn to 64 as well puts
-// the model on the fused MFMA kernels (their masked LayerNorms handle F < FP) instead of the unfused per-stage
-// chain -- measured 15.4 -> 12.4 us per 128-atom structure (profiles/r03/width_sweep.txt).  The other
-// combinations keep the minimal power-of-two padding: at FeP = 32 the unfused chain moves half the bytes and is
-// faster than the 64-wide fused kernels (7.6 / 9.2 us).  RN_POTGNN_WIDEN=0 disables, =2 widens every 17..64.
+// Which padded widths a model runs at.  Fe padded to 64 with a narrower Fn (e.g. Fn = 32 / Fe = 64, Fn = 20 / Fe = 48): padding
+// Fn to 64 as well puts the model on the fused MFMA kernels (their masked LayerNorms handle F < FP) instead of the unfused
+// per-stage chain (round 3: 15.4 -> 12.4 us per 128-atom structure).  Since round 5 the same holds for Fe in 17..32 (below).
+// RN_POTGNN_WIDEN=0: minimal power-of-two padding everywhere; =1: round 4's policy; =3: experiment.
 void widen_for_fused(rn::Dims &d) {
-  static const int widen = getenv("RN_POTGNN_WIDEN") ? atoi(getenv("RN_POTGNN_WIDEN")) : 1;
+  static const int widen = getenv("RN_POTGNN_WIDEN") ? atoi(getenv("RN_POTGNN_WIDEN")) : 2;
   if (widen == 0) return;
   if (d.FeP == 64 && d.FnP < 64) d.FnP = 64;
-  // round 5: with the role-specialised EdgeBlock at 3.4 us the 64-wide fused kernels also beat the unfused chain at
-  // Fn in 33..64 / Fe in 17..32 (8.3 against 9.1 us per 128-atom structure; Fn <= 32 stays: 7.7 unfused against 8.3,
-  // profiles/r05/width_sweep.txt)
-  if (d.FeP == 32 && d.FnP == 64) d.FeP = 64;
-  if (widen >= 2 && d.FeP == 32 && d.FnP <= 64) d.FnP = d.FeP = 64;            // Fe in 17..32, any Fn up to 64
+  // round 5: with the role-specialised EdgeBlock at 3.2 us per structure and pass the 64-wide fused kernels (7.8 us per
+  // 128-atom structure whatever the real widths) are level with or ahead of the unfused chain for every Fe in 17..32 (7.5-7.9 us
+  // at Fn <= 32, 9.1 at Fn in 33..64: profiles/r05/width_sweep.txt), so those pad to 64 x 64 as well: one kernel family
+  // for every edge width in 17..64.  Fe <= 16 with a wide Fn stays unfused (6.0 us).  RN_POTGNN_WIDEN=1 keeps round 4's
+  // policy (only Fe in 33..64 widens Fn).
+  if (widen >= 2 && d.FeP == 32 && d.FnP >= 32 && d.FnP <= 64) d.FnP = d.FeP = 64;  // Fe in 17..32, Fn in 17..64 (Fn <= 16: 6.8 unfused against 7.7)
   if (widen >= 3 && d.FeP <= 16 && d.FnP >= 32 && d.FnP <= 64) d.FnP = d.FeP = 64;  // (experiment) Fe <= 16 with Fn in 17..64
 }
 

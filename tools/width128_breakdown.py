@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
 import bench
-for fn, fe in ((128,128),(64,128),(128,64)):
+for fn, fe in [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or ((128,128),(64,128),(128,64)):
     name=f"w{fn}x{fe}"; bench.HPARAMS[name]=(fn,fe,4)
     wl = bench.make_workload((4,2,2), 1000, name, seed=91)
     model = wl["model"](); pos = torch.tensor(wl["positions"], device="cuda")
