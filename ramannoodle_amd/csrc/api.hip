@@ -102,6 +102,7 @@ struct PackedLayout {
     size_t c2_WT, c2_bias, c2n1_g, c2n1_b, c2n2_g, c2n2_b;
     size_t c3_WnT, c3_nshift, c3_WeT, c3n1_g, c3n1_b, c3n2_g, c3n2_b;
     size_t c3n1_gs, c3n1_bs;  // c3_norm_1 with the gate's exp2 scale folded in (-log2e | 2 log2e): narrow kernels
+    size_t c2n1_gs, c2n1_bs, c1n_gs, c1n_bs;  // the same for c2_norm_1 and c1_norm (narrow kernels)
     size_t mfma_scale;        // [8] split-f16 prescales (s, 1/s): c1_WeT | W4 | W5 | c2_WT (kernels.hpp: mfma_prescale)
     size_t t_c3We, t_c3Wn, t_c2W, t_c1We, t_c1Wn;  // transposed copies [N][K] (reverse pass)
     // copies of c3_linear / c2_linear centred over their real output columns (kernels_edge_ps.hip) and the
@@ -167,7 +168,7 @@ struct rn_potgnn {
   bool keep_stages = false;
   bool debug_sync = false;  // RN_POTGNN_DEBUG_SYNC=1: synchronise + check after every kernel
   // graph
-  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin, bt_begin, pt_begin;
+  std::vector<int> edge_a, edge_b, out_ptr, in_ptr, in_edge, atom_type, tile_begin, trip_off, rev_edge, nt_begin, et_begin, bt_begin, pt_begin, in_pos;
   bool use_fused = false;
   bool use_edge2 = false;  // fused EdgeBlock in its frame-pipelined form (edge_block2_kernel + edge_c2_kernel)
   bool split_projections = true;  // RN_POTGNN_SPLIT_PROJ=0: the forward's stand-alone projections on the exact-f32 MFMA kernel
@@ -218,6 +219,7 @@ struct rn_potgnn {
   rn_potgnn_reduce_fn reducer = nullptr;  // data-parallel training: sums doubles over ranks
   void *reducer_ctx = nullptr;
   bool last_was_f64 = false;
+  bool last_in_order = false;  // the last run kept its edge rows in (b, a) order (narrow kernels)
   // profiling
   int profiling = 0;
   std::vector<TimedLaunch> timed;
@@ -348,6 +350,10 @@ void pack_weights(rn_potgnn *h, const float *w) {
     p.c3n2_b = L.take(FeP);
     p.c3n1_gs = L.take(2 * FeP);
     p.c3n1_bs = L.take(2 * FeP);
+    p.c2n1_gs = L.take(2 * FeP);
+    p.c2n1_bs = L.take(2 * FeP);
+    p.c1n_gs = L.take(2 * FnP);
+    p.c1n_bs = L.take(2 * FnP);
     p.mfma_scale = L.take(8);
     p.mfma_scale_c = L.take(8);  // (right behind mfma_scale: one copy fetches both after a device-resident step)
     p.t_c3We = L.take((size_t)4 * FeP * FeP);
@@ -460,6 +466,16 @@ void pack_weights(rn_potgnn *h, const float *w) {
       o[q.c3n1_bs + k] = -1.4426950408889634f * o[q.c3n1_b + k];
       o[q.c3n1_gs + FeP + k] = 2.0f * 1.4426950408889634f * o[q.c3n1_g + FeP + k];
       o[q.c3n1_bs + FeP + k] = 2.0f * 1.4426950408889634f * o[q.c3n1_b + FeP + k];
+      o[q.c2n1_gs + k] = -1.4426950408889634f * o[q.c2n1_g + k];
+      o[q.c2n1_bs + k] = -1.4426950408889634f * o[q.c2n1_b + k];
+      o[q.c2n1_gs + FeP + k] = 2.0f * 1.4426950408889634f * o[q.c2n1_g + FeP + k];
+      o[q.c2n1_bs + FeP + k] = 2.0f * 1.4426950408889634f * o[q.c2n1_b + FeP + k];
+    }
+    for (int k = 0; k < FnP; ++k) {
+      o[q.c1n_gs + k] = -1.4426950408889634f * o[q.c1n_g + k];
+      o[q.c1n_bs + k] = -1.4426950408889634f * o[q.c1n_b + k];
+      o[q.c1n_gs + FnP + k] = 2.0f * 1.4426950408889634f * o[q.c1n_g + FnP + k];
+      o[q.c1n_bs + FnP + k] = 2.0f * 1.4426950408889634f * o[q.c1n_b + FnP + k];
     }
   }
   {  // readout
@@ -704,6 +720,8 @@ void ensure_precision(rn_potgnn *h) {
     o.c3_norm_1 = {w + q.c3n1_g, w + q.c3n1_b};
     o.c3_norm_2 = {w + q.c3n2_g, w + q.c3n2_b};
     o.c3_norm_1s = {w + q.c3n1_gs, w + q.c3n1_bs};
+    o.c2_norm_1s = {w + q.c2n1_gs, w + q.c2n1_bs};
+    o.c1_norm_s = {w + q.c1n_gs, w + q.c1n_bs};
     o.mfma_scale = w + q.mfma_scale;
     o.c3_WeT_c = w + q.c3_WeT_c;
     o.c3_WnT_c = w + q.c3_WnT_c;
@@ -867,7 +885,8 @@ struct ChunkRun {
       }
       if (!done)
         launch_geom_rbf<T>(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0,
-                           P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
+                           P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st(), narrow());
+      h->last_in_order = narrow();  // (kernels_narrow.hip: edge rows in (b, a) order; rn_potgnn_debug_stage undoes it)
     }
     {
       Timer t(h, st(), K_NODE_INIT);
@@ -1489,6 +1508,14 @@ std::vector<DerivedOp> derived_ops(const rn_potgnn *h, int *first_stage = nullpt
     scaled(q.c3n1_b, FeP, -1.4426950408889634f, q.c3n1_bs);
     scaled(q.c3n1_g + FeP, FeP, 2.0f * 1.4426950408889634f, q.c3n1_gs + FeP);
     scaled(q.c3n1_b + FeP, FeP, 2.0f * 1.4426950408889634f, q.c3n1_bs + FeP);
+    scaled(q.c2n1_g, FeP, -1.4426950408889634f, q.c2n1_gs);
+    scaled(q.c2n1_b, FeP, -1.4426950408889634f, q.c2n1_bs);
+    scaled(q.c2n1_g + FeP, FeP, 2.0f * 1.4426950408889634f, q.c2n1_gs + FeP);
+    scaled(q.c2n1_b + FeP, FeP, 2.0f * 1.4426950408889634f, q.c2n1_bs + FeP);
+    scaled(q.c1n_g, FnP, -1.4426950408889634f, q.c1n_gs);
+    scaled(q.c1n_b, FnP, -1.4426950408889634f, q.c1n_bs);
+    scaled(q.c1n_g + FnP, FnP, 2.0f * 1.4426950408889634f, q.c1n_gs + FnP);
+    scaled(q.c1n_b + FnP, FnP, 2.0f * 1.4426950408889634f, q.c1n_bs + FnP);
   }
   transpose(L.W0T, FeP, HP, L.t_W0);
   transpose(L.W3T, HP, HP, L.t_W3);
@@ -2011,10 +2038,36 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   const bool narrow_mode = want_narrow && narrow_supported(d);
   int max_rows = 0;
   if (narrow_mode && !getenv("RN_POTGNN_TILE_KB")) {
-    const size_t per_row = edge_narrow_lds_bytes(d.Fe, 1024, 1024) / 1024 + 1;
+    const size_t per_row = edge_narrow_lds_bytes(d.Fn, d.Fe, 1024, 1024) / 1024 + 1;
     size_t budget = std::min<size_t>(256, (size_t)40 * 1024 / per_row);
     if (const char *e = getenv("RN_POTGNN_NARROW_TILE_ROWS")) budget = (size_t)std::max(1, atoi(e));  // experiment knob
     max_rows = build_tiles(std::max<size_t>(1, budget), h->tile_begin);
+    // The greedy partition fills every tile but the last (256 atoms of degree 18: eighteen tiles of 14 atoms and one
+    // of 4).  The same NUMBER of tiles with boundaries at equal shares of the edge list (14, 13, 14, 13, ...) costs
+    // the same lane slots and keeps the workgroups of a frame in step, as long as no tile exceeds the budget.
+    if (!getenv("RN_POTGNN_NARROW_TILE_ROWS") && h->tile_begin.size() > 2) {
+      const int T = (int)h->tile_begin.size() - 1;
+      std::vector<int> tb(1, 0);
+      for (int t = 1; t < T; ++t) {
+        const int64_t want = ((int64_t)E * t + T - 1) / T;
+        int n = tb.back();
+        while (n < N && h->out_ptr[n] < want) ++n;
+        tb.push_back(std::max(n, tb.back()));
+      }
+      tb.push_back(N);
+      int worst_out = 0, worst_in = 0, greedy_in = 0;
+      bool ok = true;
+      for (int t = 0; t < T; ++t) {
+        ok = ok && tb[t + 1] > tb[t];
+        worst_out = std::max(worst_out, h->out_ptr[tb[t + 1]] - h->out_ptr[tb[t]]);
+        worst_in = std::max(worst_in, h->in_ptr[tb[t + 1]] - h->in_ptr[tb[t]]);
+        greedy_in = std::max(greedy_in, h->in_ptr[h->tile_begin[t + 1]] - h->in_ptr[h->tile_begin[t]]);
+      }
+      if (ok && (size_t)worst_out <= budget && worst_in <= std::max(greedy_in, (int)budget)) {
+        h->tile_begin = tb;
+        max_rows = worst_out;
+      }
+    }
   } else if (getenv("RN_POTGNN_TILE_KB") || vpl8) {
     const size_t tile_kb = getenv("RN_POTGNN_TILE_KB") ? (size_t)atoi(getenv("RN_POTGNN_TILE_KB")) : 64;
     max_rows = build_tiles(std::max<size_t>(1, tile_kb * 1024 / row_bytes), h->tile_begin);
@@ -2211,6 +2264,8 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     h->trip_off[e + 1] = h->trip_off[e] + cnt;
   }
 
+  h->in_pos.assign(E, 0);
+  for (int i = 0; i < E; ++i) h->in_pos[h->in_edge[i]] = i;  // position of edge e in the (b, a) order
   h->rev_edge.assign(E, -1);
   for (int e = 0; e < E; ++e) {  // reverse edge (b -> a): binary search in b's sorted out-list
     const int bd = edge_b[e], ad = edge_a[e];
@@ -2304,7 +2359,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     const size_t o_a = push(hp->edge_a), o_b = push(hp->edge_b), o_op = push(hp->out_ptr),
                  o_ip = push(hp->in_ptr), o_ie = push(hp->in_edge), o_at = push(hp->atom_type),
                  o_tb = push(hp->tile_begin), o_to = push(hp->trip_off), o_rv = push(hp->rev_edge),
-                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin), o_bt = push(hp->bt_begin), o_pt = push(hp->pt_begin);
+                 o_nt = push(hp->nt_begin), o_et = push(hp->et_begin), o_bt = push(hp->bt_begin), o_pt = push(hp->pt_begin), o_ipos = push(hp->in_pos);
     hp->g_ints.ensure(ints.size() * sizeof(int));
     HIP_TRY(hipMemcpy(hp->g_ints.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const int *base = hp->g_ints.as<int>();
@@ -2316,6 +2371,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     g.out_ptr = base + o_op;
     g.in_ptr = base + o_ip;
     g.in_edge = base + o_ie;
+    g.in_pos = base + o_ipos;
     g.atom_type = base + o_at;
     g.rev_edge = base + o_rv;
     g.num_tiles = (int)hp->tile_begin.size() - 1;
@@ -2395,7 +2451,7 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
     hp->ps_fail.ensure(2048);  // [0] the failure word; timing builds (RN_PS_TIMING) keep their cycle counters from byte 64 on
     HIP_TRY(hipMemset(hp->ps_fail.p, 0, 2048));
     hp->split_projections = getenv("RN_POTGNN_SPLIT_PROJ") ? atoi(getenv("RN_POTGNN_SPLIT_PROJ")) != 0 : true;
-    hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fe, hp->g.max_tile_out_rows,
+    hp->use_narrow = narrow_mode && edge_narrow_lds_bytes(hp->d.Fn, hp->d.Fe, hp->g.max_tile_out_rows,
                                                           hp->g.max_tile_in_rows) <= (size_t)64 * 1024;
     // Chunk size and lanes.  Throughput rises monotonically with the frames per launch
     // (profiles/r01_chunk_sweep.txt, profiles/r01/overlap_experiments.txt section 7) and the
@@ -3166,6 +3222,13 @@ int rn_potgnn_debug_stage(rn_potgnn *h, int stage, int index, float *out, size_t
     if ((size_t)(r * c) > out_capacity) throw HipError{hipErrorInvalidValue, "out_capacity too small"};
     HIP_TRY(hipMemcpy2D(out, c * sizeof(float), src, ld * sizeof(float), c * sizeof(float), r,
                         hipMemcpyDeviceToHost));
+    if (h->last_in_order && r == ME && stage != 1) {  // per-edge rows of a narrow run: back to edge-id order
+      std::vector<float> tmp(out, out + r * c);
+      const int E = h->g.E;
+      for (int64_t s = 0; s < S; ++s)
+        for (int e = 0; e < E; ++e)
+          std::memcpy(out + (s * E + e) * c, tmp.data() + (s * E + h->in_pos[e]) * c, (size_t)c * sizeof(float));
+    }
     *rows = r;
     *cols = c;
   });

@@ -15,6 +15,7 @@ struct Graph {
   const int *out_ptr;  // [N+1] CSR over a: edges out_ptr[a]..out_ptr[a+1] leave a
   const int *in_ptr;   // [N+1] CSR over b
   const int *in_edge;  // [E]  edge ids entering b, ascending
+  const int *in_pos;   // [E]  inverse of in_edge: position of edge e in the (b, a) order
   const int *atom_type;  // [N]
   const int *rev_edge;   // [E]  id of the reverse edge (b -> a), or -1
   // node tiles for the edge-block kernel
@@ -74,6 +75,8 @@ struct PassW {
   Ln<T> c3_norm_1;   // [2FeP]
   Ln<T> c3_norm_2;   // [FeP]
   Ln<T> c3_norm_1s;  // [2FeP] c3_norm_1 times the gate's exp2 scales (-log2e on the filter half, 2 log2e on the core half)
+  Ln<T> c2_norm_1s;  // [2FeP] c2_norm_1 and
+  Ln<T> c1_norm_s;   // [2FnP] c1_norm in the same form (kernels_narrow.hip)
   const T *mfma_scale;  // [8] split-f16 prescales (s, 1/s) of c1_WeT | c3_WeT[:, W4] | c3_WeT[:, W5] | c2_WT (mfma_prescale)
   // c3_linear / c2_linear centred over their real output columns (LayerNorm(x) = LayerNorm(x - mean x), and the
   // mean is linear in the inputs): projections with these come out with zero row mean (kernels_edge_ps.hip)
@@ -134,7 +137,8 @@ void launch_setup(const T *emb, const T *W2, const T *b2, const T *W4, const T *
 template <typename T>
 void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
                      int lat_stride /* 0: one lattice for every frame; 9: lattice[S][9] */,
-                     const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st);
+                     const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st,
+                     bool in_order = false /* rows in (b, a) order: the narrow kernels' layout */);
 // "Pair" edge rows (float32 evaluations on the role-specialised EdgeBlock + atom-owning NodeBlock + fused readout, FeP = 64):
 // a row's 256 bytes hold, for each group m of eight columns, [f16 hi x8][f16 lo x8] with hi = f16(x), lo = f16(x - hi) --
 // the split-f16 MFMA operand itself (device_utils.hpp), written once by the kernel that produces the row instead of being
@@ -353,7 +357,7 @@ void launch_bn_running(float *running_mean, float *running_var, const float *bat
 
 // Narrow-width kernels (kernels_narrow.hip): one lane per row, compile-time (Fn, Fe) <= 16, float32.
 bool narrow_supported(Dims d);
-size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows);
+size_t edge_narrow_lds_bytes(int fn, int fe, int tile_out_rows, int tile_in_rows);
 size_t node_tiled_lds_bytes(int fn, int fe, int tile_in_rows, int tile_nodes);
 void launch_node_narrow(const float *edge, const float *node_in, float *node_out, int S, const Graph &g, Dims d,
                         const PassW<float> &w, hipStream_t st);

@@ -104,14 +104,16 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict_
                                                        int lat_stride,  // 0: one lattice; 9: one per frame
                                                        const T *__restrict__ offs, T coef,
                                                        Dims d, T *__restrict__ unit4,
-                                                       T *__restrict__ edge0) {
+                                                       T *__restrict__ edge0, int in_order) {
   __shared__ T sdist[256];
   const int64_t total = (int64_t)S * g.E;
   const int64_t r0 = (int64_t)blockIdx.x * 256;
   const int64_t row = r0 + threadIdx.x;
   T dist = 0;
   if (row < total) {
-    const int s = (int)(row / g.E), e = (int)(row % g.E);
+    const int s = (int)(row / g.E);
+    // in_order: rows in the (b, a) order of the narrow kernels (kernels_narrow.hip) -- row i of a frame is edge in_edge[i]
+    const int e = in_order ? g.in_edge[(int)(row % g.E)] : (int)(row % g.E);
     const int a = g.edge_a[e], b = g.edge_b[e];
     const T *lat = lat_base + (int64_t)s * lat_stride;  // _gnn.py:607-610: the sample's own lattice
     const double *pa = pos + ((int64_t)s * g.N + a) * 3;
@@ -149,11 +151,11 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict_
 
 template <typename T>
 void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice, int lat_stride,
-                     const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st) {
+                     const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st, bool in_order) {
   const int64_t total = (int64_t)S * g.E;
   if (total == 0) return;
   geom_rbf_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride,
-                                                                      offsets, coef, d, unit4, edge0);
+                                                                      offsets, coef, d, unit4, edge0, in_order ? 1 : 0);
 }
 // The same with the rows written as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs), FeP = 64
 __global__ __launch_bounds__(256) void geom_rbf_pairs_kernel(const double *__restrict__ pos, int S, Graph g,
@@ -214,10 +216,10 @@ void launch_geom_rbf_pairs(const double *pos, int S, const Graph &g, const float
                                                                          edge0);
 }
 template void launch_geom_rbf<float>(const double *, int, const Graph &, const float *, int,
-                                     const float *, float, Dims, float *, float *, hipStream_t);
+                                     const float *, float, Dims, float *, float *, hipStream_t, bool);
 template void launch_geom_rbf<double>(const double *, int, const Graph &, const double *, int,
                                       const double *, double, Dims, double *, double *,
-                                      hipStream_t);
+                                      hipStream_t, bool);
 
 // ============================================================================ node init
 template <typename T>

@@ -15,8 +15,11 @@
 //     them), one lane per destination edge, two barriers per frame;
 //   * readout MLP + edge tensors + per-structure mean (_gnn.py:532-539, 354-415, 658-665) in one
 //     launch, one workgroup per frame, fixed summation order (deterministic).
-// Embeddings keep the padded [rows][16] float layout of the other kernels (geometry, snapshots and
-// the reverse pass share the buffers); padded columns are written as exact zeros.
+// Embeddings keep the padded [rows][16] float layout of the other kernels; padded columns are written as exact zeros.
+// EDGE ROWS ARE IN (b, a) ORDER in this pipeline (row i of a frame = edge Graph::in_edge[i]; geom_rbf_kernel writes them
+// so, rn_potgnn_debug_stage undoes it): everything that belongs to an atom tile -- the in-edge rows the NodeBlock sums, the
+// destination rows the EdgeBlock reads and the rows it writes -- is then ONE CONTIGUOUS BLOCK of HBM; only the EdgeBlock's
+// source rows (the tile's out-edges) are gathered, a whole 64-byte line each.
 // Widths: the kernels are instantiated for compile-time widths FN, FE that are either exact (the
 // documented 5 / 14 and the 5 / 5 of the reference's own tests) or the model's widths rounded up to a
 // multiple of four (PADDED: 4, 8, 12, 16 -- every Fn, Fe <= 16 is covered).  Rounded-up columns carry
@@ -107,6 +110,27 @@ __device__ __forceinline__ void ln_gate_row(const float (&x)[2 * F], cptr g, cpt
     out[k] = gate(yf, yc);
   }
 }
+// The same for a ZERO-MEAN row (a centred Linear's output: api.hip centre_ops; padded columns exact zeros) and the norm's
+// parameters already multiplied by the gate's exp2 scales (PassW::c1_norm_s): no mean, no mask, no scale multiplies
+template <int F, int HP>
+__device__ __forceinline__ void ln_gate_row_c(const float (&x)[2 * F], cptr gs, cptr bs, float inv2n, float (&out)[F]) {
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2 * F; c += 2) {
+    q0 = fmaf(x[c], x[c], q0);
+    q1 = fmaf(x[c + 1], x[c + 1], q1);
+  }
+  const float rstd = fast_rsq(fmaf(q0 + q1, inv2n, 1e-5f));
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    const float yf = fmaf(x[k], rstd * gs[k], bs[k]);
+    float yc = fmaf(x[F + k], rstd * gs[HP + k], bs[HP + k]);
+    yc = fminf(fmaxf(yc, -43.28f), 43.28f);  // tanh is 1 to 13 digits at |c| = 15: 2 log2e * 15
+    const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
+    const float t2 = 1.0f + e2;
+    out[k] = (e2 - 1.0f) * fast_rcp(fmaf(e1, t2, t2));
+  }
+}
 template <int F, bool PADDED = false>
 __device__ __forceinline__ void ln_row1(const float (&x)[F], cptr g, cptr b, float (&out)[F], int f = F) {
   float s = 0.f;
@@ -126,6 +150,137 @@ __device__ __forceinline__ void ln_row1(const float (&x)[F], cptr g, cptr b, flo
   for (int c = 0; c < F; ++c) out[c] = fmaf(d[c], rstd * g[c], b[c]);
 }
 
+
+// ---------------------------------------------------------------- two columns per instruction
+// The gfx950 VALU has packed float32 forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE float32 operations
+// on a 64-bit register pair at the issue cost of one).  A [filter | core] row of logical width 2F is therefore kept as
+// H = ceil(F / 2) column PAIRS per half: x2[j] = filter columns (2j, 2j + 1), x2[H + j] = core columns (2j, 2j + 1).
+// The padded weight layout puts both columns of a pair next to each other on an 8-byte boundary, so a pair of weights
+// is one 64-bit scalar operand.  With F odd the last pair's second column is a padded one: zero weights, bias and
+// LayerNorm parameters keep it at exact zero (the Linears are the CENTRED copies, api.hip centre_ops: projections come
+// out with zero row mean over the real columns and exact zeros in the padded ones, so LayerNorm(2F) needs neither a mean
+// nor a mask).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) v2f *cptr2;
+__device__ __forceinline__ v2f ldw2(cptr p) { return *reinterpret_cast<cptr2>(p); }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f bcast2(float x) { return v2f{x, x}; }
+
+template <int F>
+constexpr int pairs_of() { return (F + 1) / 2; }
+
+// acc += W x for the gated columns of a padded [filter | core] weight block, two columns per instruction
+// (k outermost for the same reason as in gated_matvec: the weights of one k are consumed as they are loaded)
+template <int K, int F, int HP, int LD, int OFF>
+__device__ __forceinline__ void gated_matvec2(cptr W, const float (&x)[K], v2f (&acc)[2 * pairs_of<F>()]) {
+  constexpr int H = pairs_of<F>();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const v2f xk = bcast2(x[k]);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      acc[j] = fma2(ldw2(W + k * LD + OFF + 2 * j), xk, acc[j]);
+      acc[H + j] = fma2(ldw2(W + k * LD + OFF + HP + 2 * j), xk, acc[H + j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int F, int HP, int OFF>
+__device__ __forceinline__ void load_pairs(cptr v, v2f (&x)[2 * pairs_of<F>()]) {
+  constexpr int H = pairs_of<F>();
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    x[j] = ldw2(v + OFF + 2 * j);
+    x[H + j] = ldw2(v + OFF + HP + 2 * j);
+  }
+}
+// sum of squares of a zero-mean [filter | core] row (padded columns are exact zeros)
+template <int H2>
+__device__ __forceinline__ float sumsq2(const v2f (&x)[H2]) {
+  v2f s0 = x[0] * x[0], s1 = H2 > 1 ? x[1] * x[1] : v2f{0.f, 0.f};
+#pragma unroll
+  for (int j = 2; j < H2; j += 2) {
+    s0 = fma2(x[j], x[j], s0);
+    if (j + 1 < H2) s1 = fma2(x[j + 1], x[j + 1], s1);
+  }
+  s0 += s1;
+  return s0.x + s0.y;
+}
+// sigmoid * tanh of two columns whose pre-activations already carry the exp2 scales (-log2e | 2 log2e):
+//   (e2 - 1) / ((1 + e1)(1 + e2)),  (1 + e1)(1 + e2) = t2 + e1 t2 with t2 = 1 + e2: one fma
+template <bool CLAMP>
+__device__ __forceinline__ v2f gate2s(v2f yf, v2f yc, v2f acc = v2f{0.f, 0.f}) {  // acc + gate
+  if (CLAMP) {  // tanh is 1 to 13 digits at |c| = 15: 2 log2e * 15
+    yc.x = fminf(fmaxf(yc.x, -43.28f), 43.28f);
+    yc.y = fminf(fmaxf(yc.y, -43.28f), 43.28f);
+  }
+  const v2f e1 = {fast_exp2(yf.x), fast_exp2(yf.y)}, e2 = {fast_exp2(yc.x), fast_exp2(yc.y)};
+  const v2f t2 = e2 + 1.0f;
+  const v2f den = fma2(e1, t2, t2);
+  const v2f rd = {fast_rcp(den.x), fast_rcp(den.y)};
+  return fma2(e2 - 1.0f, rd, acc);
+}
+// LayerNorm(2F) -> gate of a zero-mean row in pairs; gs / bs: the norm's parameters times the exp2 scales
+template <int F, int HP, bool CLAMP>
+__device__ __forceinline__ void ln_gate_pairs(const v2f (&x)[2 * pairs_of<F>()], cptr gs, cptr bs, float inv2n,
+                                              v2f (&out)[pairs_of<F>()]) {
+  constexpr int H = pairs_of<F>();
+  const v2f rstd2 = bcast2(fast_rsq(fmaf(sumsq2<2 * H>(x), inv2n, 1e-5f)));
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const v2f yf = fma2(x[j], rstd2 * ldw2(gs + 2 * j), ldw2(bs + 2 * j));
+    const v2f yc = fma2(x[H + j], rstd2 * ldw2(gs + HP + 2 * j), ldw2(bs + HP + 2 * j));
+    out[j] = gate2s<CLAMP>(yf, yc);
+  }
+}
+// LayerNorm(F) of a row in pairs (F even; torch semantics); PADDED: only the first f of the F columns are real
+template <int F, bool PADDED>
+__device__ __forceinline__ void ln_pairs(const v2f (&x)[F / 2], cptr g, cptr b, v2f (&out)[F / 2], int f = F) {
+  static_assert(F % 2 == 0, "column pairs");
+  constexpr int H = F / 2;
+  v2f s = x[0];
+#pragma unroll
+  for (int j = 1; j < H; ++j) s += x[j];
+  const float inv = PADDED ? 1.0f / (float)f : 1.0f / F;
+  const v2f mean2 = bcast2((s.x + s.y) * inv);
+  v2f d[H], q = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    d[j] = x[j] - mean2;
+    if (PADDED && 2 * j >= F - 3 && 2 * j >= f) d[j].x = 0.f;
+    if (PADDED && 2 * j + 1 >= F - 3 && 2 * j + 1 >= f) d[j].y = 0.f;
+    q = fma2(d[j], d[j], q);
+  }
+  const v2f rstd2 = bcast2(fast_rsq(fmaf(q.x + q.y, inv, 1e-5f)));
+#pragma unroll
+  for (int j = 0; j < H; ++j) out[j] = fma2(d[j], rstd2 * ldw2(g + 2 * j), ldw2(b + 2 * j));
+}
+// tanh of two columns from the hardware exp2 / rcp (device_utils.hpp fast_tanh)
+__device__ __forceinline__ v2f tanh2(v2f x) {
+  const v2f t = x * (2.0f * 1.4426950408889634f);
+  const v2f e = v2f{fast_exp2(t.x), fast_exp2(t.y)} + 1.0f;
+  const v2f rc = {fast_rcp(e.x), fast_rcp(e.y)};
+  return fma2(bcast2(-2.0f), rc, bcast2(1.0f));
+}
+// a row of F (even) real columns held as pairs -> WP floats in memory, the rest zeros.  Non-temporal: the rows an
+// EdgeBlock writes are read next by another kernel, a whole trajectory chunk later -- they should not push the rows the
+// other tiles of this frame are about to read a second time out of the XCD's L2.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int F, int WP>
+__device__ __forceinline__ void store_pairs(float *p, const v2f (&x)[F / 2]) {
+#pragma unroll
+  for (int j = 0; j < WP / 4; ++j) {
+    const v2f a = 2 * j < F / 2 ? x[2 * j < F / 2 ? 2 * j : 0] : v2f{0.f, 0.f};
+    const v2f b = 2 * j + 1 < F / 2 ? x[2 * j + 1 < F / 2 ? 2 * j + 1 : 0] : v2f{0.f, 0.f};
+    __builtin_nontemporal_store(v4f{a.x, a.y, b.x, b.y}, reinterpret_cast<v4f *>(p + 4 * j));
+  }
+}
+template <int F>
+__device__ __forceinline__ void unpack_pairs(const v2f (&x)[pairs_of<F>()], float (&out)[F]) {
+#pragma unroll
+  for (int k = 0; k < F; ++k) out[k] = (k & 1) ? x[k / 2].y : x[k / 2].x;
+}
+
 }  // namespace
 
 // ============================================================================ NodeBlock
@@ -139,6 +294,8 @@ struct NodeNarrowArgs {
   // c1_linear split into its node and edge parts, transposed, padded [filter|core] (PassW layout)
   const float *__restrict__ WnT, *__restrict__ WeT, *__restrict__ bias;
   const float *__restrict__ c1g, *__restrict__ c1b, *__restrict__ fing, *__restrict__ finb;
+  // node_tiled_kernel: the centred copy of c1_linear and c1_norm times the gate's exp2 scales
+  const float *__restrict__ WnTc, *__restrict__ WeTc, *__restrict__ biasc, *__restrict__ c1gs, *__restrict__ c1bs;
 };
 
 template <int FN, int FE, bool PADDED>
@@ -163,7 +320,7 @@ __global__ __launch_bounds__(256) void node_narrow_kernel(NodeNarrowArgs a) {
   const float *erow0 = a.edge + (int64_t)s * a.g.E * FeP;
   for (int idx = beg; idx < end; ++idx) {  // ascending edge id == the reference's scatter order
     float x[FE];
-    load_row<FE>(erow0 + (int64_t)a.g.in_edge[idx] * FeP, x);
+    load_row<FE>(erow0 + (int64_t)idx * FeP, x);
     float c1[2 * FN];
 #pragma unroll
     for (int c = 0; c < 2 * FN; ++c) c1[c] = base[c];
@@ -203,7 +360,7 @@ __host__ __device__ inline NodeTiledLds node_tiled_lds(int fn, int maxD, int max
   L.stage = off; off += (size_t)2 * 256 * 16 * 4;             // 2 x [256][16] edge rows, pieces swizzled
   L.gated = off; off += up((size_t)fn * maxD * 4);            // [fn][maxD] gate outputs of the tile's in-edge rows
   L.base = off; off += up((size_t)maxN * 2 * fn * 4);         // [maxN][2 fn] W_n node[b] + bias
-  L.ints = off; off += up((size_t)2 * maxD * 4);              // global edge id, tile-local atom of every row
+  L.ints = off; off += up((size_t)maxD * 4);                  // tile-local atom of every row
   L.total = off;
   return L;
 }
@@ -211,8 +368,9 @@ __host__ __device__ inline NodeTiledLds node_tiled_lds(int fn, int maxD, int max
 template <int FN, int FE, bool PADDED>
 __global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
   constexpr int FnP = 16, FeP = 16;
-  const cptr WnT = as_const(a.WnT), WeT = as_const(a.WeT), bias = as_const(a.bias), c1g = as_const(a.c1g),
-             c1b = as_const(a.c1b), fing = as_const(a.fing), finb = as_const(a.finb);
+  const cptr WnT = as_const(a.WnTc), WeT = as_const(a.WeTc), bias = as_const(a.biasc), c1gs = as_const(a.c1gs),
+             c1bs = as_const(a.c1bs), fing = as_const(a.fing), finb = as_const(a.finb);
+  const float inv2n = PADDED ? 1.0f / (float)(2 * a.fn) : 1.0f / (2 * FN);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
   const int maxD = g.nt_max_in_rows;
@@ -220,7 +378,7 @@ __global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
   float *stage = reinterpret_cast<float *>(smem_raw + L.stage);
   float *gated = reinterpret_cast<float *>(smem_raw + L.gated);
   float *base = reinterpret_cast<float *>(smem_raw + L.base);
-  int *d_edge = reinterpret_cast<int *>(smem_raw + L.ints), *d_bl = d_edge + maxD;
+  int *d_bl = reinterpret_cast<int *>(smem_raw + L.ints);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -232,9 +390,7 @@ __global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j0 + natoms] - di0;
   const int nchunks = max((dcount + 255) / 256, 1);  // (a tile without in-edges still has its atoms to finish)
   for (int i = tid; i < dcount; i += 256) {
-    const int e = g.in_edge[di0 + i];
-    d_edge[i] = e;
-    d_bl[i] = g.edge_b[e] - j0;
+    d_bl[i] = g.edge_b[g.in_edge[di0 + i]] - j0;
   }
   __syncthreads();
   if (sg >= a.S) return;
@@ -253,7 +409,7 @@ __global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
       const int piece = (lane & 3) ^ ((row >> 2) & 3);
       const int i = min(256 * k + row, dcount - 1);
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(a.edge + (erow0 + d_edge[i]) * FeP + 4 * piece),
+          (const __attribute__((address_space(1))) void *)(a.edge + (erow0 + di0 + i) * FeP + 4 * piece),
           (__attribute__((address_space(3))) void *)(buf + (64 * wave + 16 * j) * 16), 16, 0, 0);
     }
   };
@@ -300,7 +456,7 @@ __global__ __launch_bounds__(256) void node_tiled_kernel(NodeNarrowArgs a) {
       for (int c = 0; c < 2 * FN; ++c) c1[c] = bs[c];
       gated_matvec<FE, FN, FnP, 2 * FnP, 0>(WeT, x, c1);
       float gt[FN];
-      ln_gate_row<FN, FnP, PADDED>(c1, c1g, c1b, gt, a.fn);
+      ln_gate_row_c<FN, FnP>(c1, c1gs, c1bs, inv2n, gt);
 #pragma unroll
       for (int c = 0; c < FN; ++c) gated[c * maxD + i] = gt[c];
     }
@@ -342,19 +498,20 @@ struct EdgeNarrowArgs {
   int S;
   int fe;  // the model's Fe (PADDED instantiations: FE is Fe rounded up to a multiple of four)
   Graph g;
-  // PassW layout (kernels.hpp): c3_WeT [FeP][4FeP] = (W4 | W5), c3_WnT [FnP][6FeP] = (Wi | Wj | Wk),
-  // c3_nshift [6FeP] = (0 | bias | 0), c2_WT [FnP][2FeP]
+  // PassW layout (kernels.hpp), the CENTRED copies: c3_WeT_c [FeP][4FeP] = (W4 | W5), c3_WnT_c [FnP][6FeP] = (Wi | Wj | Wk),
+  // c3_nshift_c [6FeP] = (0 | bias | 0), c2_WT_c [FnP][2FeP], c2_bias_c
   const float *__restrict__ c3WeT, *__restrict__ c3WnT, *__restrict__ c3shift, *__restrict__ c2WT,
       *__restrict__ c2bias;
   const float *__restrict__ c3n1gs, *__restrict__ c3n1bs;  // c3_norm_1 with the gate's exp2 scales folded in
   const float *__restrict__ c3n2g, *__restrict__ c3n2b;
-  const float *__restrict__ c2n1g, *__restrict__ c2n1b, *__restrict__ c2n2g, *__restrict__ c2n2b;
+  const float *__restrict__ c2n1gs, *__restrict__ c2n1bs;  // c2_norm_1 in the same form
+  const float *__restrict__ c2n2g, *__restrict__ c2n2b;
 };
 
-// LDS row stride (floats) of the centred source rows: 2 FE values + |q|^2, a multiple of 4 with an
-// odd number of 16-byte slots so that consecutive rows start on different bank groups
+// LDS row stride (floats) of the source rows Q': 2 FE values (FE even), a multiple of 4 with an odd number of
+// 16-byte slots so that consecutive rows start on different bank groups
 __host__ __device__ constexpr int narrow_ldq(int fe) {
-  int s = (2 * fe + 1 + 3) / 4 * 4;
+  int s = (2 * fe + 3) / 4 * 4;
   return ((s / 4) % 2 == 0) ? s + 4 : s;
 }
 struct NarrowLds {
@@ -364,20 +521,32 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD) {
   NarrowLds L;
   L.bufQ = 0;
   L.ints = ((size_t)maxR * narrow_ldq(fe) * 4 + 15) & ~size_t(15);
-  L.total = L.ints + (((size_t)maxR + 6 * (size_t)maxD) * 4 + 15 & ~size_t(15));
+  L.total = L.ints + ((2 * (size_t)maxR + 5 * (size_t)maxD) * 4 + 15 & ~size_t(15));
   return L;
 }
 
-// (two workgroups per SIMD keep 128 VGPRs each: enough for the exact instantiations up to 2 FE = 28 values per
-//  row; the rounded-up ones -- whose weights overflow the 102 SGPRs into VGPR lanes -- and FE = 16 take one
-//  workgroup per SIMD instead of spilling to scratch)
-template <int FN, int FE, bool FASTG, bool PADDED>
-__global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) void edge_narrow_kernel(EdgeNarrowArgs a) {
-  constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE), W2 = 2 * FE;
+// The EdgeBlock at Fn, Fe <= 16 (_gnn.py:200-351), tile-resident like the wide kernel: the source rows
+// Q'_e = W5 edge_e + Wi node[b_e] of a tile's atoms are built once per frame in LDS (one lane per row) and reused by
+// every destination edge entering those atoms; then ONE LANE PER DESTINATION EDGE d = (k -> j):
+//   P'_d = W4 edge_d + Wj node[j] + Wk node[k] + bias                      (centred Linears: zero row mean)
+//   c2   = LayerNorm(gate(LayerNorm(c2_linear(node[j] * node[k]))))         (does not depend on the triplets: done first,
+//                                                                            so only r = edge_d + c2 lives across the loop)
+//   c3   = LayerNorm(sum over the out-edges e of j, e != (j -> k), of gate(LayerNorm(P'_d + Q'_e)))
+//   out  = tanh(edge_d + c2 + c3)
+// The triplet loop is everything: 17 iterations of 2 Fe columns on the benchmark cell.  Per triplet and lane it issues
+// (Fe = 14) 7 ds_read_b128, 14 v_pk_add (z = p + q), 14 v_pk_fma (|z|^2), rsq, and per PAIR of gates 2 v_pk_mul
+// (rstd gamma), 2 v_pk_fma (+ beta), 4 v_exp, 3 packed ops + 2 v_rcp for the gate and the accumulating v_pk_fma:
+// ~10 instructions per gate, 3 of them transcendental, where the one-column-per-instruction form of rounds 3-5
+// issued 18.4.  The variance is the plain sum of squares of z (zero mean by construction): no cross term, no |q|^2.
+// CLAMP = false when the host has proven the gate arguments small (PassW::c3_fast, api.hip refresh_pass_flags).
+template <int FN, int FE, bool CLAMP, bool PADDED>
+__global__ __launch_bounds__(256, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
+  static_assert(FE % 2 == 0, "column pairs");
+  constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE), H = FE / 2, W2 = 2 * FE;
   const cptr c3WeT = as_const(a.c3WeT), c3WnT = as_const(a.c3WnT), c3shift = as_const(a.c3shift),
              c2WT = as_const(a.c2WT), c2bias = as_const(a.c2bias), c3n1gs = as_const(a.c3n1gs),
              c3n1bs = as_const(a.c3n1bs), c3n2g = as_const(a.c3n2g), c3n2b = as_const(a.c3n2b),
-             c2n1g = as_const(a.c2n1g), c2n1b = as_const(a.c2n1b), c2n2g = as_const(a.c2n2g),
+             c2n1gs = as_const(a.c2n1gs), c2n1bs = as_const(a.c2n1bs), c2n2g = as_const(a.c2n2g),
              c2n2b = as_const(a.c2n2b);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
@@ -385,7 +554,7 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   float *bufQ = reinterpret_cast<float *>(smem_raw + L.bufQ);
   int *qb = reinterpret_cast<int *>(smem_raw + L.ints);
   const int maxD = g.max_tile_in_rows;
-  int *d_edge = qb + g.max_tile_out_rows, *d_a = d_edge + maxD, *d_bl = d_a + maxD, *d_rb = d_bl + maxD,
+  int *qpos = qb + g.max_tile_out_rows, *d_a = qpos + g.max_tile_out_rows, *d_bl = d_a + maxD, *d_rb = d_bl + maxD,
       *d_cnt = d_rb + maxD, *d_skip = d_cnt + maxD;
   const int tid = threadIdx.x;
 
@@ -398,13 +567,15 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   const int di0 = g.in_ptr[j0], dcount = g.in_ptr[j1] - di0;
 
   // ---- once per launch: the tile's topology -> LDS (the graph is the same in every frame)
-  for (int r = tid; r < rows; r += 256) qb[r] = g.edge_b[eo0 + r];
+  for (int r = tid; r < rows; r += 256) {
+    qb[r] = g.edge_b[eo0 + r];
+    qpos[r] = g.in_pos[eo0 + r];
+  }
   for (int i = tid; i < dcount; i += 256) {
     const int dst = g.in_edge[di0 + i];
     const int ad = g.edge_a[dst], bd = g.edge_b[dst];
     const int rb = g.out_ptr[bd] - eo0, re = g.out_ptr[bd + 1] - eo0;
     const int rev = g.rev_edge[dst];  // edge (b_d -> a_d): its triplet (i == k) is excluded
-    d_edge[i] = dst;
     d_a[i] = ad;
     d_bl[i] = bd - j0;
     d_rb[i] = rb;
@@ -413,180 +584,83 @@ __global__ __launch_bounds__(256, ((FE <= 14 && !PADDED) || FE <= 4 ? 2 : 1)) vo
   }
   __syncthreads();
 
-  // c3_norm_1 with the exp2 scale of the gate folded in (wave-uniform values: SGPRs)
-  auto g3 = [&](int c) { return c3n1gs[gcol<FE, FeP>(c)]; };
-  auto b3 = [&](int c) { return c3n1bs[gcol<FE, FeP>(c)]; };
   const float inv2n = PADDED ? 1.0f / (float)(2 * a.fe) : 1.0f / W2;
-  // PADDED: is column c of a [filter | core] row one of the rounded-up ones?  (only the last three of a half can be)
   const int fe_rt = a.fe;
-  auto pad_col = [fe_rt](int c) { return PADDED && (c % FE) >= FE - 3 && (c % FE) >= fe_rt; };
 
   for (int s = sg; s < a.S; s += nsg) {
     const int64_t erow0 = (int64_t)s * g.E, nrow0 = (int64_t)s * g.N;
-    // ================= source rows Q'_e = W5 edge_e + Wi node[b_e], centred, (x gamma), |q|^2
-#if RN_NARROW_PRIO
-    __builtin_amdgcn_s_setprio(RN_NARROW_PRIO);  // the short source-row stage goes ahead of other waves' triplet loops
-#endif
+    // ================= source rows Q'_e = W5 edge_e + Wi node[b_e]  (zero row mean, padded columns zero)
     for (int r = tid; r < rows; r += 256) {
       float x[FE], nb[FN];
-      load_row<FE>(a.edge_in + (erow0 + eo0 + r) * FeP, x);
+      load_row<FE>(a.edge_in + (erow0 + qpos[r]) * FeP, x);
       load_row<FN>(a.node + (nrow0 + qb[r]) * FnP, nb);
-      float q[W2], sum = 0.f;
+      v2f q[2 * H];
 #pragma unroll
-      for (int c = 0; c < W2; ++c) q[c] = 0.f;
-      gated_matvec<FE, FE, FeP, 4 * FeP, 2 * FeP>(c3WeT, x, q);
-      gated_matvec<FN, FE, FeP, 6 * FeP, 0>(c3WnT, nb, q);
+      for (int c = 0; c < 2 * H; ++c) q[c] = v2f{0.f, 0.f};
+      gated_matvec2<FE, FE, FeP, 4 * FeP, 2 * FeP>(c3WeT, x, q);
+      gated_matvec2<FN, FE, FeP, 6 * FeP, 0>(c3WnT, nb, q);
+      float *row = bufQ + r * LDQ;  // [filter pairs | core pairs]: 2 FE floats
 #pragma unroll
-      for (int c = 0; c < W2; ++c) sum += q[c];
-      const float mean = sum * inv2n;
-      float ss = 0.f;
-#pragma unroll
-      for (int c = 0; c < W2; ++c) {
-        q[c] -= mean;
-        if (pad_col(c)) q[c] = 0.f;
-        ss = fmaf(q[c], q[c], ss);
+      for (int j = 0; j < H; ++j) {
+        *reinterpret_cast<v2f *>(row + 2 * j) = q[j];
+        *reinterpret_cast<v2f *>(row + FE + 2 * j) = q[H + j];
       }
-      if (FASTG) {
-#pragma unroll
-        for (int c = 0; c < W2; ++c) q[c] *= g3(c);
-        ss *= inv2n;
-      }
-      float *row = bufQ + r * LDQ;
-#pragma unroll
-      for (int j = 0; j < W2 / 4; ++j)
-        *reinterpret_cast<float4 *>(row + 4 * j) = make_float4(q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3]);
-#pragma unroll
-      for (int c = W2 / 4 * 4; c < W2; ++c) row[c] = q[c];
-      row[W2] = ss;
     }
     __syncthreads();
 
     // ================= destination edges: one lane each
-#if RN_NARROW_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     for (int i = tid; i < dcount; i += 256) {
-      const int dst = d_edge[i];
-      const float *xrow = a.edge_in + (erow0 + dst) * FeP;
-      const float *njrow = a.node + (nrow0 + j0 + d_bl[i]) * FnP, *nkrow = a.node + (nrow0 + d_a[i]) * FnP;
-      // P'_d = W4 edge_d + Wj node[j] + Wk node[k] + bias, centred.  (The three operand rows are
-      // re-read after the triplet loop instead of being kept alive across it: 24 registers.)
-      float p[W2], sum = 0.f;
+      const int64_t drow = erow0 + di0 + i;  // (b, a) order: the tile's destination rows are contiguous
+      v2f p[2 * H], r[H];  // r = edge_d + c2
       {
         float x[FE], nj[FN], nk[FN];
-        load_row<FE>(xrow, x);
-        load_row<FN>(njrow, nj);
-        load_row<FN>(nkrow, nk);
+        load_row<FE>(a.edge_in + drow * FeP, x);
+        load_row<FN>(a.node + (nrow0 + j0 + d_bl[i]) * FnP, nj);
+        load_row<FN>(a.node + (nrow0 + d_a[i]) * FnP, nk);
+        load_pairs<FE, FeP, 2 * FeP>(c3shift, p);
+        gated_matvec2<FE, FE, FeP, 4 * FeP, 0>(c3WeT, x, p);
+        gated_matvec2<FN, FE, FeP, 6 * FeP, 2 * FeP>(c3WnT, nj, p);
+        gated_matvec2<FN, FE, FeP, 6 * FeP, 4 * FeP>(c3WnT, nk, p);
+        // c2: gate(LayerNorm(c2_linear(node[j] * node[k]))) -> LayerNorm   (_gnn.py:223-228)
+        float z[FN];
 #pragma unroll
-        for (int c = 0; c < W2; ++c) p[c] = c3shift[2 * FeP + gcol<FE, FeP>(c)];
-        gated_matvec<FE, FE, FeP, 4 * FeP, 0>(c3WeT, x, p);
-        gated_matvec<FN, FE, FeP, 6 * FeP, 2 * FeP>(c3WnT, nj, p);
-        gated_matvec<FN, FE, FeP, 6 * FeP, 4 * FeP>(c3WnT, nk, p);
+        for (int k = 0; k < FN; ++k) z[k] = nj[k] * nk[k];
+        v2f c2pre[2 * H], g2p[H];
+        load_pairs<FE, FeP, 0>(c2bias, c2pre);
+        gated_matvec2<FN, FE, FeP, 2 * FeP, 0>(c2WT, z, c2pre);
+        ln_gate_pairs<FE, FeP, true>(c2pre, c2n1gs, c2n1bs, inv2n, g2p);
+        ln_pairs<FE, PADDED>(g2p, c2n2g, c2n2b, r, fe_rt);
 #pragma unroll
-        for (int c = 0; c < W2; ++c) sum += p[c];
+        for (int j = 0; j < H; ++j) r[j] += v2f{x[2 * j], x[2 * j + 1]};
       }
-      const float mean = sum * inv2n;
-      float sp = 0.f;
+      v2f acc[H];
 #pragma unroll
-      for (int c = 0; c < W2; ++c) {
-        p[c] -= mean;
-        if (pad_col(c)) p[c] = 0.f;
-        sp = fmaf(p[c], p[c], sp);
-      }
-      float acc[FE];
+      for (int j = 0; j < H; ++j) acc[j] = v2f{0.f, 0.f};
+      const int cnt = d_cnt[i];
+      const float *qr = bufQ + d_rb[i] * LDQ, *qskip = bufQ + d_skip[i] * LDQ;
+      for (int t = 0; t < cnt; ++t) {
+        if (qr == qskip) qr += LDQ;
+        v2f zz[2 * H];
 #pragma unroll
-      for (int k = 0; k < FE; ++k) acc[k] = 0.f;
-      const int rb = d_rb[i], cnt = d_cnt[i], rskip = d_skip[i];
-      if constexpr (FASTG) {
-        // pd = p / gamma * (2 / 2Fe), pg = p * gamma:  var + eps = pd.qg + (|p|^2/2Fe + eps) + |q|^2/2Fe
-        float pd[W2];
-#pragma unroll
-        for (int c = 0; c < W2; ++c) {
-          const float gam = g3(c);
-          pd[c] = p[c] * (2.0f * inv2n) / gam;
-          p[c] *= gam;
+        for (int j = 0; j < W2 / 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * j);
+          zz[2 * j] = v2f{v.x, v.y} + p[2 * j];
+          zz[2 * j + 1] = v2f{v.z, v.w} + p[2 * j + 1];
         }
-        const float spe = sp * inv2n + 1e-5f;
-        for (int t = 0; t < cnt; ++t) {
-          const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
-          const float *qr = bufQ + rq * LDQ;
-          float q[W2];
+        qr += LDQ;
+        const v2f rstd2 = bcast2(fast_rsq(fmaf(sumsq2<2 * H>(zz), inv2n, 1e-5f)));
 #pragma unroll
-          for (int j = 0; j < W2 / 4; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * j);
-            q[4 * j] = v.x; q[4 * j + 1] = v.y; q[4 * j + 2] = v.z; q[4 * j + 3] = v.w;
-          }
-#pragma unroll
-          for (int c = W2 / 4 * 4; c < W2; ++c) q[c] = qr[c];
-          float dot0 = 0.f, dot1 = 0.f;
-#pragma unroll
-          for (int c = 0; c < W2; c += 2) {
-            dot0 = fmaf(pd[c], q[c], dot0);
-            if (c + 1 < W2) dot1 = fmaf(pd[c + 1], q[c + 1], dot1);
-          }
-          float ve = (dot0 + dot1) + (spe + qr[W2]);
-          ve = ve > 1e-5f ? ve : 1e-5f;
-          const float rstd = fast_rsq(ve);
-#pragma unroll
-          for (int k = 0; k < FE; ++k) {
-            const float e1 = fast_exp2((p[k] + q[k]) * rstd + b3(k));
-            const float e2 = fast_exp2((p[FE + k] + q[FE + k]) * rstd + b3(FE + k));
-            const float t2 = 1.0f + e2;
-            acc[k] = fmaf(e2 - 1.0f, fast_rcp(fmaf(e1, t2, t2)), acc[k]);
-          }
-        }
-      } else {
-        for (int t = 0; t < cnt; ++t) {
-          const int rq = rb + t + ((rb + t >= rskip) ? 1 : 0);
-          const float *qr = bufQ + rq * LDQ;
-          float q[W2];
-#pragma unroll
-          for (int j = 0; j < W2 / 4; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * j);
-            q[4 * j] = v.x; q[4 * j + 1] = v.y; q[4 * j + 2] = v.z; q[4 * j + 3] = v.w;
-          }
-#pragma unroll
-          for (int c = W2 / 4 * 4; c < W2; ++c) q[c] = qr[c];
-          float dot0 = 0.f, dot1 = 0.f;
-#pragma unroll
-          for (int c = 0; c < W2; c += 2) {
-            dot0 = fmaf(p[c], q[c], dot0);
-            if (c + 1 < W2) dot1 = fmaf(p[c + 1], q[c + 1], dot1);
-          }
-          const float var = fmaxf((sp + qr[W2] + 2.0f * (dot0 + dot1)) * inv2n, 0.0f);
-          const float rstd = fast_rsq(var + 1e-5f);
-#pragma unroll
-          for (int k = 0; k < FE; ++k) {
-            // (one scalar operand per instruction: rstd * gamma first, then an fma with beta -- the
-            //  form ((p+q) rstd) gamma + beta needs two scalars in one fma, i.e. an extra v_mov each)
-            const float yf = fmaf(p[k] + q[k], rstd * g3(k), b3(k));
-            float yc = fmaf(p[FE + k] + q[FE + k], rstd * g3(FE + k), b3(FE + k));
-            yc = fminf(fmaxf(yc, -43.28f), 43.28f);
-            const float e1 = fast_exp2(yf), e2 = fast_exp2(yc);
-            const float t2 = 1.0f + e2;
-            acc[k] = fmaf(e2 - 1.0f, fast_rcp(fmaf(e1, t2, t2)), acc[k]);
-          }
+        for (int j = 0; j < H; ++j) {
+          const v2f yf = fma2(zz[j], rstd2 * ldw2(c3n1gs + 2 * j), ldw2(c3n1bs + 2 * j));
+          const v2f yc = fma2(zz[H + j], rstd2 * ldw2(c3n1gs + FeP + 2 * j), ldw2(c3n1bs + FeP + 2 * j));
+          acc[j] = gate2s<CLAMP>(yf, yc, acc[j]);
         }
       }
-      float c3[FE];
-      ln_row1<FE, PADDED>(acc, c3n2g, c3n2b, c3, fe_rt);
-      // c2: gate(LayerNorm(c2_linear(node[j] * node[k]))) -> LayerNorm   (_gnn.py:223-228)
-      float x[FE], nj[FN], nk[FN];
-      load_row<FN>(njrow, nj);
-      load_row<FN>(nkrow, nk);
-      load_row<FE>(xrow, x);
-      float c2pre[W2], z[FN];
+      v2f c3[H], out[H];
+      ln_pairs<FE, PADDED>(acc, c3n2g, c3n2b, c3, fe_rt);
 #pragma unroll
-      for (int k = 0; k < FN; ++k) z[k] = nj[k] * nk[k];
-#pragma unroll
-      for (int c = 0; c < W2; ++c) c2pre[c] = c2bias[gcol<FE, FeP>(c)];
-      gated_matvec<FN, FE, FeP, 2 * FeP, 0>(c2WT, z, c2pre);
-      float g2[FE], c2[FE], out[FE];
-      ln_gate_row<FE, FeP, PADDED>(c2pre, c2n1g, c2n1b, g2, fe_rt);
-      ln_row1<FE, PADDED>(g2, c2n2g, c2n2b, c2, fe_rt);
-#pragma unroll
-      for (int k = 0; k < FE; ++k) out[k] = fast_tanh(x[k] + c2[k] + c3[k]);
-      store_row<FE, FeP>(a.edge_out + (erow0 + dst) * FeP, out);
+      for (int j = 0; j < H; ++j) out[j] = tanh2(r[j] + c3[j]);
+      store_pairs<FE, FeP>(a.edge_out + drow * FeP, out);
     }
     __syncthreads();  // bufQ may be rewritten
   }
@@ -680,14 +754,17 @@ __global__ __launch_bounds__(256) void readout_narrow_kernel(ReadoutNarrowArgs a
 // Exact instantiations: the documented widths and those of the reference's own tests.  Everything else with
 // Fn, Fe <= 16 runs on the PADDED instantiation of its widths rounded up to multiples of four.
 #define RN_NARROW_EXACT(X) X(5, 14) X(5, 5)
+#define RN_NARROW_EXACT_EDGE(X) X(5, 14)  // (the EdgeBlock works on column pairs: Fe = 5 runs as 8 rounded up)
 #define RN_NARROW_GRID(X) \
   X(4, 4) X(4, 8) X(4, 12) X(4, 16) X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(12, 4) X(12, 8) X(12, 12) X(12, 16) \
   X(16, 4) X(16, 8) X(16, 12) X(16, 16)
 
 bool narrow_supported(Dims d) { return d.FnP == 16 && d.FeP == 16 && d.Fn >= 1 && d.Fe >= 1; }
 
-size_t edge_narrow_lds_bytes(int fe, int tile_out_rows, int tile_in_rows) {
-  return narrow_lds((fe + 3) / 4 * 4, tile_out_rows, tile_in_rows).total;  // (an upper bound for the exact widths)
+// (fe_kernel: the compile-time edge width of the instantiation the launcher will pick -- Fe = 14 has its own)
+size_t edge_narrow_lds_bytes(int fn, int fe, int tile_out_rows, int tile_in_rows) {
+  const int fe_kernel = (fn == 5 && fe == 14) ? 14 : (fe + 3) / 4 * 4;  // RN_NARROW_EXACT_EDGE
+  return narrow_lds(fe_kernel, tile_out_rows, tile_in_rows).total;
 }
 
 template <int FN, int FE, bool PADDED>
@@ -728,7 +805,8 @@ void launch_node_narrow(const float *edge, const float *node_in, float *node_out
                         const PassW<float> &w, hipStream_t st) {
   if (S == 0 || g.N == 0) return;
   NodeNarrowArgs a{edge, node_in, node_out, S, d.Fn, g, w.c1_WnT, w.c1_WeT, w.c1_bias,
-                   w.c1_norm.g, w.c1_norm.b, w.final_norm.g, w.final_norm.b};
+                   w.c1_norm.g, w.c1_norm.b, w.final_norm.g, w.final_norm.b,
+                   w.c1_WnT_c, w.c1_WeT_c, w.c1_bias_c, w.c1_norm_s.g, w.c1_norm_s.b};
   static const bool tiled_ok = !(getenv("RN_POTGNN_NODE_TILED") && atoi(getenv("RN_POTGNN_NODE_TILED")) == 0);
   if (tiled_ok && g.nt_num > 0 && g.nt_narrow) {
     launch_node_tiled(a, d, st);
@@ -746,9 +824,9 @@ void launch_node_narrow(const float *edge, const float *node_in, float *node_out
 #undef X
 }
 
-template <int FN, int FE, bool FASTG, bool PADDED>
+template <int FN, int FE, bool CLAMP, bool PADDED>
 static void launch_edge_cfg(const EdgeNarrowArgs &a, hipStream_t st) {
-  auto kern = &edge_narrow_kernel<FN, FE, FASTG, PADDED>;
+  auto kern = &edge_narrow_kernel<FN, FE, CLAMP, PADDED>;
   const size_t lds = narrow_lds(FE, a.g.max_tile_out_rows, a.g.max_tile_in_rows).total;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -772,26 +850,25 @@ static void launch_edge_cfg(const EdgeNarrowArgs &a, hipStream_t st) {
 void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node, int S, const Graph &g, Dims d,
                         const PassW<float> &w, hipStream_t st) {
   if (S == 0 || g.E == 0) return;
-  EdgeNarrowArgs a{edge_in, edge_out, node, S, d.Fe, g, w.c3_WeT, w.c3_WnT, w.c3_nshift, w.c2_WT, w.c2_bias,
+  EdgeNarrowArgs a{edge_in, edge_out, node, S, d.Fe, g, w.c3_WeT_c, w.c3_WnT_c, w.c3_nshift_c, w.c2_WT_c, w.c2_bias_c,
                    w.c3_norm_1s.g, w.c3_norm_1s.b, w.c3_norm_2.g, w.c3_norm_2.b,
-                   w.c2_norm_1.g, w.c2_norm_1.b, w.c2_norm_2.g, w.c2_norm_2.b};
-  // The folded-scale triplet loop (FASTG, kernels_fused.hip) keeps 2 Fe more values per lane alive;
-  // here that costs a wave per SIMD (132 vs 100 VGPRs at Fe = 14) and measured 5 % slower than the
-  // general loop (4.23 vs 4.03 us per 256-atom structure); forced down to 128 VGPRs (four workgroups per
-  // CU again, 16 bytes of scratch) it ties with the general loop (217 k vs 219 k structures/s) although
-  // it issues 209 instead of 257 instructions per triplet.  So the general loop is always used.
-#define X(FN, FE)                                  \
-  if (d.Fn == FN && d.Fe == FE) {                  \
-    launch_edge_cfg<FN, FE, false, false>(a, st);  \
-    return;                                        \
+                   w.c2_norm_1s.g, w.c2_norm_1s.b, w.c2_norm_2.g, w.c2_norm_2.b};
+  // the gate's overflow clamp stays in the loop unless the host has bounded the gate arguments (refresh_pass_flags)
+  const bool clamp = (w.c3_fast & 1) == 0;
+#define X(FN, FE)                                                 \
+  if (d.Fn == FN && d.Fe == FE) {                                 \
+    if (clamp) launch_edge_cfg<FN, FE, true, false>(a, st);       \
+    else launch_edge_cfg<FN, FE, false, false>(a, st);            \
+    return;                                                       \
   }
-  RN_NARROW_EXACT(X)
+  RN_NARROW_EXACT_EDGE(X)
 #undef X
   const int fnc = (d.Fn + 3) / 4 * 4, fec = (d.Fe + 3) / 4 * 4;
-#define X(FN, FE)                                 \
-  if (fnc == FN && fec == FE) {                   \
-    launch_edge_cfg<FN, FE, false, true>(a, st);  \
-    return;                                       \
+#define X(FN, FE)                                                \
+  if (fnc == FN && fec == FE) {                                  \
+    if (clamp) launch_edge_cfg<FN, FE, true, true>(a, st);       \
+    else launch_edge_cfg<FN, FE, false, true>(a, st);            \
+    return;                                                      \
   }
   RN_NARROW_GRID(X)
 #undef X

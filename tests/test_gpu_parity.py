@@ -1050,7 +1050,11 @@ def test_device_resident_training_step_on_cuda_tensors():
         runs[where] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     np.testing.assert_allclose(runs["cuda"][0], runs["cpu"][0], rtol=1e-5)
     for k, v in runs["cpu"][1].items():
-        np.testing.assert_allclose(runs["cuda"][1][k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)  # (the loss is summed on another device)
+        # (the loss is summed on another device.  The bias of the Linear ahead of the training-mode BatchNorm has a
+        #  mathematically zero gradient: what Adam integrates there is rounding noise divided by its own magnitude, so
+        #  that one vector only agrees to the size of a few steps' worth of lr * noise)
+        atol = 2e-5 if k == "_to_polarizability_embedding.0.bias" else 2e-6
+        np.testing.assert_allclose(runs["cuda"][1][k].numpy(), v.numpy(), rtol=2e-5, atol=atol, err_msg=k)
 
 
 def test_device_adam_matches_torch_adam():
