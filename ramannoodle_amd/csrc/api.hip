@@ -2039,13 +2039,15 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   int max_rows = 0;
   if (narrow_mode && !getenv("RN_POTGNN_TILE_KB")) {
     const size_t per_row = edge_narrow_lds_bytes(d.Fn, d.Fe, 1024, 1024) / 1024 + 1;
-    size_t budget = std::min<size_t>(256, (size_t)40 * 1024 / per_row);
+    // 128 rows = one two-wave workgroup per tile (kernels_narrow.hip launch_edge_cfg); an atom with more out-edges gets a
+    // tile of its own and the four-wave form
+    size_t budget = std::min<size_t>(128, (size_t)40 * 1024 / per_row);
     if (const char *e = getenv("RN_POTGNN_NARROW_TILE_ROWS")) budget = (size_t)std::max(1, atoi(e));  // experiment knob
     max_rows = build_tiles(std::max<size_t>(1, budget), h->tile_begin);
     // The greedy partition fills every tile but the last (256 atoms of degree 18: eighteen tiles of 14 atoms and one
     // of 4).  The same NUMBER of tiles with boundaries at equal shares of the edge list (14, 13, 14, 13, ...) costs
     // the same lane slots and keeps the workgroups of a frame in step, as long as no tile exceeds the budget.
-    if (!getenv("RN_POTGNN_NARROW_TILE_ROWS") && h->tile_begin.size() > 2) {
+    if (h->tile_begin.size() > 2) {
       const int T = (int)h->tile_begin.size() - 1;
       std::vector<int> tb(1, 0);
       for (int t = 1; t < T; ++t) {
@@ -2170,20 +2172,23 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
   int nt_max_in = 0, nt_max_nodes = 0;
   bool nt_narrow = false;
   if (narrow_mode) {
-    // node_tiled_kernel (kernels_narrow.hip): at most 256 atoms (one lane each in its last pass) whose
-    // in-edge rows are streamed 256 at a time: the partition that fills those chunks best within 64 KiB of LDS
+    // node_tiled_kernel (kernels_narrow.hip): ONE WAVE per tile -- at most 64 atoms (one lane each in its last pass)
+    // whose in-edge rows are streamed 64 at a time: the partition that fills those chunks best, within 12 KiB of LDS
+    // (thirteen waves per CU and more); among equals the larger tiles (fewer frame starts per row)
     double best = -1;
-    for (int budget = 64; budget <= 4096; budget += 32) {
+    const int max_budget = getenv("RN_POTGNN_NODE_TILE_ROWS") ? std::max(1, atoi(getenv("RN_POTGNN_NODE_TILE_ROWS"))) : 256;
+    const int lds_kb = getenv("RN_POTGNN_NODE_TILE_KB") ? std::max(1, atoi(getenv("RN_POTGNN_NODE_TILE_KB"))) : 12;
+    for (int budget = 32; budget <= std::max(max_budget, 32); budget += 2) {
       std::vector<int> tb(1, 0);
       int rows_in = 0, max_in = 0, max_nodes = 0, first = 0;
       double work = 0;  // chunk slots the partition pays for
       auto close = [&](int n) {
         max_nodes = std::max(max_nodes, n - first);
-        work += (double)std::max((rows_in + 255) / 256, 1) * 256.0;
+        work += (double)std::max((rows_in + 63) / 64, 1) * 64.0;
       };
       for (int n = 0; n < N; ++n) {
         const int deg = h->in_ptr[n + 1] - h->in_ptr[n];
-        if (n > first && (rows_in + deg > budget || n - first >= 256)) {
+        if (n > first && (rows_in + deg > budget || n - first >= 64)) {
           close(n);
           tb.push_back(n);
           first = n;
@@ -2194,13 +2199,14 @@ int rn_potgnn_create(const rn_potgnn_config *cfg, const int32_t *edge_a, const i
       }
       close(N);
       tb.push_back(N);
-      if (node_tiled_lds_bytes(d.Fn, d.Fe, max_in, max_nodes) > (size_t)64 * 1024) {
+      // (a single atom with more in-edges than the budget still gets its tile: the LDS check below decides)
+      if (node_tiled_lds_bytes(d.Fn, d.Fe, max_in, max_nodes) > (size_t)(h->nt_begin.empty() ? 64 : lds_kb) * 1024) {
         if (!h->nt_begin.empty()) break;
         continue;
       }
       const double fill = (double)E / std::max(work, 1.0);
-      if (fill > best * 1.005) {
-        best = fill;
+      if (fill >= best * 0.999) {
+        best = std::max(best, fill);
         h->nt_begin = tb;
         nt_max_in = max_in;
         nt_max_nodes = max_nodes;
