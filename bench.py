@@ -152,7 +152,7 @@ CONFIGS = {
     3: dict(cells=(4, 4, 2), frames=10_000, seed=33, scaling="strong"),
     2: dict(cells=(4, 2, 2), frames=1_000, seed=22, scaling="weak"),
 }
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")  # newest first: where committed PMC summaries are looked up
 
 
 def algorithmic_bytes_edge_block(n, e, fn, fe):
@@ -166,15 +166,33 @@ def edge_block_mfma_flops(e, fn, fe):
     return 2 * e * (2 * fe * 2 * fe + fn * 2 * fe)
 
 
+def git_blob_hash(path):
+    """What `git hash-object` prints for the file: sha1 of "blob <size>\\0" + contents."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def committed_profile(name, n, e, fn, fe):
     """A PMC summary committed under profiles/rNN/ (taken with rocprofv3 --pmc on this very
-    workload: the file records its own N, E, Fn, Fe), newest round first; None if absent."""
+    workload: the file records its own N, E, Fn, Fe), newest round first; None if absent.
+
+    A record is only replayed under a fresh timing if the kernel it was taken on is the kernel that just ran: every
+    record carries the git blob hash of the kernel's source file at profiling time (tools/make_profile_json.py), and
+    a record without a stamp, or whose stamp differs from the file in this tree, is refused (None -> `traffic: null`)."""
     for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             rec = json.load(open(path))
             shape = rec.get("workload_shape", [128, 2304, 64, 64])  # r01 files: config 2
             if list(shape) == [n, e, fn, fe]:
+                stamp = rec.get("kernel_source")
+                try:
+                    current = git_blob_hash(os.path.join(ROOT, stamp["file"])) if stamp else None
+                except OSError:
+                    current = None
+                if not stamp or current != stamp.get("git_blob"):
+                    return None  # (the newest record of this shape is stale: an older one is older still)
                 rec = dict(rec)
                 rec["_path"] = os.path.join("profiles", rnd, name)  # named in the bench line next to what it supplies
                 return rec
@@ -194,8 +212,8 @@ def nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow
                             else "node_fused_traffic.json", n, e, fn, fe) if (fused or narrow) else None
     if rec:
         traffic = rec["hbm_bytes_per_structure_pass"] * frames * passes * steps / launches
-    return {"kernel": "node_tiled_kernel (NodeBlock scatter-aggregate, projections included: in-edge rows staged "
-                      "through LDS 256 at a time, one lane per row, per-atom sums from LDS)" if narrow
+    return {"kernel": "node_tiled_kernel (NodeBlock scatter-aggregate, projections included: one wave per atom tile, the "
+                      "tile's contiguous in-edge rows through LDS 64 at a time, one lane per row, per-atom sums from LDS)" if narrow
             else "node_block_atom_kernel (NodeBlock: 16-atom tiles, MFMA c1 projection with the gate on the accumulators, "
                  "per-atom sums in registers, operand rows through a 4-deep LDS-DMA ring)" if fused and atom
             else "node_block_fused_kernel (NodeBlock: MFMA c1 projection + scatter-aggregate)" if fused
@@ -262,6 +280,8 @@ def measure_case(wl, device, steps, warmup, label):
                      "algorithmic_bytes_per_structure_pass": per_pass},
         "roofline_nodeblock": nodeblock_roofline(times, n, e, fn, fe, frames, passes, steps, fused, narrow,
                                                  bool(flags.get("atom_owning_node_block"))),
+        # the same frames through the host entry (pageable float64 in, PCIe and the synchronisation inside the clock)
+        "host_boundary": host_boundary(model, wl["positions"]),
     }
 
 
@@ -294,6 +314,62 @@ def host_pipelined_rate(model, positions, block=2000):
     finally:
         src.free()
         dst.free()
+
+
+def host_api_rate(model, positions, reps=2):
+    """`PotGNN.calc_polarizabilities(numpy array)` -- the call `Trajectory.get_raman_spectrum` makes
+    (dynamics/_trajectory.py:71-90): caller-owned pageable float64 in, float64 out, PCIe both ways and the
+    synchronisation inside the clock.  One warm call (staging buffers), then the best of `reps`."""
+    model.calc_polarizabilities(positions[:max(1, min(len(positions), 64))])
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        model.calc_polarizabilities(positions)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return len(positions) / best
+
+
+def resident_rate(model, positions, reps=2):
+    pos = torch.tensor(positions, device="cuda")
+    out = torch.empty((len(positions), 3, 3), dtype=torch.float64, device="cuda")
+    model.calc_polarizabilities_device(pos, out, synchronize=True)
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.calc_polarizabilities_device(pos, out, synchronize=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return len(positions) / best
+
+
+def batch1_latency_us(model, positions, calls=300):
+    """One structure per call through `calc_polarizabilities`: what the reference's unchanged `Phonons` loop issues
+    (dynamics/_phonon.py:93-106: 2 M calls of batch 1).  Microseconds per call, host array in, host array out."""
+    for i in range(20):
+        model.calc_polarizabilities(positions[i % len(positions)][None])
+    t0 = time.perf_counter()
+    for i in range(calls):
+        model.calc_polarizabilities(positions[i % len(positions)][None])
+    return (time.perf_counter() - t0) / calls * 1e6
+
+
+def host_boundary(model, positions, share=1250):
+    """The host boundary where callers use it: the whole trajectory, an 8-GPU share of it, one
+    structure at a time -- each next to the HBM-resident rate of the same frames."""
+    full_host, full_res = host_api_rate(model, positions), resident_rate(model, positions)
+    out = {"entry": "PotGNN.calc_polarizabilities(numpy float64) -> rn_potgnn_calc_polarizabilities: positions cast to "
+                    "float32 into page-locked staging, one work chunk at a time (cast / H2D / kernels of consecutive chunks overlapped); "
+                    "D2H and sync inside",
+           "frames": len(positions), "host_structures_per_s": full_host, "resident_structures_per_s": full_res,
+           "host_over_resident": full_host / full_res}
+    if len(positions) > share:
+        h, r = host_api_rate(model, positions[:share], 3), resident_rate(model, positions[:share], 3)
+        out["share_of_8_gpus"] = {"frames": share, "host_structures_per_s": h, "resident_structures_per_s": r,
+                                  "host_over_resident": h / r}
+    out["batch_1_latency_us_per_call"] = batch1_latency_us(model, positions)
+    return out
 
 
 def cpu_baseline(workload, sample, reps=3):
@@ -515,10 +591,36 @@ def main():
         elapsed = float(t.item())
     times = model.kernel_times()
     model.set_profiling(0)
+    # informational, N > 1: the same step from the caller's HOST array (what `calc_polarizabilities_sharded` does: every rank
+    # uploads its block through the pipelined staging entry, results stay in HBM for the all-gather) -- the rate a
+    # `Trajectory.get_raman_spectrum` across ranks sees, beside the HBM-resident `value`
+    host_inclusive = None
+    if world > 1 and not args.no_extras:
+        host_steps = max(1, min(args.steps, 5))
+
+        def host_step():
+            if mine:
+                model.calc_polarizabilities_to_device(wl["positions"], out[:mine])
+            dist.all_gather_into_tensor(gathered, out)
+
+        host_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(host_steps):
+            host_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        th = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        host_inclusive = total * host_steps / float(th.item())
     # informational: the host-buffer entry point (adds PCIe H2D/D2H); never the headline value
     host_rate = None
+    host_api = None
     if rank == 0 and mine and not args.no_extras:
         host_rate = host_pipelined_rate(model, wl["positions"])
+        if world == 1:
+            host_api = host_boundary(model, wl["positions"])
 
     # informational (N = 1): the same step with the matrix products on the exact-fp32 MFMA instead of the
     # split-f16 products, and how far the two outputs are apart -- so that the headline can be read
@@ -532,16 +634,30 @@ def main():
             out32 = torch.zeros_like(out)
             model32.calc_polarizabilities_device(pos, out32[:mine])
             torch.cuda.synchronize()
+            model32.set_profiling(1000 + (1 << EDGE_AGG_KERNEL_ID) + (1 << NODE_AGG_KERNEL_ID))
             t1 = time.perf_counter()
             for _ in range(2):
                 model32.calc_polarizabilities_device(pos, out32[:mine])
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 2
+            times32 = model32.kernel_times()
+            model32.set_profiling(0)
             model.calc_polarizabilities_device(pos, out[:mine])
             torch.cuda.synchronize()
             diff = float((out[:mine] - out32[:mine]).abs().max() / out32[:mine].abs().max())
+            ms32, launches32 = times32.get("edge_agg", (0.0, 0))
+            bytes32 = algorithmic_bytes_edge_block(n, e, fn, fe) * mine * passes * 2
             exact = {"structures_per_s": mine / dt, "max_rel_diff_of_alpha": diff,
-                     "note": "RN_POTGNN_MFMA=f32: v_mfma_f32_16x16x4_f32 everywhere, no f16 operands"}
+                     "note": "RN_POTGNN_MFMA=f32: v_mfma_f32_16x16x4_f32 everywhere, no f16 operands",
+                     # the dominant kernel of THIS leg, HIP-event timed like the headline's (its F16 = false instantiation)
+                     "roofline_exact_fp32": ({"kernel": "edge_block_ps_kernel<F16 = false> (f32 weight fragments and operand "
+                                                        "tiles, v_mfma_f32_16x16x4_f32)",
+                                              "bound": "hbm", "achieved": bytes32 / (ms32 * 1e-3) / 1e9, "peak": 8000.0,
+                                              "unit": "GB/s", "frac": bytes32 / (ms32 * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                                              "launches": launches32, "avg_launch_ms": ms32 / launches32,
+                                              "mfma_frac": edge_block_mfma_flops(e, fn, fe) * mine * passes * 2
+                                              / (ms32 * 1e-3) / 157.3e12}
+                                             if launches32 and ms32 > 0 else None)}
             del model32
         finally:
             del os.environ["RN_POTGNN_MFMA"]
@@ -562,7 +678,7 @@ def main():
         frames_per_launch = mine * passes * args.steps / agg_launches if agg_launches else None
         roofline = {
             "kernel": ("edge_narrow_kernel (EdgeBlock: projections + triplet scatter-aggregate, one lane per "
-                       "destination edge)" if narrow
+                       "destination edge, two columns per packed-f32 instruction)" if narrow
                        else "edge_block_ps_kernel (EdgeBlock: MFMA projections by producer waves + triplet "
                             "scatter-aggregate by consumer waves, one 12-wave workgroup per CU)"
                        if fused and flags.get("role_split_edge_block")
@@ -591,8 +707,8 @@ def main():
             # each on the f16 MFMA) in fp32-equivalent FLOP/s over the 157.3 TFLOP/s fp32 peak
             "mfma_frac": (edge_block_mfma_flops(e, fn, fe) * mine * passes * args.steps / (agg_ms * 1e-3) / 157.3e12
                           if fused and not narrow and agg_ms > 0 else None),
-            "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): about 13 VALU instructions, "
-                    "3 of them transcendental, per (triplet, feature pair); achieved/peak/frac are the HBM "
+            "note": "the EdgeBlock is SIMD-issue bound (DESIGN.md section 5): about 10 VALU instructions, "
+                    "3 of them transcendental, per (triplet, gate); achieved/peak/frac are the HBM "
                     "figures the metric asks for, issue_frac (VALU-busy + MFMA-busy share of SIMD cycles, "
                     "from the committed SQ counter pass) says what actually bounds the kernel; "
                     "roofline_nodeblock is the pass's other scatter-aggregate, the one that streams",
@@ -642,6 +758,11 @@ def main():
             # `value` is the HBM-resident figure the contract asks for
             "host_pipelined_structures_per_s": host_rate,
             "host_over_resident": host_rate / (total * args.steps / elapsed) if host_rate and world == 1 else None,
+            # what callers of the Python API get (pageable float64 arrays): whole trajectory, an 8-GPU share of it,
+            # one structure per call
+            "host_boundary": host_api,
+            # N > 1: `value` from the caller's host array instead of HBM-resident positions (upload inside the clock)
+            "host_inclusive_structures_per_s": host_inclusive,
             "exact_fp32_mfma": exact,
         }
         if world == 1 and not args.no_extras and args.config == 3 and args.hparams == "perf" and not args.frames \

@@ -113,10 +113,22 @@ void rn_potgnn_destroy(rn_potgnn *h);
  * Replaces PotGNN.calc_polarizabilities (_gnn.py:667-721).
  *   positions  host f64[S*N*3]  fractional coordinates, C-contiguous, not modified
  *   alpha      host f64[S*3*3]  de-standardised symmetric tensors (alpha*sigma + mu)
- * S may be 0.  Includes H2D/D2H copies.
+ * S may be 0.  Includes H2D/D2H copies (pipelined: see rn_potgnn_calc_polarizabilities_to_device).
  */
 int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64_t S,
                                     double *alpha);
+
+/*
+ * The same evaluation (float32 arithmetic, host float64 positions) with the result left on the device: d_alpha device
+ * f64[S*9].  The positions are cast to float32 while they are staged into page-locked memory -- the reference casts them
+ * before any arithmetic (_gnn.py:709), so the results are bit-identical to a float64 upload at half the PCIe bytes -- and
+ * go through one work chunk at a time, cast / copy / kernels of consecutive chunks overlapped (rn_potgnn_calc_polarizabilities
+ * does the same and then copies the result down).  Returns once everything is enqueued; `stream` (a hipStream_t, NULL = the null stream) is
+ * made to wait for the evaluation, so work the caller enqueues on it afterwards -- the all-gather of a sharded run,
+ * dynamics/_trajectory.py:71-90 across ranks -- sees the finished d_alpha.  `positions` may be reused on return.
+ */
+int rn_potgnn_calc_polarizabilities_to_device(rn_potgnn *h, const double *positions, int64_t S, double *d_alpha,
+                                              void *stream);
 
 /*
  * The same evaluation with every kernel instantiated for float64 -- what the reference computes

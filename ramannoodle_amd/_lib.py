@@ -50,6 +50,7 @@ SIGNATURES = {
     "rn_potgnn_destroy": (None, [_P]),
     "rn_potgnn_calc_polarizabilities": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_calc_polarizabilities_f64": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "rn_potgnn_calc_polarizabilities_to_device": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "rn_potgnn_forward_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int]),
     "rn_potgnn_forward_device_f64": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int]),
     "rn_potgnn_calc_polarizabilities_async": (C.c_int, [_P, _P, C.c_int64, _P]),

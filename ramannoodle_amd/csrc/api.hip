@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rn_potgnn.h"
@@ -203,6 +205,14 @@ struct rn_potgnn {
   } slots[2];
   hipStream_t copy_stream = nullptr, exec_stream = nullptr;
   int next_slot = 0;
+  // host entry rn_potgnn_calc_polarizabilities: two page-locked buffers the caller's float64 positions are cast into
+  // (float32) piece by piece, each with the event of its host-to-device copy
+  struct HostStage {
+    float *pin[2] = {nullptr, nullptr};
+    size_t elems = 0;  // floats per buffer
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    hipEvent_t done = nullptr;
+  } hstage;
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
   int train_prec = 4;  // sizeof of the precision it ran in
@@ -825,6 +835,7 @@ struct ChunkRun {
   rn_potgnn *h;
   Lane<T> *ln;
   const double *d_pos;
+  const float *d_pos32 = nullptr;  // float32 evaluations: the chunk's positions as float32 (then d_pos is null)
   int S;
   double *d_alpha;
   float *d_vec6;
@@ -877,7 +888,12 @@ struct ChunkRun {
       Timer t(h, st(), K_GEOM);
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (pair_rows()) {
+        if (d_pos32) {
+          const float *lat = d_lat ? d_lat : P.lattice.template as<T>();
+          if (pair_rows()) launch_geom_rbf_pairs_pos32(d_pos32, S, h->g, lat, d_lat ? 9 : 0, P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
+          else launch_geom_rbf_pos32(d_pos32, S, h->g, lat, d_lat ? 9 : 0, P.offsets, (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st(), narrow());
+          done = true;
+        } else if (pair_rows()) {
           launch_geom_rbf_pairs(d_pos, S, h->g, d_lat ? d_lat : P.lattice.template as<T>(), d_lat ? 9 : 0, P.offsets,
                                 (T)h->cfg.gauss_coefficient, h->d, unit4, edge[0], st());
           done = true;
@@ -1108,10 +1124,11 @@ struct ChunkRun {
 
 template <typename T>
 void run_chunk(rn_potgnn *h, Lane<T> &ln, const double *d_pos, int S, double *d_alpha,
-               float *d_vec6, double *d_alpha_raw, const T *d_lat, const int *d_types) {
+               float *d_vec6, double *d_alpha_raw, const T *d_lat, const int *d_types, const float *d_pos32 = nullptr) {
   ChunkRun<T> c(h, ln, d_pos, S, d_alpha, d_vec6, d_alpha_raw);
   c.d_lat = d_lat;
   c.d_types = d_types;
+  c.d_pos32 = d_pos32;
   c.begin();
   for (int p = 0; p < h->cfg.num_message_passes; ++p) {
     c.stage_project(p);
@@ -1197,7 +1214,7 @@ void check_ps_fail(rn_potgnn *h) {
 template <typename T>
 void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alpha, float *d_vec6,
                     double *d_alpha_raw, hipStream_t user, bool sync, const T *d_lat = nullptr,
-                    const int *d_types = nullptr) {
+                    const int *d_types = nullptr, const float *d_pos32 = nullptr /* instead of d_pos: float32 positions */) {
   ensure_precision<T>(h);
   Precision<T> &P = prec<T>(h);
   const int N = h->cfg.num_atoms;
@@ -1205,9 +1222,10 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
   const int lanes = h->num_lanes;
   for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(P.lanes[l].stream, h->ev_start, 0));
   auto make = [&](int lane, int64_t first, int s) {
-    ChunkRun<T> c(h, P.lanes[lane], d_pos + first * N * 3, s,
+    ChunkRun<T> c(h, P.lanes[lane], d_pos ? d_pos + first * N * 3 : nullptr, s,
                   d_alpha ? d_alpha + first * 9 : nullptr, d_vec6 ? d_vec6 + first * 6 : nullptr,
                   d_alpha_raw ? d_alpha_raw + first * 9 : nullptr);
+    c.d_pos32 = d_pos32 ? d_pos32 + first * N * 3 : nullptr;
     c.d_lat = d_lat ? d_lat + first * 9 : nullptr;
     c.d_types = d_types ? d_types + first * N : nullptr;
     return c;
@@ -1227,9 +1245,10 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
       done += both;
     } else {
       const int s = (int)std::min<int64_t>(chunk, left);
-      run_chunk<T>(h, P.lanes[0], d_pos + done * N * 3, s, d_alpha ? d_alpha + done * 9 : nullptr,
+      run_chunk<T>(h, P.lanes[0], d_pos ? d_pos + done * N * 3 : nullptr, s, d_alpha ? d_alpha + done * 9 : nullptr,
                    d_vec6 ? d_vec6 + done * 6 : nullptr, d_alpha_raw ? d_alpha_raw + done * 9 : nullptr,
-                   d_lat ? d_lat + done * 9 : nullptr, d_types ? d_types + done * N : nullptr);
+                   d_lat ? d_lat + done * 9 : nullptr, d_types ? d_types + done * N : nullptr,
+                   d_pos32 ? d_pos32 + done * N * 3 : nullptr);
       h->last_chunk_structs = s;
       done += s;
     }
@@ -2520,7 +2539,91 @@ void rn_potgnn_destroy(rn_potgnn *h) {
   for (int i = 0; i < 2; ++i)
     if (h->ev_g[i]) (void)hipEventDestroy(h->ev_g[i]);
   if (h->step_host) (void)hipHostFree(h->step_host);
+  for (int b = 0; b < 2; ++b) {
+    if (h->hstage.pin[b]) (void)hipHostFree(h->hstage.pin[b]);
+    if (h->hstage.copied[b]) (void)hipEventDestroy(h->hstage.copied[b]);
+  }
+  if (h->hstage.done) (void)hipEventDestroy(h->hstage.done);
   delete h;
+}
+
+// float64 -> float32, round to nearest even: what the device's (float)double does.  Large batches on a few threads
+// (the cast reads 8 and writes 4 bytes per coordinate: at the narrow models' rates one core is the bottleneck).
+static void cast_to_float(const double *src, float *dst, size_t n) {
+  auto run = [](const double *s, float *d, size_t m) {
+    for (size_t i = 0; i < m; ++i) d[i] = (float)s[i];
+  };
+  const size_t per_thread = (size_t)1 << 20;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t nt = std::min<size_t>(std::min<size_t>(4, hw), n / per_thread);
+  if (nt < 2) return run(src, dst, n);
+  std::vector<std::thread> pool;
+  const size_t share = (n + nt - 1) / nt;
+  for (size_t t = 1; t < nt; ++t) {
+    const size_t lo = t * share, hi = std::min(n, lo + share);
+    if (lo < hi) pool.emplace_back(run, src + lo, dst + lo, hi - lo);
+  }
+  run(src, dst, std::min(n, share));
+  for (auto &t : pool) t.join();
+}
+
+// Float32 evaluation of caller-owned (usually pageable) float64 host positions into a device array of polarizabilities.
+// A float32 evaluation casts the positions to float32 before any arithmetic (_gnn.py:709), so they are cast HERE, into
+// page-locked staging, and cross PCIe as float32: half the bytes, no pageable copy, and results bit-identical to a float64
+// upload.  The batch goes through in pieces (below: whole work chunks): this thread casts piece k + 1 while piece k crosses
+// PCIe on the copy stream and the kernels of piece k - 1 run on the handle's streams behind h->exec_stream.
+static void staged_forward(rn_potgnn *h, const double *positions, int64_t S, double *d_alpha, bool sync) {
+  const size_t per_frame = (size_t)h->cfg.num_atoms * 3;
+  const int64_t chunk = std::max<int64_t>(1, h->chunk);
+  if (!h->exec_stream) HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
+  if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  // Pieces are whole work chunks: a batch that fits one chunk goes through in ONE piece.  Measured on config 3's 1250-frame
+  // share of an 8-GPU run (profiles/r06/host_boundary.txt): with the positions crossing as float32 from page-locked memory the
+  // cast + copy of the whole block is 0.3 ms of 20, and every extra launch of the persistent kernels costs more in tails than
+  // overlapping it saves -- one piece 0.994 of the resident rate, two 0.97, three 0.95, four equal ones 0.93 (round 5, a pageable
+  // float64 copy in front of the kernels: 0.76).  Longer batches overlap naturally: piece k + 1 is cast and copied under the
+  // kernels of piece k.  RN_POTGNN_HOST_PIECE = frames per piece (the bit-identity test forces small ones).
+  int64_t fixed_piece = chunk;
+  if (const char *e = getenv("RN_POTGNN_HOST_PIECE")) fixed_piece = std::max<int64_t>(1, std::min<int64_t>(chunk, atoll(e)));
+  std::vector<int64_t> pieces;
+  for (int64_t left = S; left > 0; left -= pieces.back()) pieces.push_back(std::min<int64_t>(fixed_piece, left));
+  const int64_t piece = *std::max_element(pieces.begin(), pieces.end());
+  auto &hs = h->hstage;
+  if (hs.elems < (size_t)piece * per_frame) {
+    for (int b = 0; b < 2; ++b) {
+      if (hs.pin[b]) (void)hipHostFree(hs.pin[b]);
+      hs.pin[b] = nullptr;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hs.pin[b]), (size_t)piece * per_frame * sizeof(float), hipHostMallocDefault));
+      if (!hs.copied[b]) HIP_TRY(hipEventCreateWithFlags(&hs.copied[b], hipEventDisableTiming));
+    }
+    hs.elems = (size_t)piece * per_frame;
+  }
+  h->io_pos.ensure((size_t)S * per_frame * sizeof(float));
+  float *d_pos32 = h->io_pos.as<float>();
+  int b = 0;
+  int64_t first = 0;
+  static const bool timing = getenv("RN_POTGNN_HOST_TIMING") && atoi(getenv("RN_POTGNN_HOST_TIMING")) != 0;
+  auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  double t_cast = 0, t_wait = 0;
+  for (size_t k = 0; k < pieces.size(); first += pieces[k], ++k, b ^= 1) {
+    const int64_t n = pieces[k];
+    const double t0 = now();
+    if (k >= 2) HIP_TRY(hipEventSynchronize(hs.copied[b]));  // this buffer's previous copy has left it
+    const double t1 = now();
+    cast_to_float(positions + first * per_frame, hs.pin[b], (size_t)n * per_frame);
+    t_wait += t1 - t0;
+    t_cast += now() - t1;
+    HIP_TRY(hipMemcpyAsync(d_pos32 + first * per_frame, hs.pin[b], (size_t)n * per_frame * sizeof(float), hipMemcpyHostToDevice,
+                           h->copy_stream));
+    HIP_TRY(hipEventRecord(hs.copied[b], h->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(h->exec_stream, hs.copied[b], 0));
+    forward_device<float>(h, nullptr, n, d_alpha + first * 9, nullptr, nullptr, h->exec_stream, sync && first + n >= S,
+                          nullptr, nullptr, d_pos32 + first * per_frame);
+  }
+  if (timing)
+    fprintf(stderr, "[host timing] S=%lld pieces=%zu total %.0f us: cast %.0f, buffer waits %.0f, rest (enqueue%s) %.0f\n", (long long)S,
+            pieces.size(), now() - t_begin, t_cast, t_wait, sync ? " + final sync" : "", now() - t_begin - t_cast - t_wait);
 }
 
 int rn_potgnn_forward_device(rn_potgnn *h, const double *d_positions, int64_t S, double *d_alpha,
@@ -2560,22 +2663,41 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
   }
   if (S == 0) return RN_OK;
   return guarded(h, [&]() {
-    const size_t frame_b = (size_t)h->cfg.num_atoms * 3 * sizeof(double);
-    h->io_pos.ensure((size_t)S * frame_b);
+    const size_t per_frame = (size_t)h->cfg.num_atoms * 3;
     h->io_alpha.ensure((size_t)S * 9 * sizeof(double));
-    // Caller-owned (usually pageable) host memory: the copy of work chunk k + 1 blocks this thread while the kernels of
-    // chunk k run (they are enqueued on the handle's own non-blocking streams, which a blocking hipMemcpy does not wait
-    // for), so only the first chunk's transfer is exposed: 10 000 frames of 256 atoms are 61 MB, ~10 ms of PCIe.
-    // (the kernels are ordered behind a stream of the handle's own, not the null stream: a blocking copy waits for that one)
     if (!h->exec_stream) HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
     const int64_t chunk = std::max<int64_t>(1, h->chunk);
-    for (int64_t first = 0; first < S; first += chunk) {
-      const int64_t n = std::min<int64_t>(chunk, S - first);
-      double *d_pos = h->io_pos.as<double>() + first * h->cfg.num_atoms * 3;
-      HIP_TRY(hipMemcpy(d_pos, positions + first * h->cfg.num_atoms * 3, (size_t)n * frame_b, hipMemcpyHostToDevice));
-      forward_device<float>(h, d_pos, n, h->io_alpha.as<double>() + first * 9, nullptr, nullptr, h->exec_stream, first + n >= S);
+    static const bool stage_f32 = !(getenv("RN_POTGNN_HOST_F32") && atoi(getenv("RN_POTGNN_HOST_F32")) == 0);
+    if (!stage_f32) {
+      // (the round-5 form, kept for A/B runs: float64 positions, one blocking copy per work chunk)
+      h->io_pos.ensure((size_t)S * per_frame * sizeof(double));
+      for (int64_t first = 0; first < S; first += chunk) {
+        const int64_t n = std::min<int64_t>(chunk, S - first);
+        double *d_pos = h->io_pos.as<double>() + first * per_frame;
+        HIP_TRY(hipMemcpy(d_pos, positions + first * per_frame, (size_t)n * per_frame * sizeof(double), hipMemcpyHostToDevice));
+        forward_device<float>(h, d_pos, n, h->io_alpha.as<double>() + first * 9, nullptr, nullptr, h->exec_stream, first + n >= S);
+      }
+      HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
+      return;
     }
+    staged_forward(h, positions, S, h->io_alpha.as<double>(), true);
     HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
+  });
+}
+
+int rn_potgnn_calc_polarizabilities_to_device(rn_potgnn *h, const double *positions, int64_t S, double *d_alpha, void *stream) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !d_alpha))) {
+    set_error(h, "invalid positions / d_alpha / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  return guarded(h, [&]() {
+    staged_forward(h, positions, S, d_alpha, false);
+    // the caller's stream continues behind the evaluation (e.g. the RCCL all-gather of ramannoodle_amd.parallel)
+    if (!h->hstage.done) HIP_TRY(hipEventCreateWithFlags(&h->hstage.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->hstage.done, h->exec_stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->hstage.done, 0));
   });
 }
 
@@ -2605,13 +2727,11 @@ int rn_potgnn_calc_polarizabilities_async(rn_potgnn *h, const double *positions,
   }
   if (S == 0) return RN_OK;
   return guarded(h, [&]() {
-    if (!h->copy_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-      if (!h->exec_stream) HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
-      for (auto &sl : h->slots) {
-        HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-      }
+    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->exec_stream) HIP_TRY(hipStreamCreateWithFlags(&h->exec_stream, hipStreamNonBlocking));
+    for (auto &sl : h->slots) {  // (the streams may exist already: the synchronous host entry uses them too)
+      if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+      if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     auto &sl = h->slots[h->next_slot];
     h->next_slot ^= 1;

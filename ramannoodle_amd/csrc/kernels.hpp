@@ -145,6 +145,11 @@ void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
 // re-derived by each of its three consumers; x = hi + lo to 2^-25 absolute for |x| < 1 (tanh / Gaussian outputs).
 void launch_geom_rbf_pairs(const double *pos, int S, const Graph &g, const float *lattice, int lat_stride, const float *offsets,
                            float coef, Dims d, float *unit4, float *edge0, hipStream_t st);
+// The two float32 geometry kernels on positions that are float32 already (cast on the host while staging: bit-identical rows)
+void launch_geom_rbf_pos32(const float *pos, int S, const Graph &g, const float *lattice, int lat_stride, const float *offsets,
+                           float coef, Dims d, float *unit4, float *edge0, hipStream_t st, bool in_order);
+void launch_geom_rbf_pairs_pos32(const float *pos, int S, const Graph &g, const float *lattice, int lat_stride,
+                                 const float *offsets, float coef, Dims d, float *unit4, float *edge0, hipStream_t st);
 
 template <typename T>
 void launch_node_init(const T *table, int S, const Graph &g, Dims d, T *node,

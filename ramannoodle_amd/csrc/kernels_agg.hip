@@ -98,8 +98,11 @@ __device__ __forceinline__ T wrap_min_image(T d) {
   return (m > (T)0.5) ? m - 1 : m;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict__ pos, int S,
+// PT: the type the positions arrive in.  float32 evaluations cast them to float before any arithmetic (_gnn.py:709), so
+// positions that were cast on the host while staging (rn_potgnn_calc_polarizabilities: half the PCIe bytes) give
+// bit-identical rows.
+template <typename T, typename PT>
+__global__ __launch_bounds__(256) void geom_rbf_kernel(const PT *__restrict__ pos, int S,
                                                        Graph g, const T *__restrict__ lat_base,
                                                        int lat_stride,  // 0: one lattice; 9: one per frame
                                                        const T *__restrict__ offs, T coef,
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const double *__restrict_
     const int e = in_order ? g.in_edge[(int)(row % g.E)] : (int)(row % g.E);
     const int a = g.edge_a[e], b = g.edge_b[e];
     const T *lat = lat_base + (int64_t)s * lat_stride;  // _gnn.py:607-610: the sample's own lattice
-    const double *pa = pos + ((int64_t)s * g.N + a) * 3;
-    const double *pb = pos + ((int64_t)s * g.N + b) * 3;
+    const PT *pa = pos + ((int64_t)s * g.N + a) * 3;
+    const PT *pb = pos + ((int64_t)s * g.N + b) * 3;
     T f[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) f[k] = wrap_min_image((T)pb[k] - (T)pa[k]);
@@ -154,11 +157,19 @@ void launch_geom_rbf(const double *pos, int S, const Graph &g, const T *lattice,
                      const T *offsets, T coef, Dims d, T *unit4, T *edge0, hipStream_t st, bool in_order) {
   const int64_t total = (int64_t)S * g.E;
   if (total == 0) return;
-  geom_rbf_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride,
-                                                                      offsets, coef, d, unit4, edge0, in_order ? 1 : 0);
+  geom_rbf_kernel<T, double><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride,
+                                                                              offsets, coef, d, unit4, edge0, in_order ? 1 : 0);
+}
+void launch_geom_rbf_pos32(const float *pos, int S, const Graph &g, const float *lattice, int lat_stride,
+                           const float *offsets, float coef, Dims d, float *unit4, float *edge0, hipStream_t st, bool in_order) {
+  const int64_t total = (int64_t)S * g.E;
+  if (total == 0) return;
+  geom_rbf_kernel<float, float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride,
+                                                                                 offsets, coef, d, unit4, edge0, in_order ? 1 : 0);
 }
 // The same with the rows written as split-f16 pairs (kernels.hpp: launch_geom_rbf_pairs), FeP = 64
-__global__ __launch_bounds__(256) void geom_rbf_pairs_kernel(const double *__restrict__ pos, int S, Graph g,
+template <typename PT>
+__global__ __launch_bounds__(256) void geom_rbf_pairs_kernel(const PT *__restrict__ pos, int S, Graph g,
                                                              const float *__restrict__ lat_base, int lat_stride,
                                                              const float *__restrict__ offs, float coef, Dims d,
                                                              float *__restrict__ unit4, float *__restrict__ edge0) {
@@ -172,8 +183,8 @@ __global__ __launch_bounds__(256) void geom_rbf_pairs_kernel(const double *__res
     const int s = (int)(row / g.E), e = (int)(row % g.E);
     const int a = g.edge_a[e], b = g.edge_b[e];
     const float *lat = lat_base + (int64_t)s * lat_stride;
-    const double *pa = pos + ((int64_t)s * g.N + a) * 3;
-    const double *pb = pos + ((int64_t)s * g.N + b) * 3;
+    const PT *pa = pos + ((int64_t)s * g.N + a) * 3;
+    const PT *pb = pos + ((int64_t)s * g.N + b) * 3;
     float f[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) f[k] = wrap_min_image((float)pb[k] - (float)pa[k]);
@@ -212,8 +223,15 @@ void launch_geom_rbf_pairs(const double *pos, int S, const Graph &g, const float
                            float coef, Dims d, float *unit4, float *edge0, hipStream_t st) {
   const int64_t total = (int64_t)S * g.E;
   if (total == 0) return;
-  geom_rbf_pairs_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride, offsets, coef, d, unit4,
-                                                                         edge0);
+  geom_rbf_pairs_kernel<double><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride, offsets, coef, d,
+                                                                                 unit4, edge0);
+}
+void launch_geom_rbf_pairs_pos32(const float *pos, int S, const Graph &g, const float *lattice, int lat_stride, const float *offsets,
+                                 float coef, Dims d, float *unit4, float *edge0, hipStream_t st) {
+  const int64_t total = (int64_t)S * g.E;
+  if (total == 0) return;
+  geom_rbf_pairs_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(pos, S, g, lattice, lat_stride, offsets, coef, d,
+                                                                                unit4, edge0);
 }
 template void launch_geom_rbf<float>(const double *, int, const Graph &, const float *, int,
                                      const float *, float, Dims, float *, float *, hipStream_t, bool);

@@ -43,6 +43,11 @@ def all_gather_frames(local: torch.Tensor, num_items: int, group=None) -> torch.
     return torch.cat([blocks[r, : sizes[r]] for r in range(world)])
 
 
+def _wants_float64_default() -> bool:
+    """The reference evaluates in ``torch.get_default_dtype()`` (``_gnn.py:705-710``)."""
+    return torch.get_default_dtype() == torch.float64
+
+
 def _device_path(model, group) -> bool:
     """RCCL ranks with the device model: results stay in HBM from the kernels to the all-gather."""
     return dist.get_backend(group) == "nccl" and hasattr(model, "calc_polarizabilities_device")
@@ -62,9 +67,15 @@ def calc_polarizabilities_sharded(model, positions_batch: np.ndarray, group=None
         model._check_positions(positions_batch[:0])  # same shape errors as the host entry
         model.eval()
         device = torch.device("cuda", model.device_index)
-        block = torch.from_numpy(np.ascontiguousarray(positions_batch[lo:hi], dtype=np.float64)).to(device)
-        local = model.calc_polarizabilities_device(block) if hi > lo else torch.zeros((0, 3, 3), dtype=torch.float64,
-                                                                                    device=device)
+        if hi <= lo:
+            local = torch.zeros((0, 3, 3), dtype=torch.float64, device=device)
+        elif _wants_float64_default() or not hasattr(model, "calc_polarizabilities_to_device"):
+            block = torch.from_numpy(np.ascontiguousarray(positions_batch[lo:hi], dtype=np.float64)).to(device)
+            local = model.calc_polarizabilities_device(block)
+        else:
+            # the block's upload is pipelined with its kernels (cast to float32 while staged: _gnn.py:709), and the
+            # collective is ordered behind the evaluation on torch's stream
+            local = model.calc_polarizabilities_to_device(positions_batch[lo:hi])
         return all_gather_frames(local, total, group).cpu().numpy()
     local = model.calc_polarizabilities(positions_batch[lo:hi])
     tensor = torch.from_numpy(np.ascontiguousarray(local))

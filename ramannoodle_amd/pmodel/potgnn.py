@@ -371,7 +371,8 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         caller ran ``torch.set_default_dtype(torch.float64)``; ``torch.float64`` / ``numpy.float64``
         selects the kernels instantiated for ``double`` (``rn_potgnn_calc_polarizabilities_f64``)."""
         pos = self._check_positions(positions_batch)
-        self.eval()  # as the reference does (_gnn.py:686)
+        if self.training:  # as the reference does (_gnn.py:686); not walked again per call (the reference's unchanged
+            self.eval()    # Phonons loop makes 2 M calls of one structure each, dynamics/_phonon.py:93-106)
         out = np.empty((pos.shape[0], 3, 3), dtype=np.float64)
         handle = self._ensure_handle()
         if progress and pos.shape[0] > 0:
@@ -422,6 +423,24 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         if self._handle is not None:
             rc = _lib.load().rn_potgnn_wait(self._handle)
             _lib.check(rc, self._handle, "rn_potgnn_wait")
+
+    def calc_polarizabilities_to_device(self, positions_batch: NDArray[np.float64],
+                                        out: torch.Tensor | None = None) -> torch.Tensor:
+        """``calc_polarizabilities`` with the result left in HBM (``rn_potgnn_calc_polarizabilities_to_device``): host
+        ``float64[S,N,3]`` in, device ``float64[S,3,3]`` out, float32 arithmetic.  The upload is pipelined with the
+        kernels (positions cast to float32 while staged: bit-identical results, half the PCIe bytes); torch's current
+        stream is ordered behind the evaluation, so the tensor can go straight into a collective."""
+        pos = self._check_positions(positions_batch)
+        self.eval()
+        device = torch.device("cuda", self.device_index)
+        if out is None:
+            out = torch.empty((pos.shape[0], 3, 3), dtype=torch.float64, device=device)
+        handle = self._ensure_handle()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = _lib.load().rn_potgnn_calc_polarizabilities_to_device(handle, _ptr(pos), pos.shape[0],
+                                                                   C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, handle, "rn_potgnn_calc_polarizabilities_to_device")
+        return out
 
     def calc_polarizabilities_device(self, positions: torch.Tensor, out: torch.Tensor | None = None,
                                      synchronize: bool = False, dtype=None) -> torch.Tensor:

@@ -245,6 +245,37 @@ def test_device_resident_entry_point():
     np.testing.assert_array_equal(out.cpu().numpy(), model.calc_polarizabilities(g["pos_batch"]))
 
 
+@pytest.mark.parametrize("fixture", ["rocksalt64_parity", "rocksalt64_perf"])
+def test_host_entry_stages_float32_positions_bit_identically(fixture, monkeypatch):
+    """The host entry casts the caller's float64 positions to float32 while it stages them into page-locked memory and
+    sends them through in pieces (``rn_potgnn_calc_polarizabilities`` / ``..._to_device``).  The reference casts before
+    any arithmetic (``_gnn.py:709``), so every batch size and every piece size must give the bits of a float64 upload to
+    the device-resident entry -- for the narrow kernels (documented widths) and for the wide ones."""
+    g = load_golden(fixture)
+    rng = np.random.default_rng(12)
+    base = np.asarray(g["pos_batch"], dtype=np.float64)
+    pos = (base[rng.integers(0, base.shape[0], 301)] + 1e-3 * rng.standard_normal((301,) + base.shape[1:])) % 1.0
+    reference = product_model_from_golden(g).calc_polarizabilities_device(torch.tensor(pos, device="cuda"),
+                                                                          synchronize=True).cpu().numpy()
+    for piece in (None, "1", "7", "64", "1000"):
+        if piece is None:
+            monkeypatch.delenv("RN_POTGNN_HOST_PIECE", raising=False)
+        else:
+            monkeypatch.setenv("RN_POTGNN_HOST_PIECE", piece)
+        model = product_model_from_golden(g)
+        for count in (1, 5, 301):
+            np.testing.assert_array_equal(model.calc_polarizabilities(pos[:count]), reference[:count])
+        on_device = model.calc_polarizabilities_to_device(pos)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(on_device.cpu().numpy(), reference)
+        assert on_device.is_cuda and on_device.dtype == torch.float64
+    # a non-contiguous / float32 caller array goes through the same checks and conversion as before
+    np.testing.assert_array_equal(product_model_from_golden(g).calc_polarizabilities(pos[::2].astype(np.float32)),
+                                  product_model_from_golden(g).calc_polarizabilities_device(
+                                      torch.tensor(pos[::2].astype(np.float32).astype(np.float64), device="cuda"),
+                                      synchronize=True).cpu().numpy())
+
+
 def test_phonon_raman_tensors_float64_and_spectrum():
     from ramannoodle_amd.dynamics import Phonons
     g = load_golden("triclinic20")

@@ -1,15 +1,15 @@
-import sys, time
+"""The host boundary where callers use it: `PotGNN.calc_polarizabilities(numpy)` on the whole trajectory, on config 3's
+8-GPU share and one structure per call, each beside the HBM-resident rate of the same frames (bench.py host_boundary).
+usage: python tools/host_api_rate.py [perf|parity|tio2]"""
+import json
+import sys
 sys.path.insert(0, ".")
-import numpy as np, torch
-from bench import make_workload
-wl = make_workload(num_cells=(4, 4, 2), frames=10000, hparams="perf", seed=33)
+import bench
+
+which = sys.argv[1] if len(sys.argv) > 1 else "perf"
+if which == "tio2":
+    wl = bench.make_workload(frames=20_000, hparams="parity", seed=108, structure=bench.tio2_structure(), cutoff=2.0)
+else:
+    wl = bench.make_workload(num_cells=(4, 4, 2), frames=10000, hparams=which, seed=33)
 model = wl["model"](device=0)
-pos = wl["positions"]
-model.calc_polarizabilities(pos[:2000])
-for rep in range(3):
-    t = time.perf_counter(); a = model.calc_polarizabilities(pos); dt = time.perf_counter() - t
-    print("host numpy calc_polarizabilities: %.0f structures/s" % (len(pos) / dt))
-dpos = torch.as_tensor(pos, device="cuda")
-model.calc_polarizabilities_device(dpos, synchronize=True)
-t = time.perf_counter(); b = model.calc_polarizabilities_device(dpos, synchronize=True); torch.cuda.synchronize(); dt = time.perf_counter() - t
-print("device-resident: %.0f structures/s" % (len(pos) / dt), "equal:", np.array_equal(a, b.cpu().numpy()))
+print(which, json.dumps(bench.host_boundary(model, wl["positions"]), indent=1))

@@ -9,10 +9,23 @@ FRAMES = frames of the profiled bench step (--frames, or the config's default); 
 nothing else.  Of the instantiations of a kernel family the one that moved the most bytes is taken.  Units as
 profiles/pmc_traffic.py prints them (reads doubled as MI355X_MICROARCH.md prescribes for wide coalesced
 streams on gfx950)."""
+import hashlib
 import json
 import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# which source file a kernel family lives in: bench.py replays a record only while that file is unchanged
+SOURCE = {"narrow": "kernels_narrow.hip", "ps": "kernels_edge_ps.hip", "atom": "kernels_node_atom.hip",
+          "fused": "kernels_fused.hip", "agg": "kernels_agg.hip"}
+
+
+def stamp(family):
+    rel = os.path.join("ramannoodle_amd", "csrc", SOURCE[family])
+    data = open(os.path.join(ROOT, rel), "rb").read()
+    return {"file": rel, "git_blob": hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()}
+
 
 src, dst, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 n, e, fn, fe, frames, passes = (int(v) for v in sys.argv[4:10])
@@ -37,6 +50,7 @@ for kind, names in kernels.items():
                "source": f"{os.path.basename(src)}/pmc_traffic.txt: {launches} launches over {structures} structures x {passes} passes"}
         family = ("narrow" if ("narrow" in kernel or "tiled" in kernel) else "ps" if "block_ps" in kernel
                   else "atom" if "block_atom" in kernel else "fused" if ("fused" in kernel or "block2" in kernel) else "agg")
+        rec["kernel_source"] = stamp(family)
         json.dump(rec, open(os.path.join(dst, f"{prefix}{kind}_{family}_traffic.json"), "w"), indent=1)
         print(kind, "traffic", round(per), "B per structure and pass")
         break
@@ -49,6 +63,7 @@ for kind, names in kernels.items():
                    "source": f"{os.path.basename(src)}/sq_counters.txt"}
             family = ("narrow" if ("narrow" in line or "tiled" in line) else "ps" if "block_ps" in line
                       else "atom" if "block_atom" in line else "fused" if ("fused" in line or "block2" in line) else "agg")
+            rec["kernel_source"] = stamp(family)
             json.dump(rec, open(os.path.join(dst, f"{prefix}{kind}_{family}_issue.json"), "w"), indent=1)
             print(kind, "issue", valu + mfma)
             break
