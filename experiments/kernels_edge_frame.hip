@@ -34,7 +34,7 @@
 // The tile topology lives in LDS for the whole launch (the graph is the same in every
 // frame), so no load inside the frame loop has a dependent address.
 // (Round 5: moved here from kernels_fused.hip -- retired from the product build, see the note there.)
-#include "../fused_common.hpp"
+#include "../ramannoodle_amd/csrc/fused_common.hpp"
 
 namespace rn {
 

@@ -1,7 +1,7 @@
 // Opt-in experiment kernels of round 3 that measured level with or slower than the product kernels
 // (profiles/r03/edge2_experiment.txt, edge3_experiment.txt, node_tile_sweep.txt).  Compiled only with
 // -DRN_EXPERIMENTS=1 (RN_EXTRA_FLAGS=-DRN_EXPERIMENTS=1 bash build.sh); the product build carries none of them.
-#include "../fused_common.hpp"
+#include "../ramannoodle_amd/csrc/fused_common.hpp"
 
 namespace rn {
 

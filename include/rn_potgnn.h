@@ -372,7 +372,7 @@ int rn_md_raman_intensities_device(const double *d_alpha, int64_t S, int device,
  * that the weights allow beyond 3e4): the exact-f32 MFMA instantiations run instead.  Weight
  * matrices of any finite scale are fine: each is prescaled by a power of two into f16's range;
  * bit 7 = the library was built with -DRN_EXPERIMENTS=1 and carries the opt-in round-3 experiment kernels
- * (csrc/experiments/); only then can bit 5 (RN_POTGNN_EDGE2=1 at create time: frame-pipelined EdgeBlock,
+ * (experiments/ at the repository root); only then can bit 5 (RN_POTGNN_EDGE2=1 at create time: frame-pipelined EdgeBlock,
  * edge_block2_kernel + edge_c2_kernel) or bit 6 (RN_POTGNN_EDGE3=1: twelve-wave EdgeBlock, edge_block3_kernel +
  * edge_c2_kernel) be set.  The product build ignores those knobs.
  * bit 8 = every pass of a float32 evaluation takes the role-specialised fused EdgeBlock (edge_block_ps_kernel,
@@ -390,7 +390,7 @@ int rn_potgnn_config_flags(const rn_potgnn *h);
  * Host-only (no device is touched): the schedule check the library runs per atom tile before it lets the role-specialised
  * EdgeBlock (csrc/kernels_edge_ps.hip) take a graph.  rb[i], re[i] = first and end source row of destination i of the tile
  * (destinations sorted by atom, rows counted within the tile); back = rounds that may still read the ring when a step
- * rewrites it (2 or 3); ring_tiles = the ring's capacity in 16-row tiles (8; 7 for the GRAM instantiation).  Returns 1 when
+ * rewrites it (2 .. 5 in handles the library creates; 1 .. 8 accepted here); ring_tiles = the ring's capacity in 16-row tiles (8; 7 for the GRAM instantiation).  Returns 1 when
  * the producers' schedule holds (never more than two source tiles per step, no ring slot rewritten under a round in
  * flight), 0 when not, a negative rn_status on bad arguments; *window (optional) = the most tiles one round's source rows span.
  */

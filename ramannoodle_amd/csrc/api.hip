@@ -1026,7 +1026,8 @@ struct ChunkRun {
     const Dims d = h->d;
     const int nxt = cur ^ 1;
     const size_t per_frame = (size_t)g.E * (size_t)(6 * d.FeP) * sizeof(T);
-    const int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, ((size_t)1 << 30) / std::max<size_t>(per_frame, 1)));
+    int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, ((size_t)1 << 30) / std::max<size_t>(per_frame, 1)));
+    if (const char *e = getenv("RN_POTGNN_UNFUSED_BLOCK_FRAMES")) block = std::max(1, std::min(block, atoi(e)));  // test knob: several blocks on a small batch
     ln->fbA.ensure((size_t)block * g.E * 2 * d.FeP * sizeof(T));
     ln->fbB.ensure((size_t)block * g.E * 4 * d.FeP * sizeof(T));
     T *fa = ln->fbA.template as<T>(), *fb = ln->fbB.template as<T>();
@@ -1201,14 +1202,17 @@ void check_ps_fail(rn_potgnn *h) {
   if (fail == 0) return;
   HIP_TRY(hipMemset(h->ps_fail.p, 0, sizeof(int)));
   // (which wait: 1 = the producers' split sync, 2 = a producer waiting for round g - 2's P' / c2 rows to be taken,
-  //  3 = a producer waiting for round g - back - 1 to be finished, 4 = a consumer waiting for its round)
-  static const char *const which[5] = {
+  //  3 = a producer waiting for round g - back - 1 to be finished, 4 = a consumer waiting for its round,
+  //  6 = a consumer waiting for the earlier arrivals of its round parity before it adds its own to c_rd)
+  static const char *const which[7] = {
       "role-specialised EdgeBlock: a wait between producer and consumer waves timed out",
       "role-specialised EdgeBlock: the producers' split sync timed out",
       "role-specialised EdgeBlock: a producer's wait for the consumers to take the rows of an earlier round timed out",
       "role-specialised EdgeBlock: a producer's wait for the consumers to finish an earlier round (ring rows) timed out",
-      "role-specialised EdgeBlock: a consumer's wait for its round timed out"};
-  throw HipError{hipErrorLaunchFailure, which[fail >= 0 && fail <= 4 ? fail : 0]};
+      "role-specialised EdgeBlock: a consumer's wait for its round timed out",
+      "role-specialised EdgeBlock: a wait between producer and consumer waves timed out",
+      "role-specialised EdgeBlock: a consumer's round-ordered wait before releasing its ring rows (c_rd) timed out"};
+  throw HipError{hipErrorLaunchFailure, which[fail >= 0 && fail <= 6 ? fail : 0]};
 }
 
 template <typename T>
@@ -1752,8 +1756,8 @@ void train_backward(rn_potgnn *h, const T *dvec6, T *grads /* null: leave the gr
   Reverse<T> rv{S, 1, seeds.template as<T>(), nullptr, P.grad.template as<T>(), true};
   reverse_pass<T>(h, c, rv);
   HIP_TRY(hipStreamSynchronize(st));
+  h->train_S = 0;  // (the pending forward is consumed whether or not the check below throws)
   check_ps_fail(h);
-  h->train_S = 0;
   if (sizeof(T) == 4) h->grads_on_device = true;
   if (!grads) return;
   std::vector<T> gp(h->lay.total);
@@ -3150,7 +3154,8 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
     }
     float *w = P.weights.as<float>();
     launch_adam(w, P.grad.as<float>(), h->adam_m.as<float>(), h->adam_v.as<float>(),
-                h->trainable_mask.as<unsigned char>(), n, lr, beta1, beta2, eps, weight_decay, step, st);
+                h->trainable_mask.as<unsigned char>(), n, lr, beta1, beta2, eps, weight_decay, step, st,
+                (h->use_ps && h->ps_fail.p) ? h->ps_fail.as<int>() : nullptr);
     launch_refresh_derived(w, h->derived_ops.as<DerivedOp>(), h->derived_first_stage, st);
     launch_refresh_derived(w, h->derived_ops.as<DerivedOp>() + h->derived_first_stage, h->num_derived_ops - h->derived_first_stage, st);
     launch_setup<float>(w + L.emb, w + L.W2, w + L.b2, w + L.W4, w + L.b4, h->cfg.num_atom_types, h->d,
@@ -3190,11 +3195,15 @@ int rn_potgnn_adam_step(rn_potgnn *h, double lr, double beta1, double beta2, dou
         std::memcpy(h->packed.data() + seg[i], h->step_host + seg[i + 1], (size_t)seg[i + 2] * sizeof(float));
     }
     HIP_TRY(hipStreamSynchronize(st));
-    check_ps_fail(h);  // (the taped forward of this step ran the role-specialised EdgeBlock and nothing has looked since)
+    // The taped forward of this step ran the role-specialised EdgeBlock and nothing has looked at its time-out word since.  If it
+    // is set the Adam kernel has applied nothing (it reads the same word), so weights, moments and the host mirror are those of
+    // before the step; the gradients are void either way and the handle says so before the error leaves.
+    h->grads_on_device = false;
+    h->train_S = 0;
     h->host_stale = true;
     refresh_pass_flags<float>(h);
     refresh_mfma_mode(h);
-    h->grads_on_device = false;
+    check_ps_fail(h);
   });
 }
 

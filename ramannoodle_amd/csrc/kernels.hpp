@@ -41,7 +41,7 @@ struct Graph {
   int pt_num;
   const int *pt_begin;    // [pt_num+1] node ranges
   int pt_max_out_rows, pt_max_in_rows;
-  int pt_back;            // rounds that may still read the ring when a step rewrites it (2 or 3: edge_ps_tile_ok)
+  int pt_back;            // rounds that may still read the ring when a step rewrites it (2 .. 5: edge_ps_tile_ok, the largest the ring has room for)
   int pt_gram;            // 1: the GRAM instantiation (LayerNorm cross terms on the matrix pipe; a 7-tile ring + the Gram tables)
   // node tiles of the EdgeBlock reverse kernel (edge_bwd_tile2_kernel): small enough for TWO workgroups per CU
   int bt_num;
@@ -294,7 +294,7 @@ size_t edge_ps_lds_bytes(int tile_out_rows, int tile_in_rows, bool gram);
 int edge_ps_ring_tiles(bool gram);  // ring capacity in 16-row tiles
 int edge_ps_gram_window();          // source tiles a round's window may span in the GRAM instantiation
 // one tile's destinations (first and end source row of each, sorted by atom): does the producers' schedule hold?
-// `back`: rounds g - back .. g - 1 may still be reading the ring when the step of round g rewrites it (2 or 3); `ring`: its
+// `back`: rounds g - back .. g - 1 may still be reading the ring when the step of round g rewrites it (2 .. 5 in product handles); `ring`: its
 // capacity in tiles; `window` (optional, out): the most source tiles one round's window spans
 bool edge_ps_tile_ok(const int *rb, const int *re, int D, int back, int ring, int *window);
 // `fail`: device int, set to a nonzero code if a bounded spin wait inside the kernel ran out (never in a correct run)
@@ -353,7 +353,7 @@ struct DerivedOp {
 // (kind 2 entries that read a kind 3 result go into a second launch: blocks of one launch run concurrently)
 void launch_adam(float *w, const float *g, float *m, float *v, const unsigned char *trainable, size_t n,
                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
-                 hipStream_t st);
+                 hipStream_t st, const int *poisoned = nullptr /* device word: non-zero = apply nothing */);
 void launch_refresh_derived(float *w, const DerivedOp *ops, int num_ops, hipStream_t st);
 // staging[dst .. dst + n) = w[src .. src + n) for every (src, dst, n) of `seg` (kernels_train.hip)
 void launch_gather_segments(const float *w, const long long *seg, int nseg, float *staging, hipStream_t st);

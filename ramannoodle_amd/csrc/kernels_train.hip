@@ -16,9 +16,11 @@ namespace rn {
 __global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, const unsigned char *__restrict__ trainable, size_t n,
                             float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
-                            float bc2_sqrt) {
+                            float bc2_sqrt, const int *__restrict__ poisoned) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !trainable[i]) return;
+  // (poisoned: the role-specialised EdgeBlock's time-out word -- the gradients of such a step are NaN rows: nothing is applied,
+  //  and rn_potgnn_adam_step reports the time-out after its synchronisation)
+  if (i >= n || !trainable[i] || (poisoned && *poisoned != 0)) return;
   float grad = g[i];
   if (weight_decay != 0.0f) grad = fmaf(weight_decay, w[i], grad);
   const float mi = beta1 * m[i] + (1.0f - beta1) * grad;  // exp_avg.lerp_(grad, 1 - beta1)
@@ -32,12 +34,12 @@ __global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, 
 
 void launch_adam(float *w, const float *g, float *m, float *v, const unsigned char *trainable, size_t n,
                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
-                 hipStream_t st) {
+                 hipStream_t st, const int *poisoned) {
   if (n == 0) return;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   adam_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w, g, m, v, trainable, n, (float)lr, (float)beta1,
                                                           (float)beta2, (float)eps, (float)weight_decay,
-                                                          (float)bc1, (float)sqrt(bc2));
+                                                          (float)bc1, (float)sqrt(bc2), poisoned);
 }
 
 // Pieces of the packed blob the host looks at after a device-resident step (c3_norm_1's folded constants, the prescale /

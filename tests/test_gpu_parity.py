@@ -546,7 +546,7 @@ def test_repeated_evaluation_is_bit_identical(monkeypatch, edge_ps):
     workgroup a frame lands in.  Perf and parity widths; with the role-specialised EdgeBlock (the default, split
     products on the K = 32 f16 MFMA like every other kernel) and with ``RN_POTGNN_EDGE_PS=0``, which since round 5 hands
     the EdgeBlock of the fused pipeline to the unfused chain (the per-frame fused kernel that was NOT reproducible on the
-    K = 32 instruction is retired from the product build: ``csrc/experiments/kernels_edge_frame.hip``)."""
+    K = 32 instruction is retired from the product build: ``experiments/kernels_edge_frame.hip``)."""
     from bench import make_workload
     monkeypatch.setenv("RN_POTGNN_EDGE_PS", edge_ps)
     for hparams, frames in (("perf", 3000), ("parity", 3000)):
@@ -717,7 +717,7 @@ def test_every_width_up_to_16_takes_the_narrow_kernels(fn, fe):
 @pytest.mark.parametrize("knob, flag", [("RN_POTGNN_EDGE2", "pipelined_edge_block"), ("RN_POTGNN_EDGE3", "twelve_wave_edge_block")])
 @pytest.mark.parametrize("case, cutoff, fn, fe, frames", [("triclinic20", 3.4, 64, 64, 5), ("rocksalt64_parity", 3.2, 50, 40, 9)])
 def test_opt_in_edge_block_kernels_against_oracle(monkeypatch, knob, flag, case, cutoff, fn, fe, frames):
-    """Experiment builds only (csrc/experiments/, -DRN_EXPERIMENTS=1; skipped on the product library).
+    """Experiment builds only (experiments/, -DRN_EXPERIMENTS=1; skipped on the product library).
     The two restructured forms of the fused EdgeBlock that stay in the tree as measured alternatives
     (frame-pipelined: profiles/r03/edge2_experiment.txt; twelve waves with the c2 branch in its own kernel:
     profiles/r03/edge3_experiment.txt) compute the same thing as the default kernel: ragged and regular graph,
@@ -786,6 +786,36 @@ def test_fused_edge_block_against_oracle(monkeypatch, case, cutoff, fn, fe, pass
     std_got = (got - oracle.mean) / oracle.std
     std_want = (want - oracle.mean) / oracle.std
     assert _rel_err(std_got, std_want) < REL, (case, fn, fe)
+
+
+@pytest.mark.parametrize("knobs", [{}, {"RN_POTGNN_EDGE_PS": "0"}, {"RN_POTGNN_NO_FASTG": "1"}])
+def test_ring_refused_passes_run_the_unfused_edge_block_in_several_blocks(monkeypatch, knobs):
+    """A pass of the fused pipeline that the role-specialised EdgeBlock does not serve -- a graph its ring refuses (TiO2 at
+    5 A: 47 neighbours per atom), the kernel switched off, a pass without the folded gate scale -- takes the unfused EdgeBlock
+    block of frames by block of frames (``api.hip: edge_unfused_in_blocks``).  With the block forced to 3 frames a 7-frame batch
+    walks the multi-block branch (offsets into the node projections, the node rows and the edge rows): against the oracle,
+    and bit-equal to the same batch in one block."""
+    from oracle import potgnn_oracle as O
+    g = load_golden("tio2_notebook")
+    for key, value in knobs.items():
+        monkeypatch.setenv(key, value)
+    cutoff = 5.0 if not knobs else 2.0
+    rng = np.random.default_rng(9)
+    base = g["pos_batch"]
+    pos = base[rng.integers(0, len(base), size=7)] + rng.normal(scale=2e-3, size=(7,) + base.shape[1:])
+    results = {}
+    for block in ("3", None):
+        if block is None:
+            monkeypatch.delenv("RN_POTGNN_UNFUSED_BLOCK_FRAMES", raising=False)
+        else:
+            monkeypatch.setenv("RN_POTGNN_UNFUSED_BLOCK_FRAMES", block)
+        model, oracle = _random_model(g, cutoff, 64, 64, 2, seed=64064)
+        results[block] = model.calc_polarizabilities(pos)
+        flags = model.config_flags()
+        assert flags["fused_edge_block"] and not flags["role_split_edge_block"]
+    np.testing.assert_array_equal(results["3"], results[None])
+    want = O.calc_polarizabilities(oracle, pos, faithful=False)
+    assert _rel_err((results["3"] - oracle.mean) / oracle.std, (want - oracle.mean) / oracle.std) < REL
 
 
 @pytest.mark.parametrize("case", ["triclinic20", "rocksalt64_parity", "rocksalt64_perf"])

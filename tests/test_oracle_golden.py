@@ -120,3 +120,26 @@ def test_forward_on_positions_far_outside_the_unit_cell():
         np.testing.assert_allclose(O.forward(m, pos[i:i + 1], faithful=True).numpy()[0], r["forward"][i],
                                    rtol=0, atol=1e-5)
 
+
+
+def test_triplet_fixture_digests():
+    """The one unpinned point of the oracle: the ORDER of edge triplets is a restatement of
+    ``torch_geometric...dimenet.triplets``.  ``tools/check_triplets_with_pyg.py`` checks the fixtures' seven ``trip/*`` arrays
+    against a real torch_geometric wherever one is installed; this test keeps what that script would check from drifting:
+    the SHA-256 of every fixture's arrays is the committed one, and the oracle's ``triplets`` reproduces the arrays."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_triplets_with_pyg", os.path.join(root, "tools", "check_triplets_with_pyg.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    recorded = json.load(open(os.path.join(root, "tests", "golden", "triplet_hashes.json")))
+    seen = 0
+    for name, g in tool.fixtures():
+        assert recorded.get(name) == tool.digest(g), name
+        got = O.triplets(torch.as_tensor(g["ref_edge_indexes"][[1, 2]], dtype=torch.long), int(g["positions"].shape[0]))
+        for key, arr in zip(tool.KEYS, got):
+            np.testing.assert_array_equal(arr.numpy(), g["trip/" + key], err_msg=f"{name} trip/{key}")
+        seen += 1
+    assert seen == len(recorded) >= 5

@@ -104,6 +104,61 @@ def test_eight_rank_partition_of_the_baseline_configs(tmp_path):
     assert [shard_bounds(10_000, 8, r)[:2] for r in range(8)] == [(1250 * r, 1250 * (r + 1)) for r in range(8)]
 
 
+class _AnalyticModel(_Model):
+    """Stand-in with the device model's analytic entry: d(alpha)/d(r) contracted with the modes (`method="analytic"`)."""
+
+    def _check_raman_arguments(self, ref_positions, displacements, **kwargs):
+        if kwargs.get("method", "finite-difference") not in ("finite-difference", "analytic"):
+            raise ValueError("method")
+        if displacements.shape[1:] != ref_positions.shape:
+            raise ValueError("displacements has wrong shape")
+
+    def calc_raman_tensors(self, ref_positions, displacements, delta=1e-3, method="finite-difference"):
+        if method != "analytic":
+            return super().calc_raman_tensors(ref_positions, displacements, delta)
+        self.calls.append(("analytic", displacements.shape[0]))
+        v = displacements.reshape(displacements.shape[0], self.w.shape[0]) @ self.w * 2.0  # (plus - minus) / delta of a linear model
+        return v[:, [[0, 3, 4], [3, 1, 5], [4, 5, 2]]]
+
+
+def _analytic8_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, modes = 256, 768  # BASELINE config 4: 256 atoms, 768 modes
+        rng = np.random.default_rng(44)
+        ref = rng.uniform(size=(n, 3))
+        disp = rng.normal(size=(modes, n, 3))
+        model = _AnalyticModel(n)
+        tensors = calc_raman_tensors_sharded(model, ref, disp, method="analytic")
+        assert model.calls == [("analytic", 96)], model.calls  # this rank's block only: 768 modes / 8 ranks
+        np.save(os.path.join(out_dir, f"a{rank}.npy"), tensors)
+        # a bad argument raises on every rank before any collective
+        try:
+            calc_raman_tensors_sharded(model, ref, disp[:, :-1], method="analytic")
+        except ValueError:
+            np.save(os.path.join(out_dir, f"raised{rank}.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_analytic_raman_tensors_of_config4(tmp_path):
+    """`calc_raman_tensors_sharded(method="analytic")` at the N = 8 partition of BASELINE config 4 (768 modes of a 256-atom
+    cell -> 96 modes per rank, one all-gather of float64[96,3,3] blocks): every rank evaluates its block only and returns
+    all 768 tensors, equal to the single-process result."""
+    mp.spawn(_analytic8_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    rng = np.random.default_rng(44)
+    ref = rng.uniform(size=(256, 3))
+    disp = rng.normal(size=(768, 256, 3))
+    expect = _AnalyticModel(256).calc_raman_tensors(ref, disp, method="analytic")
+    for r in range(8):
+        got = np.load(tmp_path / f"a{r}.npy")
+        assert got.shape == (768, 3, 3)
+        np.testing.assert_allclose(got, expect, rtol=1e-12, atol=1e-12)
+        assert (tmp_path / f"raised{r}.npy").exists()
+
+
 def test_shard_bounds_cover_everything():
     for total in (0, 1, 7, 8, 10000):
         for world in (1, 2, 3, 8):
