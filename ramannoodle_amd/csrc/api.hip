@@ -1235,7 +1235,12 @@ void forward_device(rn_potgnn *h, const double *d_pos, int64_t S, double *d_alph
     return c;
   };
   int64_t done = 0;
-  const int chunk = chunk_frames<T>(h);
+  // Work chunks of EQUAL size: as many as the workspace demands, the frames split evenly among them (10 000 frames at a
+  // capacity of 2344: five launches of 2000 instead of four of 2344 and one of 624, whose persistent workgroups idle through
+  // a tail as long as a full launch's).  Results do not depend on the chunking (bit-identical: tests).
+  const int capacity = chunk_frames<T>(h);
+  const int64_t pieces = (S + capacity - 1) / capacity;
+  const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(capacity, (S + pieces - 1) / std::max<int64_t>(pieces, 1)));
   h->train_S = 0;  // lane 0's workspace is about to be overwritten: a pending train_forward is void
   while (done < S) {
     const int64_t left = S - done;
@@ -2587,7 +2592,7 @@ static void staged_forward(rn_potgnn *h, const double *positions, int64_t S, dou
   // overlapping it saves -- one piece 0.994 of the resident rate, two 0.97, three 0.95, four equal ones 0.93 (round 5, a pageable
   // float64 copy in front of the kernels: 0.76).  Longer batches overlap naturally: piece k + 1 is cast and copied under the
   // kernels of piece k.  RN_POTGNN_HOST_PIECE = frames per piece (the bit-identity test forces small ones).
-  int64_t fixed_piece = chunk;
+  int64_t fixed_piece = (S + ((S + chunk - 1) / chunk) - 1) / ((S + chunk - 1) / chunk);  // (equal pieces: forward_device's rule)
   if (const char *e = getenv("RN_POTGNN_HOST_PIECE")) fixed_piece = std::max<int64_t>(1, std::min<int64_t>(chunk, atoll(e)));
   std::vector<int64_t> pieces;
   for (int64_t left = S; left > 0; left -= pieces.back()) pieces.push_back(std::min<int64_t>(fixed_piece, left));

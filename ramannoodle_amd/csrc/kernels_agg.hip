@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void geom_rbf_kernel(const PT *__restrict__ po
     for (int j = 0; j < 4; ++j) {
       const int col = 4 * q + j;
       T x = dd - offs[col];
-      o.v[j] = (col < d.Fe) ? exp(coef * (x * x)) : (T)0;
+      if constexpr (sizeof(T) == 4)  // hardware exp2 (1 ulp), as geom_rbf_pairs_kernel: libm's expf made this write-bound kernel VALU-heavy
+        o.v[j] = (col < d.Fe) ? __builtin_amdgcn_exp2f((coef * 1.4426950408889634f) * (x * x)) : 0.0f;
+      else
+        o.v[j] = (col < d.Fe) ? exp(coef * (x * x)) : (T)0;
     }
     store4(edge0 + (r0 + r) * d.FeP + 4 * q, o);
   }

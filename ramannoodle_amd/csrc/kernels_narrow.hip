@@ -520,17 +520,17 @@ struct EdgeNarrowArgs {
 
 // LDS row stride (floats) of the source rows Q': 2 FE values (FE even), a multiple of 4 with an odd number of
 // 16-byte slots so that consecutive rows start on different bank groups
-__host__ __device__ constexpr int narrow_ldq(int fe) {
-  int s = (2 * fe + 3) / 4 * 4;
+__host__ __device__ constexpr int narrow_ldq(int fe, bool fold = false) {  // fold: one more float, |q|^2 / 2Fe
+  int s = (2 * fe + (fold ? 1 : 0) + 3) / 4 * 4;
   return ((s / 4) % 2 == 0) ? s + 4 : s;
 }
 struct NarrowLds {
   size_t bufQ, ints, total;
 };
-__host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD) {
+__host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD, bool fold = false) {
   NarrowLds L;
   L.bufQ = 0;
-  L.ints = ((size_t)maxR * narrow_ldq(fe) * 4 + 15) & ~size_t(15);
+  L.ints = ((size_t)maxR * narrow_ldq(fe, fold) * 4 + 15) & ~size_t(15);
   L.total = L.ints + ((2 * (size_t)maxR + 5 * (size_t)maxD) * 4 + 15 & ~size_t(15));
   return L;
 }
@@ -549,10 +549,14 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD) {
 // ~10 instructions per gate, 3 of them transcendental, where the one-column-per-instruction form of rounds 3-5
 // issued 18.4.  The variance is the plain sum of squares of z (zero mean by construction): no cross term, no |q|^2.
 // CLAMP = false when the host has proven the gate arguments small (PassW::c3_fast, api.hip refresh_pass_flags).
-template <int FN, int FE, bool CLAMP, bool PADDED, int NT>
-__global__ __launch_bounds__(NT, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
+// FOLD (opt-in, RN_POTGNN_NARROW_FOLD=1, needs CLAMP = false): the wide kernel's folded-scale loop -- c3_norm_1's scale times
+// the gate's exp2 factor multiplied into P' and Q' once per row, the variance from the cross term p.q (p / gamma^2 in 2 Fe more
+// registers, |q|^2 with the row): 14 packed multiplies less per triplet, 28 registers more (three waves per SIMD).
+template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false>
+__global__ __launch_bounds__(NT, FOLD ? 3 : 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
   static_assert(FE % 2 == 0, "column pairs");
-  constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE), H = FE / 2, W2 = 2 * FE;
+  static_assert(!(FOLD && CLAMP), "the folded loop has no clamp");
+  constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE, FOLD), H = FE / 2, W2 = 2 * FE;
   const cptr c3WeT = as_const(a.c3WeT), c3WnT = as_const(a.c3WnT), c3shift = as_const(a.c3shift),
              c2WT = as_const(a.c2WT), c2bias = as_const(a.c2bias), c3n1gs = as_const(a.c3n1gs),
              c3n1bs = as_const(a.c3n1bs), c3n2g = as_const(a.c3n2g), c3n2b = as_const(a.c3n2b),
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(NT, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
              c2n2b = as_const(a.c2n2b);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Graph &g = a.g;
-  const NarrowLds L = narrow_lds(FE, g.max_tile_out_rows, g.max_tile_in_rows);
+  const NarrowLds L = narrow_lds(FE, g.max_tile_out_rows, g.max_tile_in_rows, FOLD);
   float *bufQ = reinterpret_cast<float *>(smem_raw + L.bufQ);
   int *qb = reinterpret_cast<int *>(smem_raw + L.ints);
   const int maxD = g.max_tile_in_rows;
@@ -610,6 +614,14 @@ __global__ __launch_bounds__(NT, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
       gated_matvec2<FE, FE, FeP, 4 * FeP, 2 * FeP>(c3WeT, x, q);
       gated_matvec2<FN, FE, FeP, 6 * FeP, 0>(c3WnT, nb, q);
       float *row = bufQ + r * LDQ;  // [filter pairs | core pairs]: 2 FE floats
+      if constexpr (FOLD) {
+        row[W2] = sumsq2<2 * H>(q) * inv2n;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          q[j] *= ldw2(c3n1gs + 2 * j);
+          q[H + j] *= ldw2(c3n1gs + FeP + 2 * j);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         *reinterpret_cast<v2f *>(row + 2 * j) = q[j];
@@ -648,6 +660,46 @@ __global__ __launch_bounds__(NT, 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
       for (int j = 0; j < H; ++j) acc[j] = v2f{0.f, 0.f};
       const int cnt = d_cnt[i];
       const float *qr = bufQ + d_rb[i] * LDQ, *qskip = bufQ + d_skip[i] * LDQ;
+      if constexpr (FOLD) {
+        // p -> p gamma (added to the rows' q gamma), pd = p / gamma * (2 / 2Fe) (the cross term against q gamma)
+        v2f pd[2 * H];
+        const float spe = fmaf(sumsq2<2 * H>(p), inv2n, 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 2 * H; ++j) {
+          const v2f gam = ldw2(c3n1gs + (j < H ? 2 * j : FeP + 2 * (j - H)));
+          const v2f ig = {fast_rcp(gam.x), fast_rcp(gam.y)};
+          pd[j] = p[j] * ig * (2.0f * inv2n);
+          if (PADDED) {  // (rounded-up columns: gamma = 0 -> keep the exact zeros)
+            if (gam.x == 0.f) pd[j].x = 0.f;
+            if (gam.y == 0.f) pd[j].y = 0.f;
+          }
+          p[j] *= gam;
+        }
+        for (int t = 0; t < cnt; ++t) {
+          if (qr == qskip) qr += LDQ;
+          v2f zz[2 * H];
+          v2f d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < W2 / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * j);
+            d0 = fma2(pd[2 * j], v2f{v.x, v.y}, d0);
+            d1 = fma2(pd[2 * j + 1], v2f{v.z, v.w}, d1);
+            zz[2 * j] = v2f{v.x, v.y} + p[2 * j];
+            zz[2 * j + 1] = v2f{v.z, v.w} + p[2 * j + 1];
+          }
+          const float qq = qr[W2];
+          qr += LDQ;
+          d0 += d1;
+          const float ve = fmaxf((d0.x + d0.y) + (spe + qq), 1e-5f);
+          const v2f rstd2 = bcast2(fast_rsq(ve));
+#pragma unroll
+          for (int j = 0; j < H; ++j) {
+            const v2f yf = fma2(zz[j], rstd2, ldw2(c3n1bs + 2 * j));
+            const v2f yc = fma2(zz[H + j], rstd2, ldw2(c3n1bs + FeP + 2 * j));
+            acc[j] = gate2s<false>(yf, yc, acc[j]);
+          }
+        }
+      } else
       for (int t = 0; t < cnt; ++t) {
         if (qr == qskip) qr += LDQ;
         v2f zz[2 * H];
@@ -760,6 +812,99 @@ __global__ __launch_bounds__(256) void readout_narrow_kernel(ReadoutNarrowArgs a
   }
 }
 
+// ---------------------------------------------------------------------------- readout on the matrix pipe
+// The readout is the one dense MLP of the narrow pipeline whose rows are independent and plentiful (E per frame): three
+// [E,16] x [16,16] products.  readout_narrow_kernel above does them as 560 scalar FMAs per row and is VALU-bound (0.91
+// busy); here they go to the matrix pipe as EXACT float32 products (v_mfma_f32_16x16x4_f32: an fmaf chain, bit for bit),
+// which leaves the VALU the two ShiftedSoftplus epilogues and the tensor arithmetic.
+// Every layer is computed TRANSPOSED, H_next^T = W^T H^T, so that the result layout of one product is the operand layout of
+// the next and nothing is transposed in between: for a tile of 16 rows, lane (r = l % 16, q = l / 16) holds columns
+// 4q .. 4q + 3 of row r of every activation -- on input one 16-byte piece of the edge row as it sits in HBM; as the MFMA's
+// B operand its element kk is H[r][4q + kk]; the A operand is W[4q + kk][r] (twelve registers, loaded once); the result
+// D[4q + i][r] is H_next[r][4q + i].  The last layer's twelve outputs of a row therefore sit in lanes q = 0, 1, 2 of the row,
+// two tensor components each (closed form of R diag(p,q,q) R^-1, _gnn.py:372-415), summed per q over the 16-lane row.
+template <bool UNUSED = false>
+__global__ __launch_bounds__(256) void readout_narrow_mfma_kernel(ReadoutNarrowArgs a) {
+  constexpr int FeP = 16, HP = 32;
+  __shared__ float red[4][3][2];
+  __shared__ float fin[6];
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  // A operands: W[4q + kk][r] of the three layers (W0T [FeP][HP], W3T [HP][HP], W5T [HP][32]: k-major)
+  float w0[4], w3[4], w5[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    w0[kk] = a.w.W0T[(4 * q + kk) * HP + r];
+    w3[kk] = a.w.W3T[(4 * q + kk) * HP + r];
+    w5[kk] = a.w.W5T[(4 * q + kk) * 32 + r];
+  }
+  // the epilogues' per-column constants for this lane's four columns 4q + i
+  f32x4_t sc0, sh0, bb3, bb5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sc0[i] = a.w.scale0[4 * q + i];
+    sh0[i] = a.w.shift0[4 * q + i];
+    bb3[i] = a.w.b3[4 * q + i];
+    bb5[i] = a.w.b5[4 * q + i];
+  }
+  const int E = a.g.E, ntiles = (E + 15) / 16;
+  float a0 = 0.f, a1 = 0.f;
+  for (int t = wv; t < ntiles; t += 4) {
+    const int e = min(16 * t + r, E - 1);
+    const bool valid = 16 * t + r < E;
+    const int64_t row = (int64_t)s * E + e;
+    const f32x4_t x = *reinterpret_cast<const f32x4_t *>(a.edge + row * FeP + 4 * q);
+    const float4 u = *reinterpret_cast<const float4 *>(a.unit4 + row * 4);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[kk], x[kk], acc, 0, 0, 0);
+    f32x4_t h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = ssp_fast(fmaf(acc[i], sc0[i], sh0[i]));
+    acc = bb3;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[kk], h[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = ssp_fast(acc[i]);
+    acc = bb5;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w5[kk], h[kk], acc, 0, 0, 0);
+    if (a.pol && valid && q < 3) *reinterpret_cast<f32x4_t *>(a.pol + row * 32 + 4 * q) = acc;
+    // q = 0: xy <- (m0 - m1) ux uy, xz <- (m2 - m3) ux uz;  q = 1: yz <- (m4 - m5) uy uz, xx <- m7 + (m6 - m7) ux ux;
+    // q = 2: yy <- m9 + (m8 - m9) uy uy, zz <- m11 + (m10 - m11) uz uz
+    const float c0 = q == 0 ? u.x * u.y : (q == 1 ? u.y * u.z : u.y * u.y);
+    const float c1 = q == 0 ? u.x * u.z : (q == 1 ? u.x * u.x : u.z * u.z);
+    const float k0 = q == 2 ? 1.f : 0.f, k1 = (q == 1 || q == 2) ? 1.f : 0.f;
+    const float t0 = fmaf(acc[0] - acc[1], c0, k0 * acc[1]), t1 = fmaf(acc[2] - acc[3], c1, k1 * acc[3]);
+    if (valid && q < 3) {
+      a0 += t0;
+      a1 += t1;
+    }
+  }
+  a0 = lg_sum<16>(a0);  // over the 16 rows of this lane's q (one DPP row)
+  a1 = lg_sum<16>(a1);
+  if (r == 0 && q < 3) {
+    red[wv][q][0] = a0;
+    red[wv][q][1] = a1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int qq[6] = {1, 2, 2, 0, 0, 1}, slot[6] = {1, 0, 1, 0, 1, 0};  // component (xx,yy,zz,xy,xz,yz) -> (q, which accumulator)
+    const int c = threadIdx.x;
+    float v = (red[0][qq[c]][slot[c]] + red[1][qq[c]][slot[c]]) + (red[2][qq[c]][slot[c]] + red[3][qq[c]][slot[c]]);
+    v = v / (float)E;
+    fin[c] = v;
+    if (a.vec6) a.vec6[(int64_t)s * 6 + c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int map[9] = {0, 3, 4, 3, 1, 5, 4, 5, 2};  // dataset/torch/utils.py:30-37
+    const double v = (double)fin[map[threadIdx.x]];
+    if (a.alpha) a.alpha[(int64_t)s * 9 + threadIdx.x] = v * a.std9[threadIdx.x] + a.mean9[threadIdx.x];
+    if (a.alpha_raw) a.alpha_raw[(int64_t)s * 9 + threadIdx.x] = v;
+  }
+}
+
 // ============================================================================ launchers
 // Exact instantiations: the documented widths and those of the reference's own tests.  Everything else with
 // Fn, Fe <= 16 runs on the PADDED instantiation of its widths rounded up to multiples of four.
@@ -840,10 +985,10 @@ void launch_node_narrow(const float *edge, const float *node_in, float *node_out
 #undef X
 }
 
-template <int FN, int FE, bool CLAMP, bool PADDED, int NT>
+template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false>
 static void launch_edge_cfg_nt(const EdgeNarrowArgs &a, hipStream_t st) {
-  auto kern = &edge_narrow_kernel<FN, FE, CLAMP, PADDED, NT>;
-  const size_t lds = narrow_lds(FE, a.g.max_tile_out_rows, a.g.max_tile_in_rows).total;
+  auto kern = &edge_narrow_kernel<FN, FE, CLAMP, PADDED, NT, FOLD>;
+  const size_t lds = narrow_lds(FE, a.g.max_tile_out_rows, a.g.max_tile_in_rows, FOLD).total;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -857,7 +1002,7 @@ static void launch_edge_cfg_nt(const EdgeNarrowArgs &a, hipStream_t st) {
   }
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-  per_cu = std::min(per_cu, 16 * 64 / NT);  // (four waves per SIMD)
+  per_cu = std::min(per_cu, (FOLD ? 12 : 16) * 64 / NT);  // (four waves per SIMD; three with the folded loop's registers)
   int nsg = per_cu * cus / a.g.num_tiles;
   nsg = nsg < 1 ? 1 : (nsg > a.S ? a.S : nsg);
   kern<<<(unsigned)nsg * (unsigned)a.g.num_tiles, NT, lds, st>>>(a);
@@ -867,6 +1012,13 @@ static void launch_edge_cfg_nt(const EdgeNarrowArgs &a, hipStream_t st) {
 // the less a barrier between the source-row stage and the destination stage idles it.
 template <int FN, int FE, bool CLAMP, bool PADDED>
 static void launch_edge_cfg(const EdgeNarrowArgs &a, hipStream_t st) {
+  if constexpr (!CLAMP && !PADDED) {
+    static const bool fold = getenv("RN_POTGNN_NARROW_FOLD") && atoi(getenv("RN_POTGNN_NARROW_FOLD")) != 0;
+    if (fold) {
+      if (a.g.max_tile_in_rows <= 128 && a.g.max_tile_out_rows <= 128) return launch_edge_cfg_nt<FN, FE, false, false, 128, true>(a, st);
+      return launch_edge_cfg_nt<FN, FE, false, false, 256, true>(a, st);
+    }
+  }
   if (a.g.max_tile_in_rows <= 128 && a.g.max_tile_out_rows <= 128) launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 128>(a, st);
   else launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 256>(a, st);
 }
@@ -903,6 +1055,10 @@ void launch_readout_narrow(const float *edge, const float *unit4, int S, const G
                            double *alpha, double *alpha_raw, float *pol, hipStream_t st) {
   if (S == 0) return;
   ReadoutNarrowArgs a{edge, unit4, S, g, w, mean9, std9, vec6, alpha, alpha_raw, pol};
+  // the three layers on the exact-float32 MFMA (one kernel for every Fe <= 16: rounded-up rows and columns are exact zeros
+  // -- zero weights, BatchNorm fold and biases, ssp(0) = 0); RN_POTGNN_READOUT_MFMA=0: the scalar-FMA kernel
+  static const bool mfma = !(getenv("RN_POTGNN_READOUT_MFMA") && atoi(getenv("RN_POTGNN_READOUT_MFMA")) == 0);
+  if (mfma) return (void)(readout_narrow_mfma_kernel<><<<S, 256, 0, st>>>(a));
   // (rounded-up columns are exact zeros all the way: zero weights, BatchNorm fold and biases, ssp(0) = 0)
   if (d.Fe == 14) return (void)(readout_narrow_kernel<14><<<S, 256, 0, st>>>(a));
   if (d.Fe == 5) return (void)(readout_narrow_kernel<5><<<S, 256, 0, st>>>(a));
