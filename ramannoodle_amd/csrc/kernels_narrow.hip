@@ -262,6 +262,7 @@ __device__ __forceinline__ v2f tanh2(v2f x) {
   const v2f rc = {fast_rcp(e.x), fast_rcp(e.y)};
   return fma2(bcast2(-2.0f), rc, bcast2(1.0f));
 }
+typedef float v4f __attribute__((ext_vector_type(4)));
 // a row of F (even) real columns held as pairs -> WP floats in memory, the rest zeros.  (Non-temporal stores were tried
 // to keep the written rows out of the XCD's L2: the four 16-byte pieces of a row then reach HBM as separate partial
 // writes -- WRITE_SIZE doubles, profiles/r06/edge_narrow_experiments.txt.)
@@ -552,7 +553,12 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD, bool
 // FOLD (opt-in, RN_POTGNN_NARROW_FOLD=1, needs CLAMP = false): the wide kernel's folded-scale loop -- c3_norm_1's scale times
 // the gate's exp2 factor multiplied into P' and Q' once per row, the variance from the cross term p.q (p / gamma^2 in 2 Fe more
 // registers, |q|^2 with the row): 14 packed multiplies less per triplet, 28 registers more (three waves per SIMD).
-template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false>
+// STAGE (RN_POTGNN_NARROW_STAGE, tiles of at most NT destinations): the finished rows go to HBM through LDS -- every lane
+// parks its row in the (by then idle) Q' buffer and the workgroup stores the tile's contiguous block 16 bytes per lane,
+// whole lines per instruction, NON-TEMPORALLY: the rows an EdgeBlock writes are read next by another kernel a trajectory
+// chunk later, and kept out of the XCD's L2 they leave it to the rows this frame's other tiles are about to read a second
+// time (every edge row is read twice per pass: as a destination row by its b atom's tile, as a source row by its a atom's).
+template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false, bool STAGE = false>
 __global__ __launch_bounds__(NT, FOLD ? 3 : 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
   static_assert(FE % 2 == 0, "column pairs");
   static_assert(!(FOLD && CLAMP), "the folded loop has no clamp");
@@ -631,8 +637,13 @@ __global__ __launch_bounds__(NT, FOLD ? 3 : 2) void edge_narrow_kernel(EdgeNarro
     __syncthreads();
 
     // ================= destination edges: one lane each
-    for (int i = tid; i < dcount; i += NT) {
+    // (uniform trip count: the STAGE form has workgroup barriers behind the body)
+    for (int i0 = 0; i0 < dcount; i0 += NT) {
+      const int i = i0 + tid;
+      const bool active = i < dcount;
       const int64_t drow = erow0 + di0 + i;  // (b, a) order: the tile's destination rows are contiguous
+      v2f out[H];
+      if (active) {
       v2f p[2 * H], r[H];  // r = edge_d + c2
       {
         float x[FE], nj[FN], nk[FN];
@@ -718,11 +729,24 @@ __global__ __launch_bounds__(NT, FOLD ? 3 : 2) void edge_narrow_kernel(EdgeNarro
           acc[j] = gate2s<CLAMP>(yf, yc, acc[j]);
         }
       }
-      v2f c3[H], out[H];
+      v2f c3[H];
       ln_pairs<FE, PADDED>(acc, c3n2g, c3n2b, c3, fe_rt);
 #pragma unroll
       for (int j = 0; j < H; ++j) out[j] = tanh2(r[j] + c3[j]);
-      store_pairs<FE, FeP>(a.edge_out + drow * FeP, out);
+      }  // active
+      bool staged = false;
+      if constexpr (STAGE) {
+        if (dcount <= NT) {    // (uniform: one destination per lane, nobody comes back to the Q' rows)
+          staged = true;
+          __syncthreads();     // every lane's triplet loop is done
+          if (active) store_pairs<FE, FeP>(bufQ + i * FeP, out);
+          __syncthreads();     // the tile's rows are parked
+          float *dstblk = a.edge_out + (erow0 + di0) * FeP;
+          for (int idx = tid; idx < dcount * (FeP / 4); idx += NT)
+            __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(bufQ + 4 * idx), reinterpret_cast<v4f *>(dstblk + 4 * idx));
+        }
+      }
+      if (!staged && active) store_pairs<FE, FeP>(a.edge_out + drow * FeP, out);
     }
     __syncthreads();  // bufQ may be rewritten
   }
@@ -985,9 +1009,9 @@ void launch_node_narrow(const float *edge, const float *node_in, float *node_out
 #undef X
 }
 
-template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false>
+template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false, bool STAGE = false>
 static void launch_edge_cfg_nt(const EdgeNarrowArgs &a, hipStream_t st) {
-  auto kern = &edge_narrow_kernel<FN, FE, CLAMP, PADDED, NT, FOLD>;
+  auto kern = &edge_narrow_kernel<FN, FE, CLAMP, PADDED, NT, FOLD, STAGE>;
   const size_t lds = narrow_lds(FE, a.g.max_tile_out_rows, a.g.max_tile_in_rows, FOLD).total;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1019,8 +1043,13 @@ static void launch_edge_cfg(const EdgeNarrowArgs &a, hipStream_t st) {
       return launch_edge_cfg_nt<FN, FE, false, false, 256, true>(a, st);
     }
   }
-  if (a.g.max_tile_in_rows <= 128 && a.g.max_tile_out_rows <= 128) launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 128>(a, st);
-  else launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 256>(a, st);
+  static const bool stage = getenv("RN_POTGNN_NARROW_STAGE") && atoi(getenv("RN_POTGNN_NARROW_STAGE")) != 0;
+  if (a.g.max_tile_in_rows <= 128 && a.g.max_tile_out_rows <= 128) {
+    if (stage) launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 128, false, true>(a, st);
+    else launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 128>(a, st);
+  } else {
+    launch_edge_cfg_nt<FN, FE, CLAMP, PADDED, 256>(a, st);
+  }
 }
 
 void launch_edge_narrow(const float *edge_in, float *edge_out, const float *node, int S, const Graph &g, Dims d,
