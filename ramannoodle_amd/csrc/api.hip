@@ -147,7 +147,9 @@ struct Precision {
   std::vector<DeviceBuf> snap_node, snap_edge;
   // forward tape + cotangent workspace of the reverse pass (Jacobian d alpha / d r)
   std::vector<DeviceBuf> tape_node, tape_edge, tape_agg;
-  DeviceBuf bw[17];
+  DeviceBuf bw[18];
+  hipStream_t side = nullptr;  // weight-gradient products of the reverse pass run here, beside the cotangent chain
+  hipEvent_t ev_side[3] = {nullptr, nullptr, nullptr};
   DeviceBuf tn_arena;  // partial sums of the weight-gradient products (reverse_pass)
   DeviceBuf tape_z1, bn_stats, grad, seeds, mv, type_sums;  // training: pre-BatchNorm activations, batch sums, gradient blob
   bool tape_on = false;
@@ -1288,7 +1290,7 @@ struct Reverse {
   bool train_bn;
 };
 
-enum { DE0, DE1, DN0, DN1, DNX, DPQ, DNP3, DC2, DPROD, DBC1, DNPC1, DPOL, DUNIT, DH, POL, DOUT, BWN };
+enum { DE0, DE1, DN0, DN1, DNX, DPQ, DNP3, DC2, DPROD, DBC1, DNPC1, DPOL, DUNIT, DH, POL, DOUT, DPROD2, BWN };
 
 template <typename T>
 void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
@@ -1304,7 +1306,7 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
   const size_t sizes[BWN] = {ce * d.FeP, ce * d.FeP, cn * d.FnP, cn * d.FnP, cn * d.FnP,
                              ce * 4 * d.FeP, cn * 6 * d.FeP, ce * std::max(2 * d.FeP, HP), ce * d.FnP,
                              ce * 2 * d.FnP, cn * 2 * d.FnP, ce * 32, ce * 4, ce * HP, fe * 32,
-                             (size_t)C * 6};
+                             (size_t)C * 6, rv.grad ? fe * d.FnP : 0};
   T *b[BWN];
   for (int i = 0; i < BWN; ++i) {
     P.bw[i].ensure(sizes[i] * sizeof(T));
@@ -1349,6 +1351,31 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
       tn = &tn_store;
     }
   }
+
+  // The weight-gradient products dW^T = X^T dY of a pass hang off the cotangent chain: nothing reads them before the final
+  // reduction.  They run on a SIDE stream, ordered behind the kernel that produced their dY and joined before the next pass
+  // overwrites it (and before the reduction) -- small latency-bound launches under the chain's small latency-bound launches.
+  // (RN_POTGNN_TN_SIDE=0: in line on the chain's stream, as through round 5.)
+  static const bool want_side = !(getenv("RN_POTGNN_TN_SIDE") && atoi(getenv("RN_POTGNN_TN_SIDE")) == 0);
+  const bool overlap = G != nullptr && sizeof(T) == 4 && want_side;
+  hipStream_t sd = st;
+  if (overlap) {
+    if (!P.side) {
+      HIP_TRY(hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking));
+      for (auto &e : P.ev_side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    sd = P.side;
+  }
+  auto side_after_chain = [&](int which) {  // what the chain has enqueued so far precedes what the side stream gets next
+    if (!overlap) return;
+    HIP_TRY(hipEventRecord(P.ev_side[which], st));
+    HIP_TRY(hipStreamWaitEvent(sd, P.ev_side[which], 0));
+  };
+  auto chain_after_side = [&]() {  // ... and the other way round
+    if (!overlap) return;
+    HIP_TRY(hipEventRecord(P.ev_side[2], sd));
+    HIP_TRY(hipStreamWaitEvent(st, P.ev_side[2], 0));
+  };
 
   // ---- readout: recompute h1 (bufA), h2 (bufB), pol; then reverse
   const T *edgeP = P.tape_edge[NP].template as<T>();
@@ -1405,8 +1432,10 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     project(edge0, fe, d.FeP, w.c3_WeT, 4 * d.FeP, bufB, nullptr, 0, nullptr);
     project(nullptr, fe, d.FnP, w.c2_WT, 2 * d.FeP, bufA, w.c2_bias, 1, node1);
     // EdgeBlock
+    chain_after_side();  // (the previous pass's products have read the dY buffers this pass overwrites)
     launch_edge_bwd<T>(bufB, c.np3, bufA, edge1, P.tape_agg[p].template as<T>(), de_next, de_prev, b[DPQ],
                        b[DNP3], b[DC2], C, B, g, d, w, G ? &gw : nullptr, st);
+    side_after_chain(0);
     back_gemm(b[DPQ], ce, 4 * d.FeP, L.pass[p].c3_WeT, L.pass[p].t_c3We, d.FeP, de_prev, true);
     // node_{p+1} cotangent: incoming + projections + c2 operand
     // (accumulated in place: dn_next is dead once this pass's NodeBlock has consumed it)
@@ -1415,25 +1444,29 @@ void reverse_pass(rn_potgnn *h, ChunkRun<T> &c, const Reverse<T> &rv) {
     launch_prod_bwd<T>(b[DPROD], node1, dn_next, C, B, g, d, st);
     if (G) {
       const auto &q = L.pass[p];
-      launch_gemm_tn<T>(edge0, d.FeP, b[DPQ], 4 * d.FeP, ce, d.FeP, 4 * d.FeP, G + q.c3_WeT, 4 * d.FeP, nullptr, 0, nullptr, g, st, tn);
-      launch_gemm_tn<T>(node1, d.FnP, b[DNP3], 6 * d.FeP, cn, d.FnP, 6 * d.FeP, G + q.c3_WnT, 6 * d.FeP, G + q.c3_nshift, 0, nullptr, g, st, tn);
-      // (d prod is consumed: its buffer takes the c2 operand node[b]*node[a], read as plain rows)
-      launch_prod_fwd<T>(node1, b[DPROD], fe, g, d, st);
-      launch_gemm_tn<T>(b[DPROD], d.FnP, b[DC2], 2 * d.FeP, ce, d.FnP, 2 * d.FeP, G + q.c2_WT, 2 * d.FeP, G + q.c2_bias, 0, nullptr, g, st, tn);
+      launch_gemm_tn<T>(edge0, d.FeP, b[DPQ], 4 * d.FeP, ce, d.FeP, 4 * d.FeP, G + q.c3_WeT, 4 * d.FeP, nullptr, 0, nullptr, g, sd, tn);
+      launch_gemm_tn<T>(node1, d.FnP, b[DNP3], 6 * d.FeP, cn, d.FnP, 6 * d.FeP, G + q.c3_WnT, 6 * d.FeP, G + q.c3_nshift, 0, nullptr, g, sd, tn);
+      // the c2 operand node[b]*node[a], read as plain rows: into d prod's buffer once that is consumed -- or, beside the chain,
+      // into a buffer of its own
+      T *prod = overlap ? b[DPROD2] : b[DPROD];
+      launch_prod_fwd<T>(node1, prod, fe, g, d, sd);
+      launch_gemm_tn<T>(prod, d.FnP, b[DC2], 2 * d.FeP, ce, d.FnP, 2 * d.FeP, G + q.c2_WT, 2 * d.FeP, G + q.c2_bias, 0, nullptr, g, sd, tn);
     }
     // NodeBlock (needs bc1 = We edge_p, recomputed into bufA now that c2pre is consumed)
     project(edge0, fe, d.FeP, w.c1_WeT, 2 * d.FnP, bufA, nullptr, 0, nullptr);
     launch_node_bwd<T>(c.npc1, bufA, node1, dn_next, dn_prev, b[DBC1], b[DNPC1], C, B, g, d, w,
                        G ? &gw : nullptr, st);
+    side_after_chain(1);
     back_gemm(b[DBC1], ce, 2 * d.FnP, L.pass[p].c1_WeT, L.pass[p].t_c1We, d.FeP, de_prev, true);
     back_gemm(b[DNPC1], cn, 2 * d.FnP, L.pass[p].c1_WnT, L.pass[p].t_c1Wn, d.FnP, dn_prev, true);
     if (G) {
       const auto &q = L.pass[p];
-      launch_gemm_tn<T>(edge0, d.FeP, b[DBC1], 2 * d.FnP, ce, d.FeP, 2 * d.FnP, G + q.c1_WeT, 2 * d.FnP, nullptr, 0, nullptr, g, st, tn);
-      launch_gemm_tn<T>(node0, d.FnP, b[DNPC1], 2 * d.FnP, cn, d.FnP, 2 * d.FnP, G + q.c1_WnT, 2 * d.FnP, G + q.c1_bias, 0, nullptr, g, st, tn);
+      launch_gemm_tn<T>(edge0, d.FeP, b[DBC1], 2 * d.FnP, ce, d.FeP, 2 * d.FnP, G + q.c1_WeT, 2 * d.FnP, nullptr, 0, nullptr, g, sd, tn);
+      launch_gemm_tn<T>(node0, d.FnP, b[DNPC1], 2 * d.FnP, cn, d.FnP, 2 * d.FnP, G + q.c1_WnT, 2 * d.FnP, G + q.c1_bias, 0, nullptr, g, sd, tn);
     }
     cur ^= 1;
   }
+  chain_after_side();
   if (tn) launch_tn_reduce(*tn, st);
   if (G) {
     P.type_sums.ensure((size_t)h->cfg.num_atom_types * d.Fn * sizeof(T));
@@ -2538,6 +2571,12 @@ void rn_potgnn_destroy(rn_potgnn *h) {
     if (h->f64.lanes[l].stream) (void)hipStreamDestroy(h->f64.lanes[l].stream);
     if (h->f64.lanes[l].done) (void)hipEventDestroy(h->f64.lanes[l].done);
   }
+  if (h->f32.side) (void)hipStreamDestroy(h->f32.side);
+  if (h->f64.side) (void)hipStreamDestroy(h->f64.side);
+  for (int i = 0; i < 3; ++i) {
+    if (h->f32.ev_side[i]) (void)hipEventDestroy(h->f32.ev_side[i]);
+    if (h->f64.ev_side[i]) (void)hipEventDestroy(h->f64.ev_side[i]);
+  }
   for (auto &sl : h->slots) {
     if (sl.copied) (void)hipEventDestroy(sl.copied);
     if (sl.done) (void)hipEventDestroy(sl.done);
@@ -2562,7 +2601,8 @@ static void cast_to_float(const double *src, float *dst, size_t n) {
   auto run = [](const double *s, float *d, size_t m) {
     for (size_t i = 0; i < m; ++i) d[i] = (float)s[i];
   };
-  const size_t per_thread = (size_t)1 << 20;
+  const size_t per_thread = (size_t)1 << 17;  // (1 MiB of float64 per thread and more: a 1250-frame block of a trajectory that is
+                                              //  not in the CPU's caches casts at DRAM rate, ~1 ms on one core, 0.3 on four)
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const size_t nt = std::min<size_t>(std::min<size_t>(4, hw), n / per_thread);
   if (nt < 2) return run(src, dst, n);

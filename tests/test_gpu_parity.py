@@ -1371,7 +1371,10 @@ def test_bench_single_gpu_line_contract():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0 < roof["frac"] < 1
     assert roof["algorithmic_bytes_per_structure_pass"] == 4 * (256 * 64 + 2 * 4608 * 64)  # B_EB, SURVEY 8d
-    assert roof["traffic"] is not None and roof["issue_frac"] is not None   # committed records of this shape
+    # traffic / issue_frac replay committed PMC records -- but only records taken on the kernel source that is in this tree
+    # (bench.committed_profile; tests/test_host_logic.py::test_committed_profile_records_are_fresh keeps them so)
+    assert roof["traffic"] is not None and roof["issue_frac"] is not None and "profiles/r06" in roof["traffic_source"]
+    assert result["host_boundary"]["batch_1_latency_us_per_call"] > 0 and 0 < result["host_boundary"]["host_over_resident"] < 1.5
     cpu = result["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "structures/s"
     exact = result["exact_fp32_mfma"]

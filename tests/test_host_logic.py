@@ -570,3 +570,28 @@ def test_role_split_schedule_check_on_the_host():
     # TiO2 at 5 A: 47 out-edges per atom -- a round's window spans seven tiles, two rounds in flight need nine
     assert check(*_tile_rows(4, 47), 2, 8) == (False, 7) and check(*_tile_rows(4, 47), 2, 9)[0]
     assert lib.rn_potgnn_debug_ps_schedule(None, None, 0, 2, 8, None) < 0
+
+
+def test_committed_profile_records_are_fresh():
+    """`bench.py` prints `roofline.traffic` / `issue_frac` from PMC / SQ passes committed under profiles/rNN/ -- next to a
+    FRESH timing.  Every record carries the git blob hash of the kernel source it was taken on and is refused when that file
+    has changed since; this test fails as soon as a kernel edit leaves the newest records behind, so
+    that the profile is re-taken (tools/profile.sh + tools/make_profile_json.py) before the change is committed."""
+    import json
+    import bench
+    shapes = {"perf": (256, 4608, 64, 64), "parity": (256, 4608, 5, 14)}
+    for name, shape in (("edge_ps_traffic.json", "perf"), ("edge_ps_issue.json", "perf"), ("node_atom_traffic.json", "perf"),
+                        ("edge_narrow_traffic.json", "parity"), ("edge_narrow_issue.json", "parity"),
+                        ("node_narrow_traffic.json", "parity")):
+        rec = bench.committed_profile(name, *shapes[shape])
+        assert rec is not None, f"{name}: no record of this shape whose kernel source is the one in this tree"
+        assert rec["_path"].startswith("profiles/r06"), rec["_path"]
+    # a record without a stamp, or with a foreign one, is refused
+    stale = os.path.join(bench.ROOT, "profiles", "r05", "edge_ps_traffic.json")
+    assert "kernel_source" not in json.load(open(stale))
+    older = bench.PROFILE_ROUNDS
+    try:
+        bench.PROFILE_ROUNDS = ("r05",)
+        assert bench.committed_profile("edge_ps_traffic.json", 256, 4608, 64, 64) is None
+    finally:
+        bench.PROFILE_ROUNDS = older
