@@ -434,19 +434,51 @@ def test_full_size_properties():
     """Config 2 size (128 atoms, 18 neighbours, perf widths): properties that need no
     oracle -- chunk independence, lattice-translation invariance, symmetric output."""
     from bench import make_workload
-    wl = make_workload(num_cells=(4, 2, 2), frames=24, hparams="perf", seed=22)
+    wl = make_workload(num_cells=(4, 2, 2), frames=1000, hparams="perf", seed=22)  # BASELINE config 2 at its full size
     model = wl["model"](max_chunk_structures=0)
-    small = wl["model"](max_chunk_structures=5)
+    small = wl["model"](max_chunk_structures=37)
     pos = wl["positions"]
+    assert pos.shape == (1000, 128, 3) and model.num_edges == 2304
     a = model.calc_polarizabilities(pos)
     np.testing.assert_array_equal(a, small.calc_polarizabilities(pos))
     np.testing.assert_array_equal(a, np.swapaxes(a, 1, 2))
+    perm = np.random.default_rng(3).permutation(len(pos))
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos[perm]), a[perm])
     shift = np.random.default_rng(1).integers(-2, 3, size=(1,) + pos.shape[1:]).astype(np.float64)
-    b = model.calc_polarizabilities(pos + shift)
-    assert _rel_err(b, a) < REL
+    b = model.calc_polarizabilities(pos[:200] + shift)
+    assert _rel_err(b, a[:200]) < REL
     from oracle import potgnn_oracle as O
     orc = O.calc_polarizabilities(wl["oracle"](), pos[:2], faithful=False)
     assert _rel_err(a[:2], orc) < REL
+
+
+def test_config3_full_size_properties_at_the_documented_widths():
+    """BASELINE config 3's cell and trajectory at full size (256 atoms, 10 000 frames) on the reference's documented
+    hyper-parameters (Fn = 5, Fe = 14: the narrow kernels, edge rows in destination order): frames are independent -- a
+    permutation of the batch permutes the result bit-exactly, pieces give the bits of the whole whatever the work chunks --,
+    the host entry (float32 staging) and the device-resident entry (float64 positions) agree bit for bit, outputs are
+    symmetric and finite, lattice translations change nothing beyond float32 round-off, and the first frames match the
+    oracle."""
+    from bench import make_workload
+    from oracle import potgnn_oracle as O
+    wl = make_workload(num_cells=(4, 4, 2), frames=10_000, hparams="parity", seed=33)
+    model = wl["model"]()
+    pos = wl["positions"]
+    assert model.config_flags()["narrow_kernels"] and model.num_edges == 4608 and model.num_triplets == 78336
+    a = model.calc_polarizabilities(pos)
+    assert a.shape == (10_000, 3, 3) and np.isfinite(a).all()
+    np.testing.assert_array_equal(a, np.swapaxes(a, 1, 2))
+    perm = np.random.default_rng(7).permutation(len(pos))
+    np.testing.assert_array_equal(model.calc_polarizabilities(pos[perm]), a[perm])
+    pieces = np.concatenate([model.calc_polarizabilities(pos[lo:hi])
+                             for lo, hi in ((0, 1), (1, 778), (778, 4099), (4099, 10_000))])
+    np.testing.assert_array_equal(pieces, a)
+    resident = model.calc_polarizabilities_device(torch.tensor(pos, device="cuda"), synchronize=True).cpu().numpy()
+    np.testing.assert_array_equal(resident, a)
+    shift = np.random.default_rng(1).integers(-2, 3, size=(1,) + pos.shape[1:]).astype(np.float64)
+    assert _rel_err(model.calc_polarizabilities(pos[:500] + shift), a[:500]) < REL
+    assert np.abs(a - a.mean(axis=0)).max() > 1e2 * REL * np.abs(a).max()
+    assert _rel_err(a[:3], O.calc_polarizabilities(wl["oracle"](), pos[:3], faithful=False)) < REL
 
 
 def test_config3_full_size_properties():
@@ -1275,6 +1307,31 @@ def test_train_single_epoch_reduces_loss():
     # evaluation after training uses the updated weights and running statistics
     a = model.calc_polarizabilities(pos[:3])
     assert a.shape == (3, 3, 3) and np.isfinite(a).all()
+
+
+def test_config5_shape_epochs_learn_with_the_optimiser_on_the_device():
+    """BASELINE config 5 at its shape (256-atom cell, Fn = Fe = 64, P = 4, mini-batches of 32, synthetic teacher targets) and
+    a sixteenth of its size: three epochs over 768 structures through the reference's `train_single_epoch` with weights,
+    gradients and Adam moments resident in HBM -- the loop's return contract holds, the loss falls from epoch to epoch, and
+    the evaluation afterwards runs on the trained weights (the 50 000-structure epoch itself: profiles/r06/other_configs.txt)."""
+    from bench import make_workload, rocksalt
+    from ramannoodle_amd.dataset import PolarizabilityDataset
+    from ramannoodle_amd.pmodel import DeviceAdam, train_single_epoch
+    wl = make_workload((4, 4, 2), 768, "perf", seed=55)
+    teacher = wl["model"]()
+    alpha = teacher.calc_polarizabilities(wl["positions"])
+    lattice, _, zs = rocksalt(4, 4, 2)
+    ds = PolarizabilityDataset(lattice, zs, wl["positions"], alpha)
+    val = torch.utils.data.Subset(ds, range(128))
+    torch.manual_seed(1)
+    student = wl["model"]()
+    before = student.calc_polarizabilities(wl["positions"][:4])
+    opt = DeviceAdam(student, lr=1e-3)
+    losses = [train_single_epoch(student, ds, val, 32, opt, torch.nn.MSELoss()) for _ in range(3)]
+    assert all(np.isfinite(l[0]) and np.isfinite(l[1]) and l[2].shape == (6,) for l in losses)
+    assert losses[2][0] < losses[1][0] < losses[0][0], [l[0] for l in losses]
+    after = student.calc_polarizabilities(wl["positions"][:4])
+    assert np.isfinite(after).all() and np.abs(after - before).max() > 0
 
 
 def test_sharded_entry_points_keep_results_on_the_device():
