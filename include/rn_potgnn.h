@@ -209,6 +209,16 @@ int rn_potgnn_forward_samples(rn_potgnn *h, const double *lattices, const int32_
                               const double *positions, int64_t S, float *vec6);
 
 /*
+ * PotGNN.forward in evaluation mode as the reference computes it when the model was built under
+ * torch.set_default_dtype(torch.float64): its parameters are then float64 and forward computes in their dtype
+ * (_gnn.py:617-665, 493-494).  Every kernel instantiated for double (the float32 master weights widened exactly);
+ * lattices f64[S*9] or NULL, atom_types int32[S*N] or NULL as for rn_potgnn_forward_samples; vec6 host f64[S*6],
+ * standardised (xx,yy,zz,xy,xz,yz).
+ */
+int rn_potgnn_forward_samples_f64(rn_potgnn *h, const double *lattices, const int32_t *atom_types,
+                                  const double *positions, int64_t S, double *vec6);
+
+/*
  * The same on DEVICE buffers (PotGNN.forward with CUDA tensors: the reference returns its result on the device its
  * inputs live on, _gnn.py:617-665, test/tests/torch/test_gnn.py:130-160): d_lattices device f32[S*9] or NULL,
  * d_atom_types device int32[S*N] or NULL (already validated by the caller: entries in [0, num_atom_types)),

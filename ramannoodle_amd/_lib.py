@@ -60,6 +60,7 @@ SIGNATURES = {
     "rn_potgnn_forward": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_lattices": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "rn_potgnn_forward_samples": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
+    "rn_potgnn_forward_samples_f64": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
     "rn_potgnn_raman_tensors": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, _P]),
     "rn_potgnn_alpha_jacobian": (C.c_int, [_P, _P, C.c_int, _P]),
     "rn_potgnn_raman_tensors_analytic": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

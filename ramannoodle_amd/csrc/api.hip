@@ -2908,6 +2908,46 @@ int rn_potgnn_forward_samples(rn_potgnn *h, const double *lattices, const int32_
   });
 }
 
+int rn_potgnn_forward_samples_f64(rn_potgnn *h, const double *lattices, const int32_t *atom_types,
+                                  const double *positions, int64_t S, double *vec6) {
+  if (!h) return RN_ERR_INVALID_ARGUMENT;
+  if (S < 0 || (S > 0 && (!positions || !vec6))) {
+    set_error(h, "invalid positions / vec6 / S");
+    return RN_ERR_INVALID_ARGUMENT;
+  }
+  if (S == 0) return RN_OK;
+  const size_t SN = (size_t)S * h->cfg.num_atoms;
+  if (atom_types)
+    for (size_t i = 0; i < SN; ++i)
+      if (atom_types[i] < 0 || atom_types[i] >= h->cfg.num_atom_types) {
+        set_error(h, "atom type %d of sample %zu, atom %zu is outside [0,%d)", atom_types[i],
+                  i / h->cfg.num_atoms, i % h->cfg.num_atoms, h->cfg.num_atom_types);
+        return RN_ERR_INVALID_ARGUMENT;
+      }
+  return guarded(h, [&]() {
+    sync_host(h);  // the float64 copy of the weights is made from the host master copy
+    h->io_pos.ensure(SN * 3 * sizeof(double));
+    h->io_alpha.ensure((size_t)S * 9 * sizeof(double));
+    HIP_TRY(hipMemcpy(h->io_pos.p, positions, SN * 3 * sizeof(double), hipMemcpyHostToDevice));
+    if (lattices) {
+      h->io_lat.ensure((size_t)S * 9 * sizeof(double));
+      HIP_TRY(hipMemcpy(h->io_lat.p, lattices, (size_t)S * 9 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (atom_types) {
+      h->io_types.ensure(SN * sizeof(int32_t));
+      HIP_TRY(hipMemcpy(h->io_types.p, atom_types, SN * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    // the standardised tensor (what PotGNN.forward returns as a 6-vector) is the reduction's value before alpha * sigma + mu
+    forward_device<double>(h, h->io_pos.as<double>(), S, nullptr, nullptr, h->io_alpha.as<double>(), nullptr, true,
+                           lattices ? h->io_lat.as<double>() : nullptr, atom_types ? h->io_types.as<int>() : nullptr);
+    std::vector<double> raw((size_t)S * 9);
+    HIP_TRY(hipMemcpy(raw.data(), h->io_alpha.p, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int pick[6] = {0, 4, 8, 1, 2, 5};  // (xx, yy, zz, xy, xz, yz): dataset/torch/utils.py:44-60
+    for (int64_t s = 0; s < S; ++s)
+      for (int k = 0; k < 6; ++k) vec6[s * 6 + k] = raw[(size_t)s * 9 + pick[k]];
+  });
+}
+
 int rn_potgnn_raman_tensors(rn_potgnn *h, const double *ref_positions, const double *displacements,
                             int64_t M, double delta, double *raman) {
   if (!h) return RN_ERR_INVALID_ARGUMENT;

@@ -479,11 +479,14 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         topology is the reference structure's.  An atomic number the model has no atom type for raises
         ``IndexError``, as the reference's ``Embedding`` does.
 
-        Arithmetic: ``forward`` evaluates in float32 and returns a float32 tensor whatever ``torch.get_default_dtype()`` is
-        (evaluation and training mode, host and CUDA tensors alike) -- the reference computes in the dtype of its parameters,
-        float32 unless the caller changed torch's default before constructing the model.  The float64 instantiation of the
-        kernels is reached through ``calc_polarizabilities(..., dtype=torch.float64)`` (which follows the default dtype when
-        ``dtype`` is ``None``, ``_gnn.py:705-710``), ``calc_polarizabilities_device`` and ``train_gradients_f64``.
+        Arithmetic: the reference's ``forward`` computes in the dtype of the model's parameters (``_gnn.py:493-494``):
+        float32 unless the caller ran ``torch.set_default_dtype(torch.float64)`` before constructing the model.  So does this
+        one in EVALUATION mode: a model whose parameters are float64 (built under that default, or ``model.double()``) runs
+        the kernels instantiated for ``double`` (``rn_potgnn_forward_samples_f64``) and returns a float64 tensor; the device
+        keeps float32 master weights, so float64 parameters take part rounded to float32 (exact for a state dict that was
+        trained in float32).  In TRAINING mode ``forward`` evaluates in float32 whatever the parameters' dtype (the float64
+        step is ``train_gradients_f64``).  ``calc_polarizabilities(..., dtype=...)`` follows the default dtype when
+        ``dtype`` is ``None`` (``_gnn.py:705-710``), as does ``calc_polarizabilities_device``.
         An evaluation-mode ``forward`` (or any other evaluation) between a training-mode ``forward`` and its ``backward()``
         reuses the device workspace the pending step's tape refers to: run ``backward()`` first -- the backward of a step
         whose tape was overwritten raises ``ValueError`` ("needs a preceding train_forward").
@@ -499,7 +502,8 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
         if tuple(lat_t.shape) != (s, 3, 3) or tuple(zs_t.shape) != (s, self.num_atoms):
             raise ValueError("lattice / atomic_numbers do not match positions")
         on_device = pos_t.is_cuda or lat_t.is_cuda or zs_t.is_cuda
-        if on_device and not self.training:
+        model_f64 = (not self.training) and next(self.parameters()).dtype == torch.float64
+        if on_device and not self.training and not model_f64:
             return self._forward_on_device(lat_t, zs_t, pos_t)
         if on_device and self._device_training and getattr(self, "_dp_group", None) is None:
             # device-resident training on a device-resident batch: nothing crosses PCIe in either direction
@@ -527,8 +531,15 @@ class PotGNN(torch.nn.Module, PolarizabilityModel):  # pylint: disable=too-many-
             else:
                 out = _TrainStep.apply(self, pos, extra, *self.parameters())
             return out.to(out_device) if out_device is not None else out
-        out = np.empty((s, 6), dtype=np.float32)
         handle = self._ensure_handle()
+        if model_f64:  # the model's parameters are float64: evaluate in double, as the reference does
+            out64 = np.empty((s, 6), dtype=np.float64)
+            rc = _lib.load().rn_potgnn_forward_samples_f64(
+                handle, None if same_lattice else _ptr(lat), None if types is None else _ptr(types), _ptr(pos), s, _ptr(out64))
+            _lib.check(rc, handle, "rn_potgnn_forward_samples_f64")
+            result = torch.from_numpy(out64)
+            return result.to(out_device) if out_device is not None else result
+        out = np.empty((s, 6), dtype=np.float32)
         if same_lattice and same_species:
             rc = _lib.load().rn_potgnn_forward(handle, _ptr(pos), s, _ptr(out))
             _lib.check(rc, handle, "rn_potgnn_forward")

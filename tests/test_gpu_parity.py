@@ -155,6 +155,49 @@ def test_forward_with_per_sample_atomic_numbers():
         model.forward(torch.tensor(lat), torch.tensor(unknown), torch.tensor(pos))
 
 
+def test_forward_computes_in_the_dtype_of_the_models_parameters():
+    """The reference's ``forward`` computes in the dtype its parameters were built with (``_gnn.py:493-494, 617-665``): a
+    model constructed under ``torch.set_default_dtype(torch.float64)`` -- or turned with ``.double()`` -- evaluates in double.
+    Against the reference's own float64 ``forward`` outputs (fixtures made by the reference under that default): the plain
+    batch, a lattice per sample, species per sample; host tensors and CUDA tensors.  Tolerance 1e-7 of the largest output:
+    the device keeps float32 master weights and float32 Gaussian offsets (exactly widened), the reference under that default
+    builds its offsets in float64 -- measured 4e-8 here, against 1e-6 for the float32 kernels."""
+    F64 = 1e-7
+    g, r2, r3 = load_golden("triclinic20"), load_golden("triclinic20_r2"), load_golden("triclinic20_r3")
+    model32 = product_model_from_golden(g).eval()
+    torch.set_default_dtype(torch.float64)
+    try:
+        model = product_model_from_golden(g).eval()  # parameters float64, as the reference's under this default
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert next(model.parameters()).dtype == torch.float64 and next(model32.parameters()).dtype == torch.float32
+    s = r2["lat/positions"].shape[0]
+    zs_ref = torch.tensor(g["atomic_numbers"]).expand(s, -1)
+    out = model.forward(torch.tensor(r2["lat/lattices"]), zs_ref, torch.tensor(r2["lat/positions"]))
+    assert out.dtype == torch.float64 and not out.is_cuda
+    scale = np.abs(r2["lat/forward64"]).max()
+    assert np.abs(out.numpy() - r2["lat/forward64"]).max() < F64 * scale
+    out32 = model32.forward(torch.tensor(r2["lat/lattices"]), zs_ref, torch.tensor(r2["lat/positions"]))
+    assert out32.dtype == torch.float32 and np.abs(out32.numpy() - r2["lat/forward64"]).max() < REL * scale
+    assert np.abs(out32.numpy().astype(np.float64) - out.numpy()).max() > 0  # (two arithmetics: the test can tell them apart)
+    zs, lat, pos = r3["zs/atomic_numbers"], r3["zs/lattices"], r3["zs/positions"]
+    out = model.forward(torch.tensor(lat), torch.tensor(zs), torch.tensor(pos)).numpy()
+    assert np.abs(out - r3["zs/forward64"]).max() < F64 * np.abs(r3["zs/forward64"]).max()
+    if "f64/forward" in g.files:  # the fixture's own batch on the reference lattice and species
+        n = min(4, g["pos_batch"].shape[0])
+        plain = model.forward(torch.tensor(g["lattice"]).expand(n, 3, 3), torch.tensor(g["atomic_numbers"]).expand(n, -1),
+                              torch.tensor(g["pos_batch"][:n])).numpy()
+        assert np.abs(plain - g["f64/forward"][:n]).max() < F64 * np.abs(g["f64/forward"]).max()
+    # CUDA tensors in, a float64 CUDA tensor out
+    dev = model.forward(torch.tensor(lat, device="cuda"), torch.tensor(zs, device="cuda"), torch.tensor(pos, device="cuda"))
+    assert dev.is_cuda and dev.dtype == torch.float64
+    np.testing.assert_array_equal(dev.cpu().numpy(), out)
+    # .double() on a float32 model does the same, .float() brings the float32 kernels back
+    turned = product_model_from_golden(g).eval().double()
+    np.testing.assert_array_equal(turned.forward(torch.tensor(lat), torch.tensor(zs), torch.tensor(pos)).numpy(), out)
+    assert turned.float().forward(torch.tensor(lat), torch.tensor(zs), torch.tensor(pos)).dtype == torch.float32
+
+
 def test_calc_polarizabilities_in_float64(golden):
     """``calc_polarizabilities`` evaluates in ``torch.get_default_dtype()`` (``_gnn.py:705-710``):
     under a float64 default (or ``dtype=torch.float64``) the kernels instantiated for ``double`` run
