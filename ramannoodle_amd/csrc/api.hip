@@ -2638,6 +2638,12 @@ static void staged_forward(rn_potgnn *h, const double *positions, int64_t S, dou
   for (int64_t left = S; left > 0; left -= pieces.back()) pieces.push_back(std::min<int64_t>(fixed_piece, left));
   const int64_t piece = *std::max_element(pieces.begin(), pieces.end());
   auto &hs = h->hstage;
+  // A previous call through the to-device entry returned with its copies and kernels still enqueued: its staging buffers
+  // must have left the host before they are overwritten, and its kernels must have read their float32 positions before
+  // this call's copies land in the same device buffer.
+  for (int b = 0; b < 2; ++b)
+    if (hs.copied[b]) HIP_TRY(hipEventSynchronize(hs.copied[b]));
+  if (hs.done) HIP_TRY(hipStreamWaitEvent(h->copy_stream, hs.done, 0));
   if (hs.elems < (size_t)piece * per_frame) {
     for (int b = 0; b < 2; ++b) {
       if (hs.pin[b]) (void)hipHostFree(hs.pin[b]);
@@ -2670,6 +2676,8 @@ static void staged_forward(rn_potgnn *h, const double *positions, int64_t S, dou
     forward_device<float>(h, nullptr, n, d_alpha + first * 9, nullptr, nullptr, h->exec_stream, sync && first + n >= S,
                           nullptr, nullptr, d_pos32 + first * per_frame);
   }
+  if (!hs.done) HIP_TRY(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(hs.done, h->exec_stream));  // (everything this call enqueued, on every lane, precedes it)
   if (timing)
     fprintf(stderr, "[host timing] S=%lld pieces=%zu total %.0f us: cast %.0f, buffer waits %.0f, rest (enqueue%s) %.0f\n", (long long)S,
             pieces.size(), now() - t_begin, t_cast, t_wait, sync ? " + final sync" : "", now() - t_begin - t_cast - t_wait);
@@ -2744,8 +2752,6 @@ int rn_potgnn_calc_polarizabilities_to_device(rn_potgnn *h, const double *positi
   return guarded(h, [&]() {
     staged_forward(h, positions, S, d_alpha, false);
     // the caller's stream continues behind the evaluation (e.g. the RCCL all-gather of ramannoodle_amd.parallel)
-    if (!h->hstage.done) HIP_TRY(hipEventCreateWithFlags(&h->hstage.done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(h->hstage.done, h->exec_stream));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->hstage.done, 0));
   });
 }

@@ -288,6 +288,30 @@ def test_device_resident_entry_point():
     np.testing.assert_array_equal(out.cpu().numpy(), model.calc_polarizabilities(g["pos_batch"]))
 
 
+def test_narrow_kernels_do_not_depend_on_their_tiling(monkeypatch):
+    """The narrow EdgeBlock / NodeBlock (documented widths) give the same bits whatever the atom tiles: the default two-wave
+    tiles, four-wave tiles, tiles of 400 rows (several destinations per lane: the uniform-trip-count loop), one-atom tiles,
+    and the opt-in forms that only move data differently (rows to HBM through LDS; the scalar-FMA readout is a different
+    summation order and agrees to round-off, as does the folded-scale loop)."""
+    g = load_golden("rocksalt64_parity")
+    pos = np.concatenate([g["pos_batch"]] * 3)
+    base = product_model_from_golden(g).calc_polarizabilities(pos)
+    scale = np.abs(base).max()
+    for knobs, exact in (({"RN_POTGNN_NARROW_TILE_ROWS": "256"}, True), ({"RN_POTGNN_NARROW_TILE_ROWS": "400"}, True),
+                         ({"RN_POTGNN_NARROW_TILE_ROWS": "18"}, True), ({"RN_POTGNN_NODE_TILE_ROWS": "64"}, True),
+                         ({"RN_POTGNN_NODE_RING": "2"}, True), ({"RN_POTGNN_NARROW_STAGE": "1"}, True),
+                         ({"RN_POTGNN_READOUT_MFMA": "0"}, False), ({"RN_POTGNN_NARROW_FOLD": "1"}, False)):
+        for key, value in knobs.items():
+            monkeypatch.setenv(key, value)
+        got = product_model_from_golden(g).calc_polarizabilities(pos)
+        for key in knobs:
+            monkeypatch.delenv(key)
+        if exact:
+            np.testing.assert_array_equal(got, base, err_msg=str(knobs))
+        else:
+            assert np.abs(got - base).max() < 2e-6 * scale, knobs
+
+
 @pytest.mark.parametrize("fixture", ["rocksalt64_parity", "rocksalt64_perf"])
 def test_host_entry_stages_float32_positions_bit_identically(fixture, monkeypatch):
     """The host entry casts the caller's float64 positions to float32 while it stages them into page-locked memory and
@@ -312,6 +336,18 @@ def test_host_entry_stages_float32_positions_bit_identically(fixture, monkeypatc
         torch.cuda.synchronize()
         np.testing.assert_array_equal(on_device.cpu().numpy(), reference)
         assert on_device.is_cuda and on_device.dtype == torch.float64
+    # back-to-back calls that return before their work is done: every call's staging and device buffers are its own until
+    # its copies and kernels are through with them
+    monkeypatch.delenv("RN_POTGNN_HOST_PIECE", raising=False)
+    model = product_model_from_golden(g)
+    batches = [pos[::-1].copy(), pos.copy(), (pos[:150] + 0.25) % 1.0, pos[100:].copy()]
+    want = [model.calc_polarizabilities(b) for b in batches]
+    outs = [model.calc_polarizabilities_to_device(b) for b in batches]  # no synchronisation in between
+    mixed = model.calc_polarizabilities(pos)                              # ... and the synchronous entry right behind them
+    torch.cuda.synchronize()
+    for got, ref in zip(outs, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    np.testing.assert_array_equal(mixed, reference)
     # a non-contiguous / float32 caller array goes through the same checks and conversion as before
     np.testing.assert_array_equal(product_model_from_golden(g).calc_polarizabilities(pos[::2].astype(np.float32)),
                                   product_model_from_golden(g).calc_polarizabilities_device(
