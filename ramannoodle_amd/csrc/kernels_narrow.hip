@@ -6,15 +6,15 @@
 // on 4-lane groups and move the padding through HBM.  Here a whole row lives in ONE lane's registers:
 //   * no padding (compile-time Fn, Fe), no cross-lane reductions at all;
 //   * every weight is wave-uniform with a compile-time index, so the compiler keeps the weights in
-//     SGPRs (s_load_dwordx16 batches) and the projections are plain v_fma chains -- at K = 5..16 an
-//     MFMA tile would be mostly padding;
-//   * NodeBlock (_gnn.py:122-151): one lane per (frame, atom) walks the atom's in-edges in the
-//     reference's scatter order -- a streaming gather of 64-byte edge rows, no LDS, no barrier;
+//     SGPRs (s_load batches) and the projections are plain / packed fma chains -- at K = 5..16 an
+//     MFMA tile would be mostly padding (the exception is the readout MLP: below);
+//   * NodeBlock (_gnn.py:122-151): one WAVE per tile of atoms streams the tile's in-edge rows -- one contiguous
+//     block -- through its own LDS slot, one lane per row, one lane per atom for the sum; no barrier;
 //   * EdgeBlock (_gnn.py:200-351): tile-resident like the wide kernel (the source rows Q' of a
 //     tile's atoms are built once per frame in LDS and reused by every destination edge entering
-//     them), one lane per destination edge, two barriers per frame;
+//     them), one lane per destination edge, two columns per packed-f32 instruction, two barriers per frame;
 //   * readout MLP + edge tensors + per-structure mean (_gnn.py:532-539, 354-415, 658-665) in one
-//     launch, one workgroup per frame, fixed summation order (deterministic).
+//     launch, one workgroup per frame, the three layers on the exact-float32 MFMA, fixed summation order.
 // Embeddings keep the padded [rows][16] float layout of the other kernels; padded columns are written as exact zeros.
 // EDGE ROWS ARE IN (b, a) ORDER in this pipeline (row i of a frame = edge Graph::in_edge[i]; geom_rbf_kernel writes them
 // so, rn_potgnn_debug_stage undoes it): everything that belongs to an atom tile -- the in-edge rows the NodeBlock sums, the
@@ -274,11 +274,6 @@ __device__ __forceinline__ void store_pairs(float *p, const v2f (&x)[F / 2]) {
     const v2f b = 2 * j + 1 < F / 2 ? x[2 * j + 1 < F / 2 ? 2 * j + 1 : 0] : v2f{0.f, 0.f};
     *reinterpret_cast<float4 *>(p + 4 * j) = make_float4(a.x, a.y, b.x, b.y);
   }
-}
-template <int F>
-__device__ __forceinline__ void unpack_pairs(const v2f (&x)[pairs_of<F>()], float (&out)[F]) {
-#pragma unroll
-  for (int k = 0; k < F; ++k) out[k] = (k & 1) ? x[k / 2].y : x[k / 2].x;
 }
 
 }  // namespace

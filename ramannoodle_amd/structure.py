@@ -21,7 +21,8 @@ def apply_pbc(positions: NDArray[np.float64]) -> NDArray[np.float64]:
     the time the GPU needs to evaluate those frames), so arrays take ``floor``; everything else takes the reference's
     expression, with its exceptions."""
     if isinstance(positions, np.ndarray) and positions.dtype.kind == "f":
-        return positions - np.floor(positions)
+        wrapped = np.floor(positions)
+        return np.subtract(positions, wrapped, out=wrapped)  # (one temporary, not two: the arrays are trajectories)
     try:
         return positions - positions // 1
     except TypeError as exc:
