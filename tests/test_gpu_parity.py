@@ -1485,6 +1485,8 @@ def test_bench_two_ranks_contract(tmp_path):
     assert result["value"] == pytest.approx(2 * 96 * 2 / (result["ms_per_step"] * 2e-3), rel=1e-6)
     assert result["roofline"]["launches"] > 0 and result["unit"] == "structures/s"
     assert "128 atoms" in result["config"]["workload"]
+    # N > 1 extra: the same step from the caller's host array (every rank uploads its block through the staging entry)
+    assert 0 < result["host_inclusive_structures_per_s"] < 1.5 * result["value"]
 
 
 def test_bench_single_gpu_line_contract():
