@@ -548,13 +548,16 @@ __host__ __device__ inline NarrowLds narrow_lds(int fe, int maxR, int maxD, bool
 // FOLD (opt-in, RN_POTGNN_NARROW_FOLD=1, needs CLAMP = false): the wide kernel's folded-scale loop -- c3_norm_1's scale times
 // the gate's exp2 factor multiplied into P' and Q' once per row, the variance from the cross term p.q (p / gamma^2 in 2 Fe more
 // registers, |q|^2 with the row): 14 packed multiplies less per triplet, 28 registers more (three waves per SIMD).
+#ifndef RN_NARROW_WAVES
+#define RN_NARROW_WAVES 2  // waves per SIMD the register allocation aims at least for (2: whatever fits <= 128 VGPRs = four waves)
+#endif
 // STAGE (RN_POTGNN_NARROW_STAGE, tiles of at most NT destinations): the finished rows go to HBM through LDS -- every lane
 // parks its row in the (by then idle) Q' buffer and the workgroup stores the tile's contiguous block 16 bytes per lane,
 // whole lines per instruction, NON-TEMPORALLY: the rows an EdgeBlock writes are read next by another kernel a trajectory
 // chunk later, and kept out of the XCD's L2 they leave it to the rows this frame's other tiles are about to read a second
 // time (every edge row is read twice per pass: as a destination row by its b atom's tile, as a source row by its a atom's).
 template <int FN, int FE, bool CLAMP, bool PADDED, int NT, bool FOLD = false, bool STAGE = false>
-__global__ __launch_bounds__(NT, FOLD ? 3 : 2) void edge_narrow_kernel(EdgeNarrowArgs a) {
+__global__ __launch_bounds__(NT, FOLD ? 3 : RN_NARROW_WAVES) void edge_narrow_kernel(EdgeNarrowArgs a) {
   static_assert(FE % 2 == 0, "column pairs");
   static_assert(!(FOLD && CLAMP), "the folded loop has no clamp");
   constexpr int FnP = 16, FeP = 16, LDQ = narrow_ldq(FE, FOLD), H = FE / 2, W2 = 2 * FE;
@@ -1021,7 +1024,7 @@ static void launch_edge_cfg_nt(const EdgeNarrowArgs &a, hipStream_t st) {
   }
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-  per_cu = std::min(per_cu, (FOLD ? 12 : 16) * 64 / NT);  // (four waves per SIMD; three with the folded loop's registers)
+  per_cu = std::min(per_cu, (FOLD ? 12 : (RN_NARROW_WAVES >= 5 ? 20 : 16)) * 64 / NT);  // (four waves per SIMD; three with the folded loop's registers)
   int nsg = per_cu * cus / a.g.num_tiles;
   nsg = nsg < 1 ? 1 : (nsg > a.S ? a.S : nsg);
   kern<<<(unsigned)nsg * (unsigned)a.g.num_tiles, NT, lds, st>>>(a);
