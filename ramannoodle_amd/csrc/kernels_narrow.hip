@@ -1025,6 +1025,8 @@ static void launch_edge_cfg_nt(const EdgeNarrowArgs &a, hipStream_t st) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   per_cu = std::min(per_cu, (FOLD ? 12 : (RN_NARROW_WAVES >= 5 ? 20 : 16)) * 64 / NT);  // (four waves per SIMD; three with the folded loop's registers)
+  static const int wg_cap = getenv("RN_POTGNN_NARROW_WGS") ? std::max(1, atoi(getenv("RN_POTGNN_NARROW_WGS"))) : 0;  // experiment knob: workgroups per CU
+  if (wg_cap > 0) per_cu = std::min(per_cu, wg_cap);
   int nsg = per_cu * cus / a.g.num_tiles;
   nsg = nsg < 1 ? 1 : (nsg > a.S ? a.S : nsg);
   kern<<<(unsigned)nsg * (unsigned)a.g.num_tiles, NT, lds, st>>>(a);
