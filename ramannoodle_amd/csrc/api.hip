@@ -214,6 +214,8 @@ struct rn_potgnn {
     size_t elems = 0;  // floats per buffer
     hipEvent_t copied[2] = {nullptr, nullptr};
     hipEvent_t done = nullptr;
+    char *out_pin = nullptr;  // the result (+ the EdgeBlock's time-out word) of the synchronous host entry
+    size_t out_bytes = 0;
   } hstage;
   int last_chunk_structs = 0;
   int train_S = 0;  // frames of the pending train_forward (0 = none)
@@ -2592,6 +2594,7 @@ void rn_potgnn_destroy(rn_potgnn *h) {
     if (h->hstage.copied[b]) (void)hipEventDestroy(h->hstage.copied[b]);
   }
   if (h->hstage.done) (void)hipEventDestroy(h->hstage.done);
+  if (h->hstage.out_pin) (void)hipHostFree(h->hstage.out_pin);
   delete h;
 }
 
@@ -2737,8 +2740,28 @@ int rn_potgnn_calc_polarizabilities(rn_potgnn *h, const double *positions, int64
       HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
       return;
     }
-    staged_forward(h, positions, S, h->io_alpha.as<double>(), true);
-    HIP_TRY(hipMemcpy(alpha, h->io_alpha.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    // ONE synchronisation per call: the result and the role-specialised EdgeBlock's time-out word come down into page-locked
+    // memory behind the kernels (a blocking hipMemcpy each, after a stream synchronisation of its own, was 30 of the ~450 us
+    // of a one-structure call: the reference's unchanged Phonons loop makes 2 M of those, dynamics/_phonon.py:93-106)
+    staged_forward(h, positions, S, h->io_alpha.as<double>(), false);
+    auto &hs = h->hstage;
+    const size_t out_bytes = (size_t)S * 9 * sizeof(double);
+    if (hs.out_bytes < out_bytes + 16) {
+      if (hs.out_pin) (void)hipHostFree(hs.out_pin);
+      hs.out_pin = nullptr;
+      hs.out_bytes = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hs.out_pin), out_bytes + 16, hipHostMallocDefault));
+      hs.out_bytes = out_bytes + 16;
+    }
+    int *fail_pin = reinterpret_cast<int *>(hs.out_pin + out_bytes);
+    *fail_pin = 0;
+    HIP_TRY(hipMemcpyAsync(hs.out_pin, h->io_alpha.p, out_bytes, hipMemcpyDeviceToHost, h->exec_stream));
+    const bool watch = h->use_ps && h->ps_fail.p;
+    if (watch) HIP_TRY(hipMemcpyAsync(fail_pin, h->ps_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->exec_stream));
+    HIP_TRY(hipStreamSynchronize(h->exec_stream));
+    resolve_timers(h);
+    if (watch && *fail_pin != 0) check_ps_fail(h);  // (reads the word again, clears it and throws)
+    std::memcpy(alpha, hs.out_pin, out_bytes);
   });
 }
 
